@@ -1,0 +1,449 @@
+// DSKD loss 2 (`decode_v1`): dynamically semantic-guided feature-map distillation, forward
+// value and the gradient with respect to the student query embeddings.
+//
+// Replaces the level x image x box Python loop of
+// mmdet/models/dense_heads/gfl_deformable_detr_head_il.py:664-718 plus
+// KnowledgeDistillationKLDivLoss (mmdet/models/losses/kd_loss.py:10-43, T=2, 'sum').
+// Reference semantics kept exactly:
+//  * box k (teacher score order, images concatenated) is paired with the k-th student query
+//    (ascending flattened index) whose last-layer label is a previous-task label;
+//    m_k = softmax_c(|hs_t[keepid[k]] - hs_s[id_pred[k]]|);
+//  * per level the box is mapped with the UN-padded image size, floor/ceil to the grid,
+//    EXCLUSIVE ends, later boxes overwrite earlier ones ("owner" = last covering box);
+//  * pred = F_teacher * Mask, target = F_student * Mask (detached); softmax / log-softmax /
+//    mean run over dim=1 of a [C,H,W] tensor, i.e. over H;  value = T^2/H * KL summed over
+//    (c, w), summed over levels and images, divided by B;
+//  * the gradient reaches only hs_s (through Mask on the pred side).
+//
+// MI355X mapping.  The reference materialises [B,C,H,W] masks and runs ~10 launches per box
+// and a KL chain per (level, image).  Here:
+//   fgkd_pairs   1 block: ordered compaction of the paired student rows + the M softmaxes
+//   fgkd_owner   owner map per pixel (int16), one thread per pixel
+//   fgkd_kl      one workgroup per (level, image, channel, 64-column strip): both feature
+//                strips are read from HBM exactly ONCE with coalesced 256-B row segments,
+//                parked in LDS (<= 51 KB at 100 rows), the per-column online-softmax
+//                statistics give the KL in the same sweep, and the second sweep (the
+//                gradient w.r.t. the mask, accumulated per owner box) runs out of LDS.
+//                HBM-bound: algorithmic bytes = 2 * sum(HW) * C * 4 per image (45.5 MB).
+//   fgkd_finish  softmax/abs backward into the dense grad_hs_s, fixed-order loss reduction
+#include "common.h"
+#include <vector>
+
+namespace dskd {
+namespace {
+
+constexpr int kMaxLevels = 8;
+constexpr int kStrip = 64;     // columns per workgroup
+constexpr int kRowGroups = 4;  // waves per workgroup; wave g owns rows h % 4 == g
+constexpr int kMaxBoxes = 1024;  // per image (LDS accumulators)
+
+struct FgLevels {
+  const float* fs[kMaxLevels];
+  const float* ft[kMaxLevels];
+  int H[kMaxLevels];
+  int W[kMaxLevels];
+  int tiles[kMaxLevels];       // strips per row
+  int blk_start[kMaxLevels + 1];  // first fgkd_kl block of the level
+  long long own_start[kMaxLevels];  // first owner-map element of the level
+};
+
+constexpr int kMaxImages = 64;
+struct FgImages {            // small per-image tables, passed by value (kernel arguments)
+  int box_start[kMaxImages + 1];
+  float img_hw[2 * kMaxImages];
+};
+
+struct FgWs {
+  float* m;        // [M, D] softmax masks
+  float* gm;       // [M, D] d loss / d m
+  int* id_pred;    // [M]
+  float* partial;  // [nblocks] loss partials
+  short* owner;    // [sum_l B*H_l*W_l]
+};
+
+inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+FgWs carve(void* ws, int M, int D, long long nblocks, size_t* total) {
+  FgWs w;
+  char* p = (char*)ws;
+  size_t off = 0;
+  w.m = (float*)(p + off); off += align_up(sizeof(float) * (size_t)M * D);
+  w.gm = (float*)(p + off); off += align_up(sizeof(float) * (size_t)M * D);
+  w.id_pred = (int*)(p + off); off += align_up(sizeof(int) * (size_t)(M + 1));
+  w.partial = (float*)(p + off); off += align_up(sizeof(float) * (size_t)nblocks);
+  w.owner = (short*)(p + off);
+  if (total) *total = off;
+  return w;
+}
+
+// ---------------------------------------------------------------- pairs
+__global__ __launch_bounds__(256) void fgkd_pairs_kernel(
+    const float* __restrict__ hs_t, const int64_t* __restrict__ keepid_t,
+    const float* __restrict__ hs_s, const int64_t* __restrict__ labels_s,
+    const unsigned char* __restrict__ prev_mask, int N, int D, int NC, int M, FgWs ws,
+    int* __restrict__ status) {
+  __shared__ int s_count;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave == 0) {
+    int cnt = 0;
+    for (int base = 0; base < N; base += 64) {
+      const int n = base + lane;
+      bool hit = false;
+      if (n < N) {
+        const int64_t lab = labels_s[n];
+        hit = lab >= 0 && lab < NC && prev_mask[lab] != 0;
+      }
+      const unsigned long long mk = __ballot(hit);
+      const int pos = cnt + __popcll(mk & ((1ull << lane) - 1ull));
+      if (hit && pos < M) ws.id_pred[pos] = n;
+      cnt += __popcll(mk);
+    }
+    if (lane == 0) {
+      s_count = cnt;
+      status[0] = cnt < M ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  const int cnt = s_count;
+  for (int k = wave; k < M; k += 4) {
+    float* mk = ws.m + (size_t)k * D;
+    if (k >= cnt) {  // reference would raise IndexError; flagged through status
+      for (int c = lane; c < D; c += 64) mk[c] = 0.f;
+      continue;
+    }
+    const float* t = hs_t + (size_t)keepid_t[k] * D;
+    const float* s = hs_s + (size_t)ws.id_pred[k] * D;
+    float mx = -INFINITY;
+    for (int c = lane; c < D; c += 64) mx = fmaxf(mx, fabsf(t[c] - s[c]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int c = lane; c < D; c += 64) sum += expf(fabsf(t[c] - s[c]) - mx);
+    sum = wave_sum(sum);
+    for (int c = lane; c < D; c += 64) mk[c] = expf(fabsf(t[c] - s[c]) - mx) / sum;
+  }
+}
+
+// ---------------------------------------------------------------- owner map
+__global__ __launch_bounds__(256) void fgkd_owner_kernel(const float* __restrict__ boxes,
+                                                         FgImages im, int H, int W,
+                                                         short* __restrict__ owner) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.y;
+  const int px = blockIdx.x * blockDim.x + threadIdx.x;
+  if (px >= H * W) return;
+  const int h = px / W, w = px - h * W;
+  const int b0 = im.box_start[i], b1 = im.box_start[i + 1];
+  const float ih = im.img_hw[2 * i], iw = im.img_hw[2 * i + 1];
+  int own = -1;
+  for (int j = b0; j < b1; ++j) {
+    const f32x4 bx = *reinterpret_cast<const f32x4*>(boxes + (size_t)j * 4);
+    // new = box / img * grid, floor / ceil, .int(); slices are [min, max) and clip at the edges
+    const int wmin = (int)floorf(bx.x / iw * (float)W);
+    const int wmax = (int)ceilf(bx.z / iw * (float)W);
+    const int hmin = (int)floorf(bx.y / ih * (float)H);
+    const int hmax = (int)ceilf(bx.w / ih * (float)H);
+    if (h >= hmin && h < hmax && w >= wmin && w < wmax) own = j - b0;  // later boxes overwrite
+  }
+  owner[(size_t)i * H * W + px] = (short)own;
+}
+
+// ---------------------------------------------------------------- fused KL + mask gradient
+struct ColStat {
+  float A, Za, S, Bm, Zb;
+};
+
+__device__ __forceinline__ void stat_push(ColStat& st, float a, float b) {
+  // online softmax statistics: Za = sum exp(a-A), S = sum exp(a-A)(a-b), Zb = sum exp(b-Bm)
+  if (a > st.A) {
+    const float r = expf(st.A - a);
+    st.Za *= r;
+    st.S *= r;
+    st.A = a;
+  }
+  const float ea = expf(a - st.A);
+  st.Za += ea;
+  st.S = fmaf(ea, a - b, st.S);
+  if (b > st.Bm) {
+    st.Zb *= expf(st.Bm - b);
+    st.Bm = b;
+  }
+  st.Zb += expf(b - st.Bm);
+}
+
+__device__ __forceinline__ void stat_merge(ColStat& x, const ColStat& y) {
+  const float A = fmaxf(x.A, y.A);
+  const float rx = x.A == A ? 1.f : expf(x.A - A);
+  const float ry = y.A == A ? 1.f : expf(y.A - A);
+  x.Za = x.Za * rx + y.Za * ry;
+  x.S = x.S * rx + y.S * ry;
+  x.A = A;
+  const float Bm = fmaxf(x.Bm, y.Bm);
+  const float qx = x.Bm == Bm ? 1.f : expf(x.Bm - Bm);
+  const float qy = y.Bm == Bm ? 1.f : expf(y.Bm - Bm);
+  x.Zb = x.Zb * qx + y.Zb * qy;
+  x.Bm = Bm;
+}
+
+__global__ __launch_bounds__(kStrip * kRowGroups) void fgkd_kl_kernel(
+    FgLevels lv, FgImages im, int levels, int C, int D, float T, FgWs ws) {
+  extern __shared__ float s_dyn[];
+  // locate (level, image, channel, strip)
+  int l = 0;
+  while (l + 1 < levels && (int)blockIdx.x >= lv.blk_start[l + 1]) ++l;
+  const int H = lv.H[l], W = lv.W[l], tiles = lv.tiles[l];
+  int rel = blockIdx.x - lv.blk_start[l];
+  const int tile = rel % tiles; rel /= tiles;
+  const int c = rel % C;
+  const int i = rel / C;
+  const int w0 = tile * kStrip;
+  const int col = threadIdx.x & (kStrip - 1);
+  const int rg = threadIdx.x >> 6;
+  const int w = w0 + col;
+  const bool wv = w < W;
+
+  // LDS carve: a[H][64], ft[H][64], owner[H][64] (short), per-box mask / grad, stats
+  float* s_a = s_dyn;
+  float* s_ft = s_a + H * kStrip;
+  short* s_own = (short*)(s_ft + H * kStrip);
+  float* s_m = (float*)(s_own + ((H * kStrip + 1) & ~1));
+  const int b0 = im.box_start[i], nb = im.box_start[i + 1] - b0;
+  float* s_g = s_m + nb;
+  ColStat* s_st = (ColStat*)(s_g + nb);  // [kRowGroups][64]
+
+  for (int j = threadIdx.x; j < nb; j += blockDim.x) {
+    s_m[j] = ws.m[(size_t)(b0 + j) * D + c];
+    s_g[j] = 0.f;
+  }
+  __syncthreads();
+
+  const size_t plane = ((size_t)i * C + c) * (size_t)H * W;
+  const float* fs = lv.fs[l] + plane;
+  const float* ft = lv.ft[l] + plane;
+  const short* own = ws.owner + lv.own_start[l] + (size_t)i * H * W;
+  const float invT = 1.f / T;
+
+  ColStat st;
+  st.A = -INFINITY; st.Za = 0.f; st.S = 0.f; st.Bm = -INFINITY; st.Zb = 0.f;
+  for (int h = rg; h < H; h += kRowGroups) {
+    float a = 0.f, b = 0.f, ftv = 0.f;
+    short o = -1;
+    if (wv) {
+      const size_t e = (size_t)h * W + w;
+      o = own[e];
+      const float mk = o >= 0 ? s_m[o] : 0.f;
+      const float fsv = fs[e];
+      ftv = ft[e];
+      a = (fsv * mk) * invT;  // target logits: student * mask / T
+      b = (ftv * mk) * invT;  // pred logits:   teacher * mask / T
+      stat_push(st, a, b);
+    }
+    s_a[h * kStrip + col] = a;
+    s_ft[h * kStrip + col] = ftv;
+    s_own[h * kStrip + col] = o;
+  }
+  s_st[rg * kStrip + col] = st;
+  __syncthreads();
+
+  // column statistics (every thread merges the four row groups of its column)
+  ColStat cs = s_st[col];
+#pragma unroll
+  for (int g = 1; g < kRowGroups; ++g) stat_merge(cs, s_st[g * kStrip + col]);
+  float klcol = 0.f;
+  if (wv && rg == 0) {
+    // sum_h t_h (log t_h - log p_h) = S/Za - (A + log Za) + (Bm + log Zb)
+    klcol = cs.S / cs.Za - (cs.A + logf(cs.Za)) + (cs.Bm + logf(cs.Zb));
+    klcol *= T * T / (float)H;
+  }
+  if (rg == 0) {
+    klcol = wave_sum(klcol);
+    if (col == 0) ws.partial[blockIdx.x] = klcol;
+  }
+
+  // second sweep out of LDS: d loss / d mask[c] at (h, w) = (T/H) (p - t) * F_t, summed per owner
+  if (wv && nb > 0) {
+    const float kscale = T / (float)H;
+    const float iZa = 1.f / cs.Za, iZb = 1.f / cs.Zb;
+    int cur = -1;
+    float acc = 0.f;
+    for (int h = rg; h < H; h += kRowGroups) {
+      const int o = s_own[h * kStrip + col];
+      if (o != cur) {
+        if (cur >= 0 && acc != 0.f) atomicAdd(&s_g[cur], acc);
+        cur = o;
+        acc = 0.f;
+      }
+      if (o >= 0) {
+        const float a = s_a[h * kStrip + col];
+        const float ftv = s_ft[h * kStrip + col];
+        const float b = (ftv * s_m[o]) * invT;
+        const float t = expf(a - cs.A) * iZa;
+        const float p = expf(b - cs.Bm) * iZb;
+        acc = fmaf(kscale * (p - t), ftv, acc);
+      }
+    }
+    if (cur >= 0 && acc != 0.f) atomicAdd(&s_g[cur], acc);
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < nb; j += blockDim.x) {
+    const float g = s_g[j];
+    if (g != 0.f) atomicAdd(ws.gm + (size_t)(b0 + j) * D + c, g);
+  }
+}
+
+// ---------------------------------------------------------------- finish
+// block 0: loss; blocks 1..: one wave per pair -> softmax / abs backward into grad_hs_s
+__global__ __launch_bounds__(256) void fgkd_finish_kernel(
+    const float* __restrict__ hs_t, const int64_t* __restrict__ keepid_t,
+    const float* __restrict__ hs_s, int D, int M, long long nblocks, float scale, FgWs ws,
+    const int* __restrict__ status, float* __restrict__ loss, float* __restrict__ grad_hs) {
+  if (blockIdx.x == 0) {
+    __shared__ float s_p[256];
+    float s = 0.f;
+    for (long long k = threadIdx.x; k < nblocks; k += blockDim.x) s += ws.partial[k];
+    s_p[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) s_p[threadIdx.x] += s_p[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = s_p[0] * scale;
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int k = (blockIdx.x - 1) * 4 + (threadIdx.x >> 6);
+  if (k >= M) return;
+  const float* mk = ws.m + (size_t)k * D;
+  const float* gk = ws.gm + (size_t)k * D;
+  float dot = 0.f;
+  for (int c = lane; c < D; c += 64) dot = fmaf(mk[c], gk[c], dot);
+  dot = wave_sum(dot);
+  const float* t = hs_t + (size_t)keepid_t[k] * D;
+  const int row = ws.id_pred[k];
+  const float* s = hs_s + (size_t)row * D;
+  float* g = grad_hs + (size_t)row * D;
+  for (int c = lane; c < D; c += 64) {
+    const float gz = mk[c] * (gk[c] - dot);  // softmax backward
+    const float dlt = t[c] - s[c];
+    const float sgn = dlt > 0.f ? 1.f : (dlt < 0.f ? -1.f : 0.f);
+    g[c] = -gz * sgn * scale;  // d|t - s|/ds = -sign(t - s)
+  }
+}
+
+struct FgPlan {
+  FgLevels lv;
+  long long nblocks;
+  long long owner_elems;
+  size_t lds_max;
+};
+
+int make_plan(const float* const* fs, const float* const* ft, const int32_t* shapes, int levels,
+              int B, int C, FgPlan* p) {
+  if (levels < 1 || levels > kMaxLevels) return fail(DSKD_ERR_INVALID_ARG, "fgkd: levels=%d unsupported", levels);
+  long long blk = 0, own = 0;
+  p->lds_max = 0;
+  for (int l = 0; l < levels; ++l) {
+    const int H = shapes[2 * l], W = shapes[2 * l + 1];
+    if (H <= 0 || W <= 0) return fail(DSKD_ERR_INVALID_ARG, "fgkd: bad level shape %dx%d", H, W);
+    p->lv.fs[l] = fs ? fs[l] : nullptr;
+    p->lv.ft[l] = ft ? ft[l] : nullptr;
+    p->lv.H[l] = H;
+    p->lv.W[l] = W;
+    p->lv.tiles[l] = (W + kStrip - 1) / kStrip;
+    p->lv.blk_start[l] = (int)blk;
+    p->lv.own_start[l] = own;
+    blk += (long long)B * C * p->lv.tiles[l];
+    own += (long long)B * H * W;
+    const size_t lds = sizeof(float) * 2 * (size_t)H * kStrip + sizeof(short) * (((size_t)H * kStrip + 1) & ~(size_t)1);
+    if (lds > p->lds_max) p->lds_max = lds;
+  }
+  p->lv.blk_start[levels] = (int)blk;
+  for (int l = levels; l < kMaxLevels; ++l) {
+    p->lv.fs[l] = nullptr; p->lv.ft[l] = nullptr; p->lv.H[l] = 1; p->lv.W[l] = 1; p->lv.tiles[l] = 1;
+    p->lv.own_start[l] = own;
+    if (l > levels) p->lv.blk_start[l] = (int)blk;
+  }
+  if (blk > 0x7FFFFFFFLL) return fail(DSKD_ERR_INVALID_ARG, "fgkd: grid too large");
+  p->nblocks = blk;
+  p->owner_elems = own;
+  return DSKD_OK;
+}
+
+}  // namespace
+}  // namespace dskd
+
+using namespace dskd;
+
+extern "C" int64_t dskd_fgkd_workspace(int B, int C, int levels, const int32_t* shapes, int M, int N) {
+  (void)N;
+  FgPlan plan;
+  if (B < 0 || C <= 0 || M < 0 || !shapes) return 0;
+  if (make_plan(nullptr, nullptr, shapes, levels, B, C, &plan)) return 0;
+  size_t head = 0;
+  carve(nullptr, M, C, plan.nblocks, &head);
+  return (int64_t)(head + align_up(sizeof(short) * (size_t)plan.owner_elems) + 256);
+}
+
+extern "C" int dskd_fgkd_fwd(const float* const* feat_s, const float* const* feat_t,
+                             const int32_t* shapes, int levels, int B, int C,
+                             const float* boxes, const int32_t* box_start,
+                             const float* img_hw, const float* hs_t, const int64_t* keepid_t,
+                             const float* hs_s, const int64_t* labels_s,
+                             const uint8_t* prev_mask, int N, int D, int NC, int M, float T,
+                             float loss_weight, float* loss, float* grad_hs_s,
+                             void* workspace, int32_t* status, void* stream) {
+  if (B <= 0 || C <= 0 || N <= 0 || D <= 0 || NC <= 0 || M < 0)
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_fgkd_fwd: bad sizes");
+  if (C != D) return fail(DSKD_ERR_INVALID_ARG, "dskd_fgkd_fwd: feature channels (%d) must equal embedding dims (%d)", C, D);
+  if (!(T >= 1.f)) return fail(DSKD_ERR_INVALID_ARG, "dskd_fgkd_fwd: T must be >= 1");
+  if (!feat_s || !feat_t || !shapes || !box_start || !img_hw || !hs_t || !hs_s || !labels_s ||
+      !prev_mask || !loss || !grad_hs_s || !workspace || !status || (M > 0 && (!boxes || !keepid_t)))
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_fgkd_fwd: null pointer");
+  if (box_start[0] != 0 || box_start[B] != M)
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_fgkd_fwd: box_start must run from 0 to M");
+  int max_nb = 0;
+  for (int i = 0; i < B; ++i) {
+    const int nb = box_start[i + 1] - box_start[i];
+    if (nb < 0 || nb > kMaxBoxes) return fail(DSKD_ERR_INVALID_ARG, "dskd_fgkd_fwd: image %d has %d boxes (limit %d)", i, nb, kMaxBoxes);
+    if (nb > max_nb) max_nb = nb;
+  }
+  FgPlan plan;
+  if (int rc = make_plan(feat_s, feat_t, shapes, levels, B, C, &plan)) return rc;
+  const size_t lds = plan.lds_max + sizeof(float) * 2 * (size_t)max_nb +
+                     sizeof(ColStat) * kRowGroups * kStrip + sizeof(float) * kRowGroups + 64;
+  if (lds > 160 * 1024)
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_fgkd_fwd: a level with H too large for the LDS strip (%zu B)", lds);
+  hipStream_t st = (hipStream_t)stream;
+  const FgWs ws = carve(workspace, M, D, plan.nblocks, nullptr);
+
+  if (B > kMaxImages) return fail(DSKD_ERR_INVALID_ARG, "dskd_fgkd_fwd: B=%d exceeds %d images per call", B, kMaxImages);
+  FgImages im;
+  for (int i = 0; i <= kMaxImages; ++i) im.box_start[i] = box_start[i <= B ? i : B];
+  for (int i = 0; i < 2 * kMaxImages; ++i) im.img_hw[i] = i < 2 * B ? img_hw[i] : 1.f;
+
+  if (hipMemsetAsync(ws.gm, 0, sizeof(float) * (size_t)M * D + 16, st) != hipSuccess)
+    return fail(DSKD_ERR_LAUNCH, "dskd_fgkd_fwd: memset failed");
+  if (hipMemsetAsync(grad_hs_s, 0, sizeof(float) * (size_t)N * D, st) != hipSuccess)
+    return fail(DSKD_ERR_LAUNCH, "dskd_fgkd_fwd: memset failed");
+
+  hipLaunchKernelGGL(fgkd_pairs_kernel, dim3(1), dim3(256), 0, st, hs_t, keepid_t, hs_s, labels_s,
+                     prev_mask, N, D, NC, M, ws, status);
+  if (int rc = check_launch("dskd_fgkd_fwd/pairs")) return rc;
+  for (int l = 0; l < levels; ++l) {
+    const int H = plan.lv.H[l], W = plan.lv.W[l];
+    hipLaunchKernelGGL(fgkd_owner_kernel, dim3((H * W + 255) / 256, B), dim3(256), 0, st, boxes, im,
+                       H, W, ws.owner + plan.lv.own_start[l]);
+    if (int rc = check_launch("dskd_fgkd_fwd/owner")) return rc;
+  }
+  if (lds > 48 * 1024 &&
+      hipFuncSetAttribute((const void*)fgkd_kl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)lds) != hipSuccess)
+    return fail(DSKD_ERR_LAUNCH, "dskd_fgkd_fwd: cannot reserve %zu B of LDS", lds);
+  hipLaunchKernelGGL(fgkd_kl_kernel, dim3((unsigned)plan.nblocks), dim3(kStrip * kRowGroups), lds, st,
+                     plan.lv, im, levels, C, D, T, ws);
+  if (int rc = check_launch("dskd_fgkd_fwd/kl")) return rc;
+  const float scale = loss_weight / (float)B;
+  hipLaunchKernelGGL(fgkd_finish_kernel, dim3(1 + (M + 3) / 4), dim3(256), 0, st, hs_t, keepid_t, hs_s,
+                     D, M, plan.nblocks, scale, ws, status, loss, grad_hs_s);
+  return check_launch("dskd_fgkd_fwd/finish");
+}

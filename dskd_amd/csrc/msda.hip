@@ -1,0 +1,466 @@
+// Multi-scale deformable attention (sampling + aggregation), forward and backward,
+// hand-written for gfx950 (MI355X).
+//
+// Replaces ext-mmcv `MultiScaleDeformableAttnFunction` (mmcv-full 1.3.17..1.6.2), which
+// the reference imports at mmdet/models/utils/transformer.py:22-29 and reaches from the
+// encoder (transformer.py:985-995) and the decoder (transformer.py:1032-1043).
+// Semantics: per (b, q, h)
+//   out[b,q,h,:] = sum_{l,p} attn[b,q,h,l,p] * S_l(loc[b,q,h,l,p])
+// with x = loc_x*W_l - 0.5, y = loc_y*H_l - 0.5 and S_l the zero-padded bilinear sample of
+// value[b, start_l + y*W_l + x, h, :].
+//
+// MI355X mapping (not mmcv's one-thread-per-output-channel):
+//  * value rows are [heads*32] contiguous, so one corner of one head is a 128-B (f32) or
+//    64-B (bf16) line.  A wave owns whole queries: 8 heads x (8 | 4) lanes, 16 B per lane,
+//    so every gather instruction moves complete lines and the output row is one coalesced
+//    1-KiB (f32) / 512-B (bf16) store.  No cross-lane reduction in the forward at all.
+//  * the 128 sampling points of a query (8 heads x 16) are turned into (byte offset, weight)
+//    quadruples ONCE, cooperatively (2 points per lane), parked in the wave's private LDS
+//    slice and re-read as broadcast ds_read_b128 -- instead of every lane redoing the
+//    floor/weight/bounds arithmetic for its head.
+//  * gathers are raw buffer loads: 32-bit offsets against a per-image descriptor, and an
+//    out-of-image corner is encoded as an out-of-range offset, which the hardware returns
+//    as zeros (exactly grid_sample's zero padding; no clamped re-read, no NaN*0).
+//  * work items are dealt to XCDs in contiguous chunks (xcd_remap) so that raster
+//    neighbours, which sample overlapping windows, share one 4 MiB L2.
+//  * backward: d(out)/d(value) is a scatter; contributions are added with no-return
+//    global_atomic_add_f32 shaped as two full 128-B segments per wave instruction (the
+//    full-rate shape, MI355X_MICROARCH.md "Global float atomics"); grad_loc / grad_attn
+//    come from per-head dot products reduced with DPP inside 8- / 4-lane groups.
+#include "common.h"
+
+namespace dskd {
+namespace {
+
+constexpr int kHeads = 8;
+constexpr int kCh = 32;
+constexpr int kWaves = 4;       // waves per workgroup
+constexpr int kMaxLevels = 4;
+constexpr int kMaxLP = 16;      // levels * points
+constexpr int kHeadStride = 17; // LDS slots per head: 16 samples + 1 pad (bank spread)
+constexpr int kOOB = 0x7F000000;  // byte offset beyond every descriptor range
+
+struct LevelGeom {
+  int H[kMaxLevels];
+  int W[kMaxLevels];
+  int start[kMaxLevels];
+};
+
+__device__ __forceinline__ int sel4(const int* a, int i) {
+  return i == 0 ? a[0] : (i == 1 ? a[1] : (i == 2 ? a[2] : a[3]));
+}
+
+template <typename T>
+struct Traits;
+template <>
+struct Traits<float> {
+  static constexpr int QPW = 1;    // queries per wave pass
+  static constexpr int LPH = 8;    // lanes per head
+  static constexpr int ROWB = 1024;  // bytes per value row (8 heads x 32 ch)
+  static constexpr int NACC = 4;   // channels per lane
+};
+template <>
+struct Traits<__bf16> {
+  static constexpr int QPW = 2;
+  static constexpr int LPH = 4;
+  static constexpr int ROWB = 512;
+  static constexpr int NACC = 8;
+};
+
+// One sampling point -> four corner byte offsets (row * ROWB, or kOOB) and the four
+// bilinear weights.  aux = (lx, ly, attn, level) for the backward.
+template <int ROWB>
+__device__ __forceinline__ void point_params(float lx_n, float ly_n, float a, int lvl,
+                                             const LevelGeom& g, i32x4& off, f32x4& w,
+                                             f32x4& aux) {
+  const int H = sel4(g.H, lvl), W = sel4(g.W, lvl), st = sel4(g.start, lvl);
+  const float x = lx_n * (float)W - 0.5f;
+  const float y = ly_n * (float)H - 0.5f;
+  off = i32x4{kOOB, kOOB, kOOB, kOOB};
+  w = f32x4{0.f, 0.f, 0.f, 0.f};
+  aux = f32x4{0.f, 0.f, a, (float)lvl};
+  // Same acceptance test as the reference op: strictly inside (-1, size).  NaN fails it.
+  if (x > -1.f && y > -1.f && x < (float)W && y < (float)H) {
+    const float xf = floorf(x), yf = floorf(y);
+    const int x0 = (int)xf, y0 = (int)yf;
+    const float lx = x - xf, ly = y - yf;
+    const float hx = 1.f - lx, hy = 1.f - ly;
+    const bool vx0 = x0 >= 0, vx1 = x0 + 1 <= W - 1;
+    const bool vy0 = y0 >= 0, vy1 = y0 + 1 <= H - 1;
+    const int r00 = (st + y0 * W + x0) * ROWB;
+    off.x = (vy0 && vx0) ? r00 : kOOB;
+    off.y = (vy0 && vx1) ? r00 + ROWB : kOOB;
+    off.z = (vy1 && vx0) ? r00 + W * ROWB : kOOB;
+    off.w = (vy1 && vx1) ? r00 + W * ROWB + ROWB : kOOB;
+    w = f32x4{hy * hx, hy * lx, ly * hx, ly * lx};
+    aux.x = lx;
+    aux.y = ly;
+  }
+}
+
+__device__ __forceinline__ void unpack_bf16x8(const u32x4& v, float* f) {
+  f[0] = __builtin_bit_cast(float, v.x << 16);
+  f[1] = __builtin_bit_cast(float, v.x & 0xFFFF0000u);
+  f[2] = __builtin_bit_cast(float, v.y << 16);
+  f[3] = __builtin_bit_cast(float, v.y & 0xFFFF0000u);
+  f[4] = __builtin_bit_cast(float, v.z << 16);
+  f[5] = __builtin_bit_cast(float, v.z & 0xFFFF0000u);
+  f[6] = __builtin_bit_cast(float, v.w << 16);
+  f[7] = __builtin_bit_cast(float, v.w & 0xFFFF0000u);
+}
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 p = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, p);
+}
+
+template <typename T>
+__device__ __forceinline__ void load_vals(__amdgpu_buffer_rsrc_t rsrc, int voff, float* f) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+  if constexpr (sizeof(T) == 4) {
+    f[0] = __builtin_bit_cast(float, v.x);
+    f[1] = __builtin_bit_cast(float, v.y);
+    f[2] = __builtin_bit_cast(float, v.z);
+    f[3] = __builtin_bit_cast(float, v.w);
+  } else {
+    unpack_bf16x8(v, f);
+  }
+}
+
+// Cooperative parameter pass shared by forward and backward.
+template <typename T, bool WITH_AUX>
+__device__ __forceinline__ void stage_points(const float* __restrict__ loc,
+                                             const float* __restrict__ attn,
+                                             const LevelGeom& g, int b, int Nq, int q0,
+                                             int q_end, int LP, int points, int lane,
+                                             i32x4* s_off, f32x4* s_wt, f32x4* s_aux) {
+  using TR = Traits<T>;
+  const int npts = TR::QPW * kHeads * LP;
+  for (int pi = lane; pi < npts; pi += 64) {
+    const int qs = pi / (kHeads * LP);
+    const int r = pi - qs * (kHeads * LP);
+    const int h = r / LP;
+    const int s = r - h * LP;
+    const int q = q0 + qs;
+    i32x4 off = i32x4{kOOB, kOOB, kOOB, kOOB};
+    f32x4 w = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 aux = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (q < q_end) {
+      const size_t base = ((size_t)b * Nq + q) * (size_t)(kHeads * LP) + r;
+      const f32x2 xy = *reinterpret_cast<const f32x2*>(loc + base * 2);
+      const float a = attn[base];
+      point_params<TR::ROWB>(xy.x, xy.y, a, s / points, g, off, w, aux);
+    }
+    const int slot = (qs * kHeads + h) * kHeadStride + s;
+    s_off[slot] = off;
+    if constexpr (WITH_AUX) {
+      s_wt[slot] = w;  // raw bilinear weights; attn lives in aux.z
+      s_aux[slot] = aux;
+    } else {
+      s_wt[slot] = w * aux.z;  // attn folded in
+    }
+  }
+}
+
+// ------------------------------------------------------------------ forward
+template <typename T>
+__global__ __launch_bounds__(kWaves * 64) void msda_fwd_kernel(
+    const T* __restrict__ value, const float* __restrict__ loc,
+    const float* __restrict__ attn, T* __restrict__ out, LevelGeom g, int Nv, int Nq,
+    int LP, int points, int qpb, int blocks_per_img) {
+  using TR = Traits<T>;
+  constexpr int SLOTS = TR::QPW * kHeads * kHeadStride;
+  __shared__ i32x4 s_off_all[kWaves][SLOTS];
+  __shared__ f32x4 s_wt_all[kWaves][SLOTS];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  i32x4* s_off = s_off_all[wave];
+  f32x4* s_wt = s_wt_all[wave];
+
+  const int vb = xcd_remap(blockIdx.x, gridDim.x);
+  const int b = vb / blocks_per_img;
+  const int blk = vb - b * blocks_per_img;
+  const int q_begin = blk * qpb;
+  const int q_end = min(q_begin + qpb, Nq);
+
+  const T* vbase = value + (size_t)b * Nv * (kHeads * kCh);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(vbase), 0, Nv * TR::ROWB, 0x00020000);
+
+  // lane -> (query slot, head, 16-byte part of the head's line)
+  const int qs = lane / (kHeads * TR::LPH);
+  const int h = (lane / TR::LPH) & (kHeads - 1);
+  const int part = lane & (TR::LPH - 1);
+  const int hb = h * (kCh * (int)sizeof(T)) + part * 16;
+  const i32x4* my_off = s_off + (qs * kHeads + h) * kHeadStride;
+  const f32x4* my_wt = s_wt + (qs * kHeads + h) * kHeadStride;
+
+  for (int q0 = q_begin + wave * TR::QPW; q0 < q_end; q0 += kWaves * TR::QPW) {
+    stage_points<T, false>(loc, attn, g, b, Nq, q0, q_end, LP, points, lane, s_off, s_wt,
+                           nullptr);
+    wave_lds_sync();
+
+    float acc[TR::NACC];
+#pragma unroll
+    for (int i = 0; i < TR::NACC; ++i) acc[i] = 0.f;
+
+#pragma unroll 4
+    for (int s = 0; s < LP; ++s) {
+      const i32x4 o = my_off[s];
+      const f32x4 w = my_wt[s];
+      float v0[TR::NACC], v1[TR::NACC], v2[TR::NACC], v3[TR::NACC];
+      load_vals<T>(rsrc, o.x + hb, v0);
+      load_vals<T>(rsrc, o.y + hb, v1);
+      load_vals<T>(rsrc, o.z + hb, v2);
+      load_vals<T>(rsrc, o.w + hb, v3);
+#pragma unroll
+      for (int i = 0; i < TR::NACC; ++i) {
+        acc[i] = fmaf(w.x, v0[i], acc[i]);
+        acc[i] = fmaf(w.y, v1[i], acc[i]);
+        acc[i] = fmaf(w.z, v2[i], acc[i]);
+        acc[i] = fmaf(w.w, v3[i], acc[i]);
+      }
+    }
+
+    const int q = q0 + qs;
+    if (q < q_end) {
+      T* orow = out + ((size_t)b * Nq + q) * (kHeads * kCh) + h * kCh;
+      if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<f32x4*>(orow + part * 4) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+      } else {
+        u32x4 p;
+        p.x = pack_bf16x2(acc[0], acc[1]);
+        p.y = pack_bf16x2(acc[2], acc[3]);
+        p.z = pack_bf16x2(acc[4], acc[5]);
+        p.w = pack_bf16x2(acc[6], acc[7]);
+        *reinterpret_cast<u32x4*>(orow + part * 8) = p;
+      }
+    }
+    wave_lds_sync();  // the next pass overwrites this wave's LDS slice
+  }
+}
+
+// ------------------------------------------------------------------ backward
+template <typename T>
+__global__ __launch_bounds__(kWaves * 64) void msda_bwd_kernel(
+    const T* __restrict__ value, const float* __restrict__ loc,
+    const float* __restrict__ attn, const T* __restrict__ grad_out,
+    float* __restrict__ grad_value, float* __restrict__ grad_loc,
+    float* __restrict__ grad_attn, LevelGeom g, int Nv, int Nq, int LP, int points,
+    int qpb, int blocks_per_img) {
+  using TR = Traits<T>;
+  constexpr int SLOTS = TR::QPW * kHeads * kHeadStride;
+  __shared__ i32x4 s_off_all[kWaves][SLOTS];
+  __shared__ f32x4 s_wt_all[kWaves][SLOTS];
+  __shared__ f32x4 s_aux_all[kWaves][SLOTS];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  i32x4* s_off = s_off_all[wave];
+  f32x4* s_wt = s_wt_all[wave];
+  f32x4* s_aux = s_aux_all[wave];
+
+  const int vb = xcd_remap(blockIdx.x, gridDim.x);
+  const int b = vb / blocks_per_img;
+  const int blk = vb - b * blocks_per_img;
+  const int q_begin = blk * qpb;
+  const int q_end = min(q_begin + qpb, Nq);
+
+  const T* vbase = value + (size_t)b * Nv * (kHeads * kCh);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(vbase), 0, Nv * TR::ROWB, 0x00020000);
+  float* gvb = grad_value + (size_t)b * Nv * (kHeads * kCh);
+
+  const int qs = lane / (kHeads * TR::LPH);
+  const int h = (lane / TR::LPH) & (kHeads - 1);
+  const int part = lane & (TR::LPH - 1);
+  const int hb = h * (kCh * (int)sizeof(T)) + part * 16;
+  const int myslot = (qs * kHeads + h) * kHeadStride;
+
+  for (int q0 = q_begin + wave * TR::QPW; q0 < q_end; q0 += kWaves * TR::QPW) {
+    stage_points<T, true>(loc, attn, g, b, Nq, q0, q_end, LP, points, lane, s_off, s_wt,
+                          s_aux);
+    wave_lds_sync();
+
+    // ---- phase A: grad_attn / grad_loc.  Lane = (query slot, head, 16-B part).
+    const int q = q0 + qs;
+    const bool qv = q < q_end;
+    float go[TR::NACC];
+    {
+      const int qc = qv ? q : q_end - 1;
+      const T* grow = grad_out + ((size_t)b * Nq + qc) * (kHeads * kCh) + h * kCh;
+      if constexpr (sizeof(T) == 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(grow + part * 4);
+        go[0] = t.x; go[1] = t.y; go[2] = t.z; go[3] = t.w;
+      } else {
+        const u32x4 t = *reinterpret_cast<const u32x4*>(grow + part * 8);
+        unpack_bf16x8(t, go);
+      }
+    }
+    const size_t gbase = (((size_t)b * Nq + (qv ? q : 0)) * kHeads + h) * (size_t)LP;
+    for (int s = 0; s < LP; ++s) {
+      const i32x4 o = s_off[myslot + s];
+      const f32x4 w = s_wt[myslot + s];
+      const f32x4 ax = s_aux[myslot + s];
+      float v0[TR::NACC], v1[TR::NACC], v2[TR::NACC], v3[TR::NACC];
+      load_vals<T>(rsrc, o.x + hb, v0);
+      load_vals<T>(rsrc, o.y + hb, v1);
+      load_vals<T>(rsrc, o.z + hb, v2);
+      load_vals<T>(rsrc, o.w + hb, v3);
+      float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+      for (int i = 0; i < TR::NACC; ++i) {
+        d0 = fmaf(v0[i], go[i], d0);
+        d1 = fmaf(v1[i], go[i], d1);
+        d2 = fmaf(v2[i], go[i], d2);
+        d3 = fmaf(v3[i], go[i], d3);
+      }
+      if constexpr (TR::LPH == 8) {
+        d0 = group8_sum(d0); d1 = group8_sum(d1); d2 = group8_sum(d2); d3 = group8_sum(d3);
+      } else {
+        d0 = group4_sum(d0); d1 = group4_sum(d1); d2 = group4_sum(d2); d3 = group4_sum(d3);
+      }
+      // one lane of the group writes this sample's gradients
+      if (qv && part == (s & (TR::LPH - 1))) {
+        const float lx = ax.x, ly = ax.y, a = ax.z;
+        const int lvl = (int)ax.w;
+        const float Wf = (float)sel4(g.W, lvl), Hf = (float)sel4(g.H, lvl);
+        const float hx = 1.f - lx, hy = 1.f - ly;
+        const float ga = w.x * d0 + w.y * d1 + w.z * d2 + w.w * d3;
+        const float gx = Wf * a * (hy * (d1 - d0) + ly * (d3 - d2));
+        const float gy = Hf * a * (hx * (d2 - d0) + lx * (d3 - d1));
+        grad_attn[gbase + s] = ga;
+        *reinterpret_cast<f32x2*>(grad_loc + (gbase + s) * 2) = f32x2{gx, gy};
+      }
+    }
+
+    // ---- phase B: grad_value scatter.  Lane = (corner parity, channel): one wave
+    // instruction adds two complete 128-B head lines.
+    const int ch = lane & 31;
+    const int cpar = lane >> 5;
+#pragma unroll 1
+    for (int qq = 0; qq < TR::QPW; ++qq) {
+      const int q2 = q0 + qq;
+      if (q2 >= q_end) break;
+      const T* grow = grad_out + ((size_t)b * Nq + q2) * (kHeads * kCh);
+      float gch[kHeads];
+#pragma unroll
+      for (int hh = 0; hh < kHeads; ++hh) gch[hh] = (float)grow[hh * kCh + ch];
+#pragma unroll
+      for (int hh = 0; hh < kHeads; ++hh) {
+        const int slot = (qq * kHeads + hh) * kHeadStride;
+        const int hoff = hh * kCh + ch;
+        for (int s = 0; s < LP; ++s) {
+          const i32x4 o = s_off[slot + s];
+          const f32x4 w = s_wt[slot + s];
+          const float a = s_aux[slot + s].z;
+          const float ga = a * gch[hh];
+          // corners (0,1) then (2,3); each half-wave takes one corner
+          const int oa = cpar ? o.y : o.x;
+          const float wa = cpar ? w.y : w.x;
+          const int ob = cpar ? o.w : o.z;
+          const float wb = cpar ? w.w : w.z;
+          if (oa != kOOB)
+            atomicAdd(gvb + (size_t)(oa / TR::ROWB) * (kHeads * kCh) + hoff, wa * ga);
+          if (ob != kOOB)
+            atomicAdd(gvb + (size_t)(ob / TR::ROWB) * (kHeads * kCh) + hoff, wb * ga);
+        }
+      }
+    }
+    wave_lds_sync();
+  }
+}
+
+int fill_geom(const int64_t* spatial_shapes, const int64_t* level_start, int levels, int Nv,
+              LevelGeom* g) {
+  int64_t covered = 0;
+  for (int l = 0; l < kMaxLevels; ++l) {
+    if (l < levels) {
+      const int64_t H = spatial_shapes[2 * l], W = spatial_shapes[2 * l + 1];
+      const int64_t st = level_start[l];
+      if (H <= 0 || W <= 0 || st < 0 || st + H * W > Nv)
+        return fail(DSKD_ERR_INVALID_ARG, "msda: level %d (H=%lld W=%lld start=%lld) exceeds Nv=%d",
+                    l, (long long)H, (long long)W, (long long)st, Nv);
+      g->H[l] = (int)H; g->W[l] = (int)W; g->start[l] = (int)st;
+      covered += H * W;
+    } else {
+      g->H[l] = 1; g->W[l] = 1; g->start[l] = 0;
+    }
+  }
+  (void)covered;
+  return DSKD_OK;
+}
+
+int check_shapes(const char* who, int B, int Nv, int Nq, int heads, int ch, int levels,
+                 int points, int dtype) {
+  if (heads != kHeads || ch != kCh)
+    return fail(DSKD_ERR_INVALID_ARG, "%s: only heads=8, ch=32 supported (got %d, %d)", who, heads, ch);
+  if (levels < 1 || levels > kMaxLevels || points < 1 || levels * points > kMaxLP)
+    return fail(DSKD_ERR_INVALID_ARG, "%s: need levels<=4 and levels*points<=16 (got %d, %d)", who, levels, points);
+  if (B < 0 || Nv <= 0 || Nq < 0)
+    return fail(DSKD_ERR_INVALID_ARG, "%s: bad sizes B=%d Nv=%d Nq=%d", who, B, Nv, Nq);
+  if ((int64_t)Nv * 1024 >= (int64_t)kOOB)
+    return fail(DSKD_ERR_INVALID_ARG, "%s: Nv=%d too large for 32-bit row offsets", who, Nv);
+  if (dtype != DSKD_DTYPE_F32 && dtype != DSKD_DTYPE_BF16)
+    return fail(DSKD_ERR_INVALID_ARG, "%s: unknown dtype %d", who, dtype);
+  return DSKD_OK;
+}
+
+constexpr int kQPB = 32;  // queries per workgroup (8 per wave)
+
+}  // namespace
+}  // namespace dskd
+
+using namespace dskd;
+
+extern "C" int dskd_msda_fwd(const void* value, const int64_t* spatial_shapes,
+                             const int64_t* level_start, const float* loc,
+                             const float* attn, void* out, int B, int Nv, int Nq,
+                             int heads, int ch, int levels, int points, int dtype,
+                             void* stream) {
+  if (int rc = check_shapes("dskd_msda_fwd", B, Nv, Nq, heads, ch, levels, points, dtype)) return rc;
+  if (!value || !loc || !attn || !out || !spatial_shapes || !level_start)
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_msda_fwd: null pointer");
+  if (B == 0 || Nq == 0) return DSKD_OK;
+  LevelGeom g;
+  if (int rc = fill_geom(spatial_shapes, level_start, levels, Nv, &g)) return rc;
+  const int bpi = (Nq + kQPB - 1) / kQPB;
+  const dim3 grid((unsigned)(B * bpi)), block(kWaves * 64);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DSKD_DTYPE_F32)
+    hipLaunchKernelGGL(msda_fwd_kernel<float>, grid, block, 0, st, (const float*)value, loc,
+                       attn, (float*)out, g, Nv, Nq, levels * points, points, kQPB, bpi);
+  else
+    hipLaunchKernelGGL(msda_fwd_kernel<__bf16>, grid, block, 0, st, (const __bf16*)value, loc,
+                       attn, (__bf16*)out, g, Nv, Nq, levels * points, points, kQPB, bpi);
+  return check_launch("dskd_msda_fwd");
+}
+
+extern "C" int dskd_msda_bwd(const void* value, const int64_t* spatial_shapes,
+                             const int64_t* level_start, const float* loc,
+                             const float* attn, const void* grad_out, float* grad_value,
+                             float* grad_loc, float* grad_attn, int B, int Nv, int Nq,
+                             int heads, int ch, int levels, int points, int dtype,
+                             void* stream) {
+  if (int rc = check_shapes("dskd_msda_bwd", B, Nv, Nq, heads, ch, levels, points, dtype)) return rc;
+  if (!value || !loc || !attn || !grad_out || !grad_value || !grad_loc || !grad_attn ||
+      !spatial_shapes || !level_start)
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_msda_bwd: null pointer");
+  if (B == 0 || Nq == 0) return DSKD_OK;
+  LevelGeom g;
+  if (int rc = fill_geom(spatial_shapes, level_start, levels, Nv, &g)) return rc;
+  const int bpi = (Nq + kQPB - 1) / kQPB;
+  const dim3 grid((unsigned)(B * bpi)), block(kWaves * 64);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DSKD_DTYPE_F32)
+    hipLaunchKernelGGL(msda_bwd_kernel<float>, grid, block, 0, st, (const float*)value, loc,
+                       attn, (const float*)grad_out, grad_value, grad_loc, grad_attn, g, Nv,
+                       Nq, levels * points, points, kQPB, bpi);
+  else
+    hipLaunchKernelGGL(msda_bwd_kernel<__bf16>, grid, block, 0, st, (const __bf16*)value, loc,
+                       attn, (const __bf16*)grad_out, grad_value, grad_loc, grad_attn, g, Nv,
+                       Nq, levels * points, points, kQPB, bpi);
+  return check_launch("dskd_msda_bwd");
+}

@@ -1,0 +1,348 @@
+"""ctypes binding of the gfx950 hot-path library (``include/dskd_hip.h``).
+
+PyTorch is used only as the owner of device memory and of the HIP stream: every
+call hands raw device pointers and sizes across the C-ABI.  There is NO CPU
+fallback here -- if ``libdskd_hip.so`` is missing or a tensor is not on the GPU the
+call raises.  (Tests and ``bench.py``'s CPU baseline may *inject* a checker
+implementation with :func:`install_cpu_checker`; the package itself never imports
+``oracle/``.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_C", "libdskd_hip.so")
+_lib: Optional[C.CDLL] = None
+
+DTYPE_F32, DTYPE_BF16 = 0, 1
+ERR_INVALID_COST, ERR_INFEASIBLE = -3, -4
+
+_vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+_SIGNATURES = {
+    "dskd_abi_version": (C.c_int, []),
+    "dskd_last_error": (C.c_char_p, []),
+    "dskd_device_count": (C.c_int, []),
+    "dskd_msda_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [C.c_int] * 8 + [_vp]),
+    "dskd_msda_bwd": (C.c_int, [_vp] * 9 + [C.c_int] * 8 + [_vp]),
+    "dskd_lsap_host": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
+    "dskd_lsap_batched": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
+    "dskd_match_cost": (C.c_int, [_vp] * 7 + [C.c_int] * 3 + [_f32] * 3 + [_vp]),
+    "dskd_proto_corr_workspace": (_i64, [C.c_int, C.c_int]),
+    "dskd_proto_corr_fwd": (C.c_int, [_vp] * 6 + [C.c_int] * 5 + [_f32] + [_vp] * 4),
+    "dskd_fgkd_workspace": (_i64, [C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int]),
+    "dskd_fgkd_fwd": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp,
+                                 _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f32, _f32,
+                                 _vp, _vp, _vp, _vp, _vp]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load the HIP library or raise: the product path has no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise NativeError(
+                f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (dskd_amd/csrc/build.sh); there is no CPU fallback")
+        lib = C.CDLL(_LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        if lib.dskd_abi_version() != 1:
+            raise NativeError("libdskd_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().dskd_last_error().decode()
+        if rc in (ERR_INVALID_COST, ERR_INFEASIBLE):
+            raise ValueError(msg)  # scipy raises ValueError for these
+        raise NativeError(f"{what} failed ({rc}): {msg}")
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _need_gpu(*ts: torch.Tensor) -> None:
+    for t in ts:
+        if not t.is_cuda:
+            raise NativeError("dskd_amd hot-path ops need GPU tensors (no CPU fallback in the product path)")
+
+
+def _host_i64(vals: Sequence[int]):
+    return (C.c_int64 * len(vals))(*[int(v) for v in vals])
+
+
+def _host_i32(vals: Sequence[int]):
+    return (C.c_int32 * len(vals))(*[int(v) for v in vals])
+
+
+def _host_f32(vals: Sequence[float]):
+    return (C.c_float * len(vals))(*[float(v) for v in vals])
+
+
+# --------------------------------------------------------------------------- checker hook
+_cpu_checker = None
+
+
+def install_cpu_checker(impl) -> None:
+    """TEST / CPU-BASELINE ONLY.  ``impl`` provides the same ops for CPU tensors
+    (the oracle); it is consulted only when an op receives CPU tensors.  The
+    package never installs one itself."""
+    global _cpu_checker
+    _cpu_checker = impl
+
+
+def cpu_checker():
+    return _cpu_checker
+
+
+def _dispatch_cpu(name: str, t: torch.Tensor):
+    if t.is_cuda:
+        return None
+    if _cpu_checker is None:
+        raise NativeError(f"{name}: CPU tensor given; the HIP path needs GPU tensors (no CPU fallback)")
+    return getattr(_cpu_checker, name)
+
+
+# --------------------------------------------------------------------------- MSDA
+def _geom(spatial_shapes: Sequence[Tuple[int, int]]):
+    flat, starts, acc = [], [], 0
+    for h, w in spatial_shapes:
+        flat += [int(h), int(w)]
+        starts.append(acc)
+        acc += int(h) * int(w)
+    return _host_i64(flat), _host_i64(starts), acc
+
+
+def msda_forward_raw(value, shapes, loc, attn):
+    _need_gpu(value, loc, attn)
+    B, Nv, heads, ch = value.shape
+    _, Nq, _, L, P, _ = loc.shape
+    ss, ls, tot = _geom(shapes)
+    assert tot == Nv, f"spatial shapes cover {tot} rows, value has {Nv}"
+    dt = {torch.float32: DTYPE_F32, torch.bfloat16: DTYPE_BF16}[value.dtype]
+    value, loc, attn = value.contiguous(), loc.contiguous().float(), attn.contiguous().float()
+    out = torch.empty((B, Nq, heads * ch), dtype=value.dtype, device=value.device)
+    rc = load().dskd_msda_fwd(value.data_ptr(), ss, ls, loc.data_ptr(), attn.data_ptr(), out.data_ptr(),
+                              B, Nv, Nq, heads, ch, L, P, dt, _stream(value))
+    _check(rc, "dskd_msda_fwd")
+    return out
+
+
+def msda_backward_raw(value, shapes, loc, attn, grad_out):
+    _need_gpu(value, loc, attn, grad_out)
+    B, Nv, heads, ch = value.shape
+    _, Nq, _, L, P, _ = loc.shape
+    ss, ls, _ = _geom(shapes)
+    dt = {torch.float32: DTYPE_F32, torch.bfloat16: DTYPE_BF16}[value.dtype]
+    value, loc, attn = value.contiguous(), loc.contiguous().float(), attn.contiguous().float()
+    grad_out = grad_out.contiguous().to(value.dtype)
+    gv = torch.zeros((B, Nv, heads, ch), dtype=torch.float32, device=value.device)
+    gl = torch.empty_like(loc)
+    ga = torch.empty_like(attn)
+    rc = load().dskd_msda_bwd(value.data_ptr(), ss, ls, loc.data_ptr(), attn.data_ptr(), grad_out.data_ptr(),
+                              gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), B, Nv, Nq, heads, ch, L, P, dt,
+                              _stream(value))
+    _check(rc, "dskd_msda_bwd")
+    return gv, gl, ga
+
+
+class _MSDAFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, value, loc, attn, shapes):
+        ctx.shapes = shapes
+        ctx.save_for_backward(value, loc, attn)
+        return msda_forward_raw(value, shapes, loc, attn)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        value, loc, attn = ctx.saved_tensors
+        gv, gl, ga = msda_backward_raw(value, ctx.shapes, loc, attn, grad_out)
+        return gv.to(value.dtype), gl.to(loc.dtype), ga.to(attn.dtype), None
+
+
+def ms_deform_attn(value: torch.Tensor, spatial_shapes: Sequence[Tuple[int, int]],
+                   sampling_locations: torch.Tensor, attention_weights: torch.Tensor) -> torch.Tensor:
+    """``MultiScaleDeformableAttnFunction.apply`` of ext-mmcv (call sites
+    /root/reference/mmdet/models/utils/transformer.py:985-995, :1032-1043).
+    value [B,Nv,heads,ch], sampling_locations [B,Nq,heads,L,P,2],
+    attention_weights [B,Nq,heads,L,P] -> [B,Nq,heads*ch]; differentiable."""
+    f = _dispatch_cpu("ms_deform_attn", value)
+    if f is not None:
+        return f(value, spatial_shapes, sampling_locations, attention_weights)
+    shapes = tuple((int(h), int(w)) for h, w in spatial_shapes)
+    return _MSDAFunction.apply(value, sampling_locations, attention_weights, shapes)
+
+
+# --------------------------------------------------------------------------- LSAP
+def lsap_host(cost: torch.Tensor):
+    """scipy-bit-exact linear_sum_assignment on a host float32 matrix (C-ABI host entry)."""
+    cost = cost.detach().to("cpu", torch.float32).contiguous()
+    nr, nc = cost.shape
+    n = min(nr, nc)
+    row = torch.empty(n, dtype=torch.int64)
+    col = torch.empty(n, dtype=torch.int64)
+    rc = load().dskd_lsap_host(cost.data_ptr(), nr, nc, row.data_ptr(), col.data_ptr())
+    _check(rc, "dskd_lsap_host")
+    return row, col
+
+
+def lsap_batched(cost_flat: torch.Tensor, nr: Sequence[int], nc: Sequence[int], offsets: Sequence[int]):
+    """Solve len(nr) problems stored back to back in ``cost_flat`` (device f32) in one launch.
+    Returns (row, col, out_offsets, status) with row/col device int64 and status device int32."""
+    _need_gpu(cost_flat)
+    nprob = len(nr)
+    outs, acc = [], 0
+    for r, c in zip(nr, nc):
+        outs.append(acc)
+        acc += min(int(r), int(c))
+    row = torch.empty(max(acc, 1), dtype=torch.int64, device=cost_flat.device)
+    col = torch.empty(max(acc, 1), dtype=torch.int64, device=cost_flat.device)
+    status = torch.zeros(max(nprob, 1), dtype=torch.int32, device=cost_flat.device)
+    rc = load().dskd_lsap_batched(cost_flat.data_ptr(), _host_i32(nr), _host_i32(nc), _host_i64(offsets), nprob,
+                                  row.data_ptr(), col.data_ptr(), _host_i64(outs), status.data_ptr(),
+                                  _stream(cost_flat))
+    _check(rc, "dskd_lsap_batched")
+    return row, col, outs, status
+
+
+def raise_for_lsap_status(status: torch.Tensor) -> None:
+    """Host check of the per-problem status words (one sync; call off the critical path)."""
+    st = status.cpu()
+    if (st == ERR_INVALID_COST).any():
+        raise ValueError("matrix contains invalid numeric entries")
+    if (st == ERR_INFEASIBLE).any():
+        raise ValueError("cost matrix is infeasible")
+
+
+# --------------------------------------------------------------------------- matching cost
+def match_cost(bbox_pred: torch.Tensor, cls_pred: torch.Tensor, gt_bboxes: torch.Tensor,
+               gt_labels: torch.Tensor, gt_start: Sequence[int], img_wh: Sequence[Tuple[float, float]],
+               w_cls: float, w_reg: float, w_iou: float) -> torch.Tensor:
+    """bbox_pred [P,Q,4], cls_pred [P,Q,C], gt_* concatenated over the P problems.
+    Returns the flat cost buffer; problem p is [Q, G_p] at Q*gt_start[p]."""
+    f = _dispatch_cpu("match_cost", bbox_pred)
+    if f is not None:
+        return f(bbox_pred, cls_pred, gt_bboxes, gt_labels, gt_start, img_wh, w_cls, w_reg, w_iou)
+    _need_gpu(cls_pred, gt_bboxes, gt_labels)
+    P, Q, _ = bbox_pred.shape
+    Cn = cls_pred.shape[-1]
+    bbox_pred = bbox_pred.detach().contiguous().float()
+    cls_pred = cls_pred.detach().contiguous().float()
+    gt_bboxes = gt_bboxes.contiguous().float()
+    gt_labels = gt_labels.contiguous().long()
+    total = int(gt_start[-1])
+    cost = torch.empty(max(Q * total, 1), dtype=torch.float32, device=bbox_pred.device)
+    wh = [v for pair in img_wh for v in pair]
+    rc = load().dskd_match_cost(bbox_pred.data_ptr(), cls_pred.data_ptr(), gt_bboxes.data_ptr(),
+                                gt_labels.data_ptr(), _host_i64(gt_start), _host_f32(wh), cost.data_ptr(),
+                                P, Q, Cn, w_cls, w_reg, w_iou, _stream(bbox_pred))
+    _check(rc, "dskd_match_cost")
+    return cost
+
+
+# --------------------------------------------------------------------------- DSKD loss 1
+class _ScaledGrad(torch.autograd.Function):
+    """loss (scalar, already computed) whose gradient w.r.t. ``x`` is the saved dense grad."""
+
+    @staticmethod
+    def forward(ctx, x, loss, grad):
+        ctx.save_for_backward(grad)
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None
+
+
+def proto_corr_loss(hs_s: torch.Tensor, labels_s: torch.Tensor, prev_mask: torch.Tensor, hs_t: torch.Tensor,
+                    keepid_t: torch.Tensor, labels_t: torch.Tensor, L: int, loss_weight: float = 1.0):
+    """DSKD loss 1 (gfl_deformable_detr_head_il.py:525-555, :1197-1222). hs_s [N,D] requires
+    grad; returns a scalar tensor whose backward reaches hs_s."""
+    f = _dispatch_cpu("proto_corr_loss", hs_s)
+    if f is not None:
+        return f(hs_s, labels_s, prev_mask, hs_t, keepid_t, labels_t, L, loss_weight)
+    _need_gpu(labels_s, prev_mask, hs_t, keepid_t, labels_t)
+    N, D = hs_s.shape
+    Cn = prev_mask.numel()
+    M = keepid_t.numel()
+    x = hs_s.detach().contiguous().float()
+    ht = hs_t.detach().contiguous().float()
+    lib = load()
+    ws = torch.empty(int(lib.dskd_proto_corr_workspace(L, D)), dtype=torch.uint8, device=x.device)
+    loss = torch.empty(1, dtype=torch.float32, device=x.device)
+    grad = torch.empty_like(x)
+    ls_, pm_ = labels_s.contiguous().long(), prev_mask.contiguous().to(torch.uint8)
+    kt_, lt_ = keepid_t.contiguous().long(), labels_t.contiguous().long()
+    rc = lib.dskd_proto_corr_fwd(x.data_ptr(), ls_.data_ptr(), pm_.data_ptr(), ht.data_ptr(),
+                                 kt_.data_ptr(), lt_.data_ptr(),
+                                 N, D, Cn, M, L, loss_weight, loss.data_ptr(), grad.data_ptr(), ws.data_ptr(),
+                                 _stream(x))
+    _check(rc, "dskd_proto_corr_fwd")
+    return _ScaledGrad.apply(hs_s, loss[0], grad.to(hs_s.dtype))
+
+
+# --------------------------------------------------------------------------- DSKD loss 2
+def fgkd_loss(feats_s: List[torch.Tensor], feats_t: List[torch.Tensor], boxes: List[torch.Tensor],
+              img_shapes: Sequence[Tuple[int, int]], hs_t: torch.Tensor, keepid_t: torch.Tensor,
+              hs_s: torch.Tensor, labels_s: torch.Tensor, prev_mask: torch.Tensor, T: float = 2.0,
+              loss_weight: float = 1.0, return_status: bool = False):
+    """DSKD loss 2, ``decode_v1`` (gfl_deformable_detr_head_il.py:664-718).
+    feats_* : per level [B,C,H,W]; boxes: per image [n_i,4] pixel xyxy (teacher order);
+    img_shapes: per image (h, w) un-padded.  Returns a scalar whose backward reaches hs_s."""
+    f = _dispatch_cpu("fgkd_loss", hs_s)
+    if f is not None:
+        return f(feats_s, feats_t, boxes, img_shapes, hs_t, keepid_t, hs_s, labels_s, prev_mask, T, loss_weight)
+    _need_gpu(hs_t, keepid_t, labels_s, prev_mask, *feats_s, *feats_t)
+    lib = load()
+    levels = len(feats_s)
+    B, Cc = feats_s[0].shape[:2]
+    N, D = hs_s.shape
+    fs = [t.detach().contiguous().float() for t in feats_s]
+    ft = [t.detach().contiguous().float() for t in feats_t]
+    shapes = []
+    for t in fs:
+        shapes += [t.shape[2], t.shape[3]]
+    starts = [0]
+    for bx in boxes:
+        starts.append(starts[-1] + int(bx.shape[0]))
+    M = starts[-1]
+    allb = (torch.cat([b.reshape(-1, 4) for b in boxes], 0) if M > 0 else hs_s.new_zeros((0, 4))).contiguous().float()
+    hw = [v for s in img_shapes for v in (float(s[0]), float(s[1]))]
+    sh = _host_i32(shapes)
+    ws = torch.empty(int(lib.dskd_fgkd_workspace(B, Cc, levels, sh, M, N)), dtype=torch.uint8, device=hs_s.device)
+    x = hs_s.detach().contiguous().float()
+    loss = torch.empty(1, dtype=torch.float32, device=x.device)
+    grad = torch.empty_like(x)
+    status = torch.zeros(1, dtype=torch.int32, device=x.device)
+    ps = (C.c_void_p * levels)(*[t.data_ptr() for t in fs])
+    pt = (C.c_void_p * levels)(*[t.data_ptr() for t in ft])
+    ht_, kt_ = hs_t.detach().contiguous().float(), keepid_t.contiguous().long()
+    ls_, pm_ = labels_s.contiguous().long(), prev_mask.contiguous().to(torch.uint8)
+    rc = lib.dskd_fgkd_fwd(ps, pt, sh, levels, B, Cc, allb.data_ptr(), _host_i32(starts), _host_f32(hw),
+                           ht_.data_ptr(), kt_.data_ptr(),
+                           x.data_ptr(), ls_.data_ptr(),
+                           pm_.data_ptr(), N, D, prev_mask.numel(), M,
+                           float(T), float(loss_weight), loss.data_ptr(), grad.data_ptr(), ws.data_ptr(),
+                           status.data_ptr(), _stream(x))
+    _check(rc, "dskd_fgkd_fwd")
+    out = _ScaledGrad.apply(hs_s, loss[0], grad.to(hs_s.dtype))
+    return (out, status) if return_status else out

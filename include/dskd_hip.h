@@ -1,0 +1,186 @@
+/*
+ * dskd_hip.h -- C-ABI of the MI355X (gfx950) hot-path library for DSKD.
+ *
+ * This is the drop-in boundary: plain pointers and sizes,
+ * no torch types.  Every pointer marked "device" is an HBM address owned by the
+ * caller (torch allocations in our host code); the library allocates nothing
+ * persistent, launches asynchronously on the passed stream (a hipStream_t passed
+ * as void*), and never throws.  Return value: 0 on success, a negative code on
+ * failure; dskd_last_error() then holds a human readable reason (thread local).
+ *
+ * Reference interfaces each entry point replaces (paths relative to the
+ * reference checkout, smilekitty7/DSKD):
+ *
+ *   dskd_msda_fwd / dskd_msda_bwd
+ *       ext-mmcv `MultiScaleDeformableAttnFunction.forward/backward`
+ *       (mmcv-full>=1.3.17,<=1.6.2, mmcv/ops/multi_scale_deform_attn.py),
+ *       imported at mmdet/models/utils/transformer.py:22-29 and reached through
+ *       the encoder/decoder calls at transformer.py:985-995 and :1032-1043.
+ *   dskd_lsap_host / dskd_lsap_batched
+ *       `scipy.optimize.linear_sum_assignment(cost)` at
+ *       mmdet/core/bbox/assigners/gfl_hungarian_assigner.py:143-151.
+ *   dskd_match_cost
+ *       the cost build of `GFLHungarianAssigner.assign`
+ *       (gfl_hungarian_assigner.py:120-140) = BBoxL1Cost + IoUCost +
+ *       QualityFocalLossCost (mmdet/core/bbox/match_costs/match_cost.py:34-51,
+ *       :193-230, :460-476).
+ *   dskd_proto_corr_fwd
+ *       prototype accumulation + `correlation_mat` + MSELoss
+ *       (mmdet/models/dense_heads/gfl_deformable_detr_head_il.py:525-555,
+ *       :1197-1222).
+ *   dskd_fgkd_fwd
+ *       the `decode_v1` feature distillation loop + KL loss
+ *       (gfl_deformable_detr_head_il.py:664-718, mmdet/models/losses/kd_loss.py:10-43).
+ */
+#ifndef DSKD_HIP_H
+#define DSKD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* value/out element type of the MSDA entry points */
+#define DSKD_DTYPE_F32 0
+#define DSKD_DTYPE_BF16 1
+
+#define DSKD_OK 0
+#define DSKD_ERR_INVALID_ARG (-1)   /* shape / pointer the kernels do not support   */
+#define DSKD_ERR_LAUNCH (-2)        /* HIP runtime refused the launch               */
+#define DSKD_ERR_INVALID_COST (-3)  /* scipy: "matrix contains invalid numeric entries" */
+#define DSKD_ERR_INFEASIBLE (-4)    /* scipy: "cost matrix is infeasible"           */
+
+/* ABI version of this header; bumped on any signature change. */
+int dskd_abi_version(void);
+/* Last error message of the calling thread ("" when none). */
+const char* dskd_last_error(void);
+/* Number of HIP devices visible to the library (0 when there is no GPU). */
+int dskd_device_count(void);
+
+/* ---------------------------------------------------------------------------
+ * Multi-scale deformable attention, sampling + aggregation.
+ *
+ *   out[b,q,h,:] = sum_{l,p} attn[b,q,h,l,p] * bilinear(value_l[b,:,h,:], loc[b,q,h,l,p])
+ *
+ * value          device, [B, Nv, heads, ch]   f32 or bf16 (dtype)
+ * spatial_shapes host,   [levels, 2] int64    (H_l, W_l)
+ * level_start    host,   [levels]   int64     row offset of level l inside Nv
+ * loc            device, [B, Nq, heads, levels, points, 2] f32, (x, y) in [0,1]
+ * attn           device, [B, Nq, heads, levels, points]    f32
+ * out            device, [B, Nq, heads*ch]    same dtype as value
+ * Supported: heads == 8, ch == 32, levels <= 4, levels*points <= 16.
+ * ------------------------------------------------------------------------- */
+int dskd_msda_fwd(const void* value, const int64_t* spatial_shapes,
+                  const int64_t* level_start, const float* loc, const float* attn,
+                  void* out, int B, int Nv, int Nq, int heads, int ch, int levels,
+                  int points, int dtype, void* stream);
+
+/* Backward of the above.
+ * grad_out    device, [B, Nq, heads*ch]  same dtype as value
+ * grad_value  device, [B, Nv, heads, ch] f32, MUST be zeroed by the caller
+ *             (contributions are accumulated with float atomics)
+ * grad_loc    device, [B, Nq, heads, levels, points, 2] f32 (overwritten)
+ * grad_attn   device, [B, Nq, heads, levels, points]    f32 (overwritten)
+ */
+int dskd_msda_bwd(const void* value, const int64_t* spatial_shapes,
+                  const int64_t* level_start, const float* loc, const float* attn,
+                  const void* grad_out, float* grad_value, float* grad_loc,
+                  float* grad_attn, int B, int Nv, int Nq, int heads, int ch,
+                  int levels, int points, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Rectangular linear sum assignment, bit-exact with scipy 1.15.3
+ * `linear_sum_assignment` (shortest augmenting path, Crouse 2016), including
+ * its tie breaking, the transpose when nr > nc, and the row-sorted output.
+ *
+ * Host version: cost is a host pointer, [nr, nc] row-major f32 (cast to f64
+ * exactly like scipy does with a float32 array). row/col hold min(nr,nc) pairs.
+ * ------------------------------------------------------------------------- */
+int dskd_lsap_host(const float* cost, int nr, int nc, int64_t* row, int64_t* col);
+
+/* Batched device version: nprob independent problems in ONE launch.
+ * cost     device, problem p is [nr[p], nc[p]] row-major f32 at cost + offsets[p]
+ * nr, nc   host,   [nprob] int32
+ * offsets  host,   [nprob] int64 (element offsets)
+ * row,col  device, int64; problem p writes min(nr,nc) pairs at out_offsets[p]
+ * out_offsets host, [nprob] int64
+ * status   device, [nprob] int32: 0 ok, DSKD_ERR_INVALID_COST / _INFEASIBLE
+ * Limits: min(nr,nc) <= 1024 and max(nr,nc) <= 1024.
+ */
+int dskd_lsap_batched(const float* cost, const int32_t* nr, const int32_t* nc,
+                      const int64_t* offsets, int nprob, int64_t* row, int64_t* col,
+                      const int64_t* out_offsets, int32_t* status, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Fused matching cost of GFLHungarianAssigner for nprob (layer, image) problems.
+ *
+ * bbox_pred  device, [nprob, Q, 4] f32 normalised (cx, cy, w, h)
+ * cls_pred   device, [nprob, Q, C] f32 logits
+ * gt_bboxes  device, [sum G, 4]    f32 pixel (x1, y1, x2, y2), problems concatenated
+ * gt_labels  device, [sum G]       int64
+ * gt_start   host,   [nprob + 1]   int64 prefix offsets into gt_bboxes/gt_labels
+ * img_wh     host,   [nprob, 2]    f32 (img_w, img_h) of the un-padded image
+ * cost       device, problem p is [Q, G_p] row-major f32 at cost + Q*gt_start[p]
+ * weights: w_cls (QFL cost), w_reg (L1 on cxcywh), w_iou (-GIoU)
+ * ------------------------------------------------------------------------- */
+int dskd_match_cost(const float* bbox_pred, const float* cls_pred,
+                    const float* gt_bboxes, const int64_t* gt_labels,
+                    const int64_t* gt_start, const float* img_wh, float* cost,
+                    int nprob, int Q, int C, float w_cls, float w_reg, float w_iou,
+                    void* stream);
+
+/* ---------------------------------------------------------------------------
+ * DSKD loss 1: between-class distance-matrix distillation.
+ *
+ * hs_s        device, [N, D] f32   student last-layer query embeddings (N = B*Q)
+ * labels_s    device, [N] int64    assigned labels of the last decoder layer
+ * prev_mask   device, [C] uint8    1 where class id is a previous-task label
+ * hs_t        device, [N, D] f32   teacher last-layer query embeddings
+ * keepid_t    device, [M] int64    flattened teacher query index per detection
+ * labels_t    device, [M] int64    teacher label per detection
+ * L           number of previous classes (rows kept, reference `[:prev_length]`)
+ * loss        device, [1] f32      MSE(D_t, D_s).mean() / L * loss_weight
+ * grad_hs_s   device, [N, D] f32   d loss / d hs_s (overwritten, dense)
+ * workspace   device, >= dskd_proto_corr_workspace(L, D) bytes
+ * ------------------------------------------------------------------------- */
+int64_t dskd_proto_corr_workspace(int L, int D);
+int dskd_proto_corr_fwd(const float* hs_s, const int64_t* labels_s,
+                        const uint8_t* prev_mask, const float* hs_t,
+                        const int64_t* keepid_t, const int64_t* labels_t, int N,
+                        int D, int C, int M, int L, float loss_weight, float* loss,
+                        float* grad_hs_s, void* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * DSKD loss 2 (`decode_v1`): semantic-guided feature-map distillation.
+ *
+ * feat_s[l], feat_t[l]  device, [B, C, H_l, W_l] f32 student / teacher neck maps
+ *                       (host arrays of `levels` device pointers)
+ * shapes      host,   [levels, 2] int32 (H_l, W_l)
+ * boxes       device, [M, 4] f32 teacher boxes, pixel xyxy, images concatenated
+ * box_start   host,   [B + 1] int32 prefix offsets of boxes per image
+ * img_hw      host,   [B, 2]  f32 (img_h, img_w) un-padded
+ * hs_t        device, [N, D] f32; keepid_t device [M] int64 (teacher row per box)
+ * hs_s        device, [N, D] f32; labels_s device [N] int64; prev_mask device [C]
+ *             the k-th student row (ascending) whose label is a previous-task
+ *             label is paired with box k (reference `id_pred`)
+ * T, loss_weight  KL temperature and weight
+ * loss        device, [1] f32   sum over levels and images / B
+ * grad_hs_s   device, [N, D] f32 d loss / d hs_s (overwritten, dense)
+ * workspace   device, >= dskd_fgkd_workspace(...) bytes
+ * status      device, [1] int32: 0 ok, 1 when fewer paired student rows than boxes
+ * Requires C == D (the reference multiplies a D-vector into C channels).
+ * ------------------------------------------------------------------------- */
+int64_t dskd_fgkd_workspace(int B, int C, int levels, const int32_t* shapes, int M, int N);
+int dskd_fgkd_fwd(const float* const* feat_s, const float* const* feat_t,
+                  const int32_t* shapes, int levels, int B, int C,
+                  const float* boxes, const int32_t* box_start, const float* img_hw,
+                  const float* hs_t, const int64_t* keepid_t, const float* hs_s,
+                  const int64_t* labels_s, const uint8_t* prev_mask, int N, int D,
+                  int NC, int M, float T, float loss_weight, float* loss,
+                  float* grad_hs_s, void* workspace, int32_t* status, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSKD_HIP_H */

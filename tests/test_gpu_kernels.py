@@ -1,0 +1,295 @@
+"""Parity of every HIP kernel against the CPU oracle, through the C-ABI (-m gpu)."""
+import numpy as np
+import pytest
+import torch
+
+from dskd_amd import native
+from oracle import assign_ref, dskd_losses_ref, msda_ref
+from oracle.lsap_ref import linear_sum_assignment as oracle_lsa
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+SHAPES_SMALL = [(12, 17), (6, 9), (3, 5), (2, 3)]
+SHAPES_FULL = [(100, 167), (50, 84), (25, 42), (13, 21)]   # 800x1333 input, BASELINE.json
+
+
+def _msda_inputs(shapes, B, Nq, seed, spread=1.3, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    Nv = sum(h * w for h, w in shapes)
+    value = torch.randn(B, Nv, 8, 32, generator=g)
+    loc = torch.rand(B, Nq, 8, len(shapes), 4, 2, generator=g) * spread - (spread - 1) / 2
+    attn = torch.softmax(torch.randn(B, Nq, 8, len(shapes) * 4, generator=g), -1).view(B, Nq, 8, len(shapes), 4)
+    return value.to(dtype), loc, attn
+
+
+@pytest.mark.parametrize("B,Nq,seed", [(1, 1, 0), (2, 37, 1), (3, 300, 2), (1, 431, 3)])
+def test_msda_fwd_f32_small(B, Nq, seed):
+    value, loc, attn = _msda_inputs(SHAPES_SMALL, B, Nq, seed)
+    ref = msda_ref.msda_grid_sample(value, SHAPES_SMALL, loc, attn)
+    out = native.msda_forward_raw(value.to(DEV), SHAPES_SMALL, loc.to(DEV), attn.to(DEV)).cpu()
+    torch.testing.assert_close(out, ref, atol=1e-5, rtol=1e-4)
+
+
+def test_msda_fwd_edge_locations():
+    """Exactly on borders, far outside, NaN: zero padding like grid_sample."""
+    value, loc, attn = _msda_inputs(SHAPES_SMALL, 1, 8, 5)
+    loc[0, 0] = 0.0
+    loc[0, 1] = 1.0
+    loc[0, 2] = -3.0
+    loc[0, 3] = 7.5
+    loc[0, 4, :, :, :, 0] = 0.5 / 17
+    loc[0, 5, :, 0] = torch.tensor([0.0, 1.0])
+    ref = msda_ref.msda_grid_sample(value, SHAPES_SMALL, loc, attn)
+    out = native.msda_forward_raw(value.to(DEV), SHAPES_SMALL, loc.to(DEV), attn.to(DEV)).cpu()
+    torch.testing.assert_close(out, ref, atol=1e-5, rtol=1e-4)
+    # NaN location contributes nothing in the HIP op (mmcv's bounds test rejects it)
+    loc2 = loc.clone()
+    loc2[0, 6] = float("nan")
+    out2 = native.msda_forward_raw(value.to(DEV), SHAPES_SMALL, loc2.to(DEV), attn.to(DEV)).cpu()
+    assert torch.equal(out2[0, 6], torch.zeros(256))
+    torch.testing.assert_close(out2[0, :6], ref[0, :6], atol=1e-5, rtol=1e-4)
+
+
+def test_msda_fwd_bf16():
+    value, loc, attn = _msda_inputs(SHAPES_SMALL, 2, 301, 7)
+    vb = value.to(torch.bfloat16)
+    ref = msda_ref.msda_grid_sample(vb.float(), SHAPES_SMALL, loc, attn)
+    out = native.msda_forward_raw(vb.to(DEV), SHAPES_SMALL, loc.to(DEV), attn.to(DEV)).cpu()
+    assert out.dtype == torch.bfloat16
+    # output rounding to bf16: 2^-8 relative
+    torch.testing.assert_close(out.float(), ref, atol=2e-2, rtol=1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_msda_bwd_small(dtype):
+    value, loc, attn = _msda_inputs(SHAPES_SMALL, 2, 203, 11, dtype=dtype)
+    g = torch.Generator().manual_seed(12)
+    go = torch.randn(2, 203, 256, generator=g).to(dtype)
+    v = value.float().requires_grad_(True)
+    l = loc.clone().requires_grad_(True)
+    a = attn.clone().requires_grad_(True)
+    msda_ref.msda_grid_sample(v, SHAPES_SMALL, l, a).backward(go.float())
+    gv, gl, ga = native.msda_backward_raw(value.to(DEV), SHAPES_SMALL, loc.to(DEV), attn.to(DEV), go.to(DEV))
+    tol = dict(atol=1e-4, rtol=1e-3) if dtype == torch.float32 else dict(atol=2e-3, rtol=2e-3)
+    torch.testing.assert_close(gv.cpu(), v.grad, **tol)
+    torch.testing.assert_close(ga.cpu(), a.grad, **tol)
+    torch.testing.assert_close(gl.cpu(), l.grad, atol=tol["atol"] * 20, rtol=tol["rtol"])
+
+
+def test_msda_autograd_function():
+    value, loc, attn = _msda_inputs(SHAPES_SMALL, 1, 50, 13)
+    v = value.to(DEV).requires_grad_(True)
+    l = loc.to(DEV).requires_grad_(True)
+    a = attn.to(DEV).requires_grad_(True)
+    out = native.ms_deform_attn(v, SHAPES_SMALL, l, a)
+    out.square().sum().backward()
+    vr, lr, ar = value.clone().requires_grad_(True), loc.clone().requires_grad_(True), attn.clone().requires_grad_(True)
+    msda_ref.msda_grid_sample(vr, SHAPES_SMALL, lr, ar).square().sum().backward()
+    torch.testing.assert_close(v.grad.cpu(), vr.grad, atol=1e-4, rtol=1e-3)
+    torch.testing.assert_close(a.grad.cpu(), ar.grad, atol=1e-4, rtol=1e-3)
+
+
+def test_msda_full_size_properties():
+    """BASELINE size (Nq = Nv = 22223): linearity in value and in attn, decoder-size parity."""
+    B = 2
+    value, loc, attn = _msda_inputs(SHAPES_FULL, B, 22223, 21, spread=1.05)
+    vd, ld, ad = value.to(DEV), loc.to(DEV), attn.to(DEV)
+    o1 = native.msda_forward_raw(vd, SHAPES_FULL, ld, ad)
+    o2 = native.msda_forward_raw(vd * 2.0, SHAPES_FULL, ld, ad)
+    torch.testing.assert_close(o2, o1 * 2.0, atol=1e-5, rtol=1e-5)
+    o3 = native.msda_forward_raw(vd, SHAPES_FULL, ld, ad * 0.5)
+    torch.testing.assert_close(o3, o1 * 0.5, atol=1e-5, rtol=1e-5)
+    # constant value + weights summing to 1 with all samples inside -> constant output
+    loc_in = (loc * 0.5 + 0.25).to(DEV)
+    oc = native.msda_forward_raw(torch.ones_like(vd), SHAPES_FULL, loc_in, ad)
+    torch.testing.assert_close(oc, torch.ones_like(oc), atol=1e-5, rtol=1e-5)
+    # oracle on a slice of queries at full value size
+    sl = slice(5000, 5600)
+    ref = msda_ref.msda_grid_sample(value, SHAPES_FULL, loc[:, sl], attn[:, sl])
+    torch.testing.assert_close(o1[:, sl].cpu(), ref, atol=1e-5, rtol=1e-4)
+    # backward: sum of grad_value equals sum over valid samples of attn*grad (conservation)
+    go = torch.ones(B, 22223, 256, device=DEV)
+    gv, gl, ga = native.msda_backward_raw(torch.ones_like(vd), SHAPES_FULL, loc_in, ad, go)
+    torch.testing.assert_close(gv.sum(), torch.tensor(float(B * 22223 * 256), device=DEV), rtol=1e-4, atol=1.0)
+    # d out / d attn with value == 1 is 32 (channels) for inside samples
+    torch.testing.assert_close(ga, torch.full_like(ga, 32.0), atol=1e-3, rtol=1e-4)
+
+
+# ----------------------------------------------------------------------------- LSAP
+def _lsap_device(mats):
+    flat = torch.cat([torch.from_numpy(m).reshape(-1) for m in mats]).to(DEV)
+    nr = [m.shape[0] for m in mats]
+    nc = [m.shape[1] for m in mats]
+    offs = np.cumsum([0] + [m.size for m in mats])[:-1].tolist()
+    row, col, outs, status = native.lsap_batched(flat, nr, nc, offs)
+    row, col, status = row.cpu().numpy(), col.cpu().numpy(), status.cpu().numpy()
+    res = []
+    for p, m in enumerate(mats):
+        n = min(m.shape)
+        res.append((row[outs[p]:outs[p] + n], col[outs[p]:outs[p] + n], status[p]))
+    return res
+
+
+def test_lsap_device_bit_exact():
+    from scipy.optimize import linear_sum_assignment as sp
+    rng = np.random.default_rng(0)
+    mats = []
+    for t in range(400):
+        nr, nc = rng.integers(1, 14), rng.integers(1, 14)
+        kind = t % 4
+        if kind == 0:
+            c = rng.integers(0, 4, size=(nr, nc))
+        elif kind == 1:
+            c = np.round(rng.normal(size=(nr, nc)), 1)
+        elif kind == 2:
+            c = rng.random((nr, nc))
+            c[:, rng.integers(0, nc)] = c[:, 0]
+        else:
+            c = rng.random((nr, nc))
+        mats.append(c.astype(np.float32))
+    for G in (1, 5, 17, 60, 100, 110, 300, 310):
+        mats.append(rng.random((300, G)).astype(np.float32))
+        mats.append(rng.integers(0, 5, size=(300, G)).astype(np.float32))
+    mats.append(rng.random((1024, 3)).astype(np.float32))
+    mats.append(rng.random((7, 1024)).astype(np.float32))
+    c = rng.random((6, 9)).astype(np.float32)
+    c[2, 4] = np.inf
+    mats.append(c)
+    res = _lsap_device(mats)
+    for m, (r, c_, st) in zip(mats, res):
+        assert st == 0
+        a = sp(m)
+        b = oracle_lsa(m)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        assert np.array_equal(r, a[0]) and np.array_equal(c_, a[1]), (m.shape,)
+
+
+def test_lsap_device_errors():
+    rng = np.random.default_rng(1)
+    bad = rng.random((5, 7)).astype(np.float32)
+    bad[1, 1] = np.nan
+    ninf = rng.random((5, 7)).astype(np.float32)
+    ninf[0, 0] = -np.inf
+    infeasible = rng.random((5, 7)).astype(np.float32)
+    infeasible[3, :] = np.inf
+    ok = rng.random((5, 7)).astype(np.float32)
+    res = _lsap_device([bad, ninf, infeasible, ok])
+    assert [r[2] for r in res] == [-3, -3, -4, 0]
+    with pytest.raises(ValueError, match="invalid numeric"):
+        native.raise_for_lsap_status(torch.tensor([0, -3]))
+    with pytest.raises(ValueError, match="infeasible"):
+        native.raise_for_lsap_status(torch.tensor([-4]))
+
+
+# ----------------------------------------------------------------------------- cost
+def test_match_cost_vs_oracle():
+    g = torch.Generator().manual_seed(3)
+    P, Q, C = 5, 300, 80
+    Gs = [17, 1, 0, 60, 9]
+    bbox = torch.rand(P, Q, 4, generator=g) * torch.tensor([1.0, 1.0, 0.5, 0.5])
+    cls = torch.randn(P, Q, C, generator=g) * 3
+    gts, labs, start, wh = [], [], [0], []
+    for p in range(P):
+        w, h = 1333.0 - 10 * p, 800.0 - 3 * p
+        xy = torch.rand(Gs[p], 2, generator=g) * torch.tensor([0.6 * w, 0.6 * h])
+        sz = torch.rand(Gs[p], 2, generator=g) * torch.tensor([0.35 * w, 0.35 * h]) + 8
+        gts.append(torch.cat([xy, xy + sz], 1))
+        labs.append(torch.randint(0, C, (Gs[p],), generator=g))
+        start.append(start[-1] + Gs[p])
+        wh.append((w, h))
+    gt = torch.cat(gts)
+    lab = torch.cat(labs)
+    cost = native.match_cost(bbox.to(DEV), cls.to(DEV), gt.to(DEV), lab.to(DEV), start, wh, 2.0, 5.0, 2.0).cpu()
+    for p in range(P):
+        if Gs[p] == 0:
+            continue
+        ref = assign_ref.cost_matrix(bbox[p], cls[p], gts[p], labs[p], wh[p][0], wh[p][1])
+        got = cost[Q * start[p]: Q * start[p + 1]].view(Q, Gs[p])
+        torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------- DSKD losses
+def _loss_inputs(B, L, seed, n_t=10, n_gt=7, C=80, D=256):
+    g = torch.Generator().manual_seed(seed)
+    N = B * 300
+    hs_s = torch.randn(N, D, generator=g)
+    hs_t = hs_s + 0.1 * torch.randn(N, D, generator=g)
+    labels = torch.full((N,), C, dtype=torch.long)
+    keep, lab_t = [], []
+    for b in range(B):
+        perm = torch.randperm(300, generator=g)
+        tl = torch.randint(0, L, (n_t,), generator=g)
+        labels[b * 300 + perm[:n_t].sort().values] = tl           # one student query per teacher box
+        labels[b * 300 + perm[n_t:n_t + n_gt]] = torch.randint(L, C, (n_gt,), generator=g)
+        keep.append(b * 300 + torch.randperm(300, generator=g)[:n_t])
+        lab_t.append(tl)
+    prev = torch.zeros(C, dtype=torch.bool)
+    prev[:L] = True
+    return hs_s, hs_t, labels, torch.cat(keep), torch.cat(lab_t), prev
+
+
+@pytest.mark.parametrize("B,L", [(1, 40), (4, 70), (2, 5)])
+def test_proto_corr_vs_oracle(B, L):
+    hs_s, hs_t, labels, keep, lab_t, prev = _loss_inputs(B, L, 100 + B)
+    x = hs_s.clone().requires_grad_(True)
+    ref = dskd_losses_ref.proto_corr_loss(x, labels, prev, hs_t, keep, lab_t, L, 1.0)
+    ref.backward()
+    xd = hs_s.to(DEV).requires_grad_(True)
+    out = native.proto_corr_loss(xd, labels.to(DEV), prev.to(DEV), hs_t.to(DEV), keep.to(DEV), lab_t.to(DEV), L, 1.0)
+    out.backward()
+    torch.testing.assert_close(out.cpu(), ref.detach(), rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(xd.grad.cpu(), x.grad, rtol=1e-3, atol=1e-7)
+
+
+def _fg_inputs(B, shapes, seed, n_t, img_hw):
+    g = torch.Generator().manual_seed(seed)
+    hs_s, hs_t, labels, keep, lab_t, prev = _loss_inputs(B, 40, seed, n_t=n_t)
+    fs = [torch.randn(B, 256, h, w, generator=g) for h, w in shapes]
+    ft = [f + 0.3 * torch.randn(f.shape, generator=g) for f in fs]
+    boxes = []
+    for b in range(B):
+        H, W = img_hw[b]
+        xy = torch.rand(n_t, 2, generator=g) * torch.tensor([0.6 * W, 0.6 * H])
+        sz = torch.rand(n_t, 2, generator=g) * torch.tensor([0.35 * W, 0.35 * H]) + 8
+        bx = torch.cat([xy, xy + sz], 1)
+        bx[:, 0::2].clamp_(0, W)
+        bx[:, 1::2].clamp_(0, H)
+        boxes.append(bx)
+    return fs, ft, boxes, hs_s, hs_t, labels, keep, prev
+
+
+@pytest.mark.parametrize("B,shapes,n_t", [(1, [(13, 21), (7, 11)], 3), (2, [(25, 42), (13, 21), (7, 11), (4, 6)], 6)])
+def test_fgkd_vs_oracle(B, shapes, n_t):
+    img_hw = [(200 - 7 * b, 333 - 5 * b) for b in range(B)]
+    fs, ft, boxes, hs_s, hs_t, labels, keep, prev = _fg_inputs(B, shapes, 200 + B, n_t, img_hw)
+    x = hs_s.clone().requires_grad_(True)
+    ref = dskd_losses_ref.fgkd_loss(fs, ft, boxes, img_hw, hs_t, keep, x, labels, prev, 2.0, 1.0)
+    ref.backward()
+    xd = hs_s.to(DEV).requires_grad_(True)
+    out, status = native.fgkd_loss([f.to(DEV) for f in fs], [f.to(DEV) for f in ft], [b.to(DEV) for b in boxes],
+                                   img_hw, hs_t.to(DEV), keep.to(DEV), xd, labels.to(DEV), prev.to(DEV), 2.0, 1.0,
+                                   return_status=True)
+    out.backward()
+    assert int(status.item()) == 0
+    torch.testing.assert_close(out.cpu(), ref.detach(), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(xd.grad.cpu(), x.grad, rtol=1e-3, atol=1e-7)
+
+
+def test_fgkd_full_size_properties():
+    """BASELINE feature sizes: identical teacher/student features give exactly zero loss and
+    zero gradient (KL of equal distributions), and no boxes gives zero as well."""
+    B = 2
+    img_hw = [(800, 1333)] * B
+    fs, ft, boxes, hs_s, hs_t, labels, keep, prev = _fg_inputs(B, SHAPES_FULL, 300, 10, img_hw)
+    fsd = [f.to(DEV) for f in fs]
+    xd = hs_s.to(DEV).requires_grad_(True)
+    out = native.fgkd_loss(fsd, fsd, [b.to(DEV) for b in boxes], img_hw, hs_t.to(DEV), keep.to(DEV), xd,
+                           labels.to(DEV), prev.to(DEV), 2.0, 1.0)
+    out.backward()
+    assert abs(float(out)) < 1e-3
+    assert float(xd.grad.abs().max()) < 1e-5
+    # real case is positive and finite
+    out2 = native.fgkd_loss(fsd, [f.to(DEV) for f in ft], [b.to(DEV) for b in boxes], img_hw, hs_t.to(DEV),
+                            keep.to(DEV), xd, labels.to(DEV), prev.to(DEV), 2.0, 1.0)
+    assert float(out2) > 0 and np.isfinite(float(out2))
