@@ -1,0 +1,182 @@
+"""ResNet backbone with the reference's constructor surface and state-dict names
+(/root/reference/mmdet/models/backbones/resnet.py:306-659: ``ResNet``; forward :631-646,
+``_freeze_stages`` :613-629, ``train`` / norm_eval :648-659; ``Bottleneck`` :100-303 with
+style='pytorch' = stride on the 3x3 conv).  Dense convolutions run on MIOpen/hipBLASLt (MFMA)
+through PyTorch-ROCm; nothing here is hand-written."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .builder import BACKBONES
+
+
+class FrozenAffineBN(nn.BatchNorm2d):
+    """BatchNorm2d whose forward, in eval mode, is a fused per-channel scale/shift
+    (what ``norm_eval=True`` + ``requires_grad=False`` make of every BN of this backbone)."""
+
+    def forward(self, x):
+        if self.training:
+            return super().forward(x)
+        scale = self.weight * torch.rsqrt(self.running_var + self.eps)
+        shift = self.bias - self.running_mean * scale
+        return x * scale.to(x.dtype).view(1, -1, 1, 1) + shift.to(x.dtype).view(1, -1, 1, 1)
+
+
+def _bn(ch, requires_grad):
+    bn = FrozenAffineBN(ch)
+    for p in bn.parameters():
+        p.requires_grad = requires_grad
+    return bn
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, style="pytorch",
+                 bn_requires_grad=True):
+        super().__init__()
+        assert style in ("pytorch", "caffe")
+        s1, s2 = (1, stride) if style == "pytorch" else (stride, 1)
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, stride=s1, bias=False)
+        self.bn1 = _bn(planes, bn_requires_grad)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=s2, padding=dilation, dilation=dilation, bias=False)
+        self.bn2 = _bn(planes, bn_requires_grad)
+        self.conv3 = nn.Conv2d(planes, planes * self.expansion, 1, bias=False)
+        self.bn3 = _bn(planes * self.expansion, bn_requires_grad)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x
+        out = F.relu(self.bn1(self.conv1(x)), inplace=True)
+        out = F.relu(self.bn2(self.conv2(out)), inplace=True)
+        out = self.bn3(self.conv3(out))
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        return F.relu(out + identity, inplace=True)
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, style="pytorch",
+                 bn_requires_grad=True):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride=stride, padding=dilation, dilation=dilation, bias=False)
+        self.bn1 = _bn(planes, bn_requires_grad)
+        self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
+        self.bn2 = _bn(planes, bn_requires_grad)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x
+        out = F.relu(self.bn1(self.conv1(x)), inplace=True)
+        out = self.bn2(self.conv2(out))
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        return F.relu(out + identity, inplace=True)
+
+
+@BACKBONES.register_module()
+class ResNet(nn.Module):
+    arch_settings = {
+        18: (BasicBlock, (2, 2, 2, 2)),
+        34: (BasicBlock, (3, 4, 6, 3)),
+        50: (Bottleneck, (3, 4, 6, 3)),
+        101: (Bottleneck, (3, 4, 23, 3)),
+        152: (Bottleneck, (3, 8, 36, 3)),
+    }
+
+    def __init__(self, depth, in_channels=3, stem_channels=None, base_channels=64, num_stages=4,
+                 strides=(1, 2, 2, 2), dilations=(1, 1, 1, 1), out_indices=(0, 1, 2, 3), style="pytorch",
+                 deep_stem=False, avg_down=False, frozen_stages=-1, conv_cfg=None,
+                 norm_cfg=dict(type="BN", requires_grad=True), norm_eval=True, dcn=None,
+                 stage_with_dcn=(False, False, False, False), plugins=None, with_cp=False,
+                 zero_init_residual=True, pretrained=None, init_cfg=None):
+        super().__init__()
+        if depth not in self.arch_settings:
+            raise KeyError(f"invalid depth {depth} for resnet")
+        assert not deep_stem and not avg_down and dcn is None and plugins is None, \
+            "only the plain ResNet of the DSKD configs is implemented"
+        assert norm_cfg.get("type", "BN") == "BN"
+        self.depth = depth
+        self.out_indices = out_indices
+        self.frozen_stages = frozen_stages
+        self.norm_eval = norm_eval
+        self.init_cfg = init_cfg
+        self.zero_init_residual = zero_init_residual
+        bn_rg = norm_cfg.get("requires_grad", True)
+        stem = stem_channels or base_channels
+        block, stage_blocks = self.arch_settings[depth]
+        self.conv1 = nn.Conv2d(in_channels, stem, 7, stride=2, padding=3, bias=False)
+        self.bn1 = _bn(stem, bn_rg)
+        self.res_layers = []
+        inplanes = stem
+        for i, nblk in enumerate(stage_blocks[:num_stages]):
+            planes = base_channels * 2 ** i
+            layers = []
+            for j in range(nblk):
+                stride = strides[i] if j == 0 else 1
+                down = None
+                if j == 0 and (stride != 1 or inplanes != planes * block.expansion):
+                    down = nn.Sequential(nn.Conv2d(inplanes, planes * block.expansion, 1, stride=stride, bias=False),
+                                         _bn(planes * block.expansion, bn_rg))
+                layers.append(block(inplanes, planes, stride, dilations[i], down, style, bn_rg))
+                inplanes = planes * block.expansion
+            name = f"layer{i + 1}"
+            self.add_module(name, nn.Sequential(*layers))
+            self.res_layers.append(name)
+        self.feat_dim = inplanes
+        self._freeze_stages()
+
+    def init_weights(self):
+        """kaiming for convs, constant for norms (resnet.py:371-385 default init_cfg); a
+        'Pretrained' init_cfg is honoured when the checkpoint file exists."""
+        ck = (self.init_cfg or {}).get("checkpoint") if isinstance(self.init_cfg, dict) else None
+        import os
+        if ck and os.path.isfile(ck):
+            sd = torch.load(ck, map_location="cpu")
+            self.load_state_dict(sd.get("state_dict", sd), strict=False)
+            return
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        if self.zero_init_residual:
+            for m in self.modules():
+                if isinstance(m, Bottleneck):
+                    nn.init.constant_(m.bn3.weight, 0)
+                elif isinstance(m, BasicBlock):
+                    nn.init.constant_(m.bn2.weight, 0)
+
+    def _freeze_stages(self):
+        if self.frozen_stages >= 0:
+            self.bn1.eval()
+            for m in (self.conv1, self.bn1):
+                for p in m.parameters():
+                    p.requires_grad = False
+        for i in range(1, self.frozen_stages + 1):
+            m = getattr(self, f"layer{i}")
+            m.eval()
+            for p in m.parameters():
+                p.requires_grad = False
+
+    def forward(self, x):
+        x = F.relu(self.bn1(self.conv1(x)), inplace=True)
+        x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+        outs = []
+        for i, name in enumerate(self.res_layers):
+            x = getattr(self, name)(x)
+            if i in self.out_indices:
+                outs.append(x)
+        return tuple(outs)
+
+    def train(self, mode=True):
+        super().train(mode)
+        self._freeze_stages()
+        if mode and self.norm_eval:
+            for m in self.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.eval()
+        return self

@@ -150,11 +150,12 @@ __global__ __launch_bounds__(256) void fgkd_owner_kernel(const float* __restrict
 
 // ---------------------------------------------------------------- fused KL + mask gradient
 struct ColStat {
-  float A, Za, S, Bm, Zb;
+  float A, Za, S, Bm, Zb, U;
 };
 
 __device__ __forceinline__ void stat_push(ColStat& st, float a, float b) {
-  // online softmax statistics: Za = sum exp(a-A), S = sum exp(a-A)(a-b), Zb = sum exp(b-Bm)
+  // online softmax statistics: Za = sum exp(a-A), S = sum exp(a-A)(a-b), Zb = sum exp(b-Bm),
+  // U = sum exp(b-Bm) expm1(a-b)
   if (a > st.A) {
     const float r = expf(st.A - a);
     st.Za *= r;
@@ -165,10 +166,14 @@ __device__ __forceinline__ void stat_push(ColStat& st, float a, float b) {
   st.Za += ea;
   st.S = fmaf(ea, a - b, st.S);
   if (b > st.Bm) {
-    st.Zb *= expf(st.Bm - b);
+    const float r = expf(st.Bm - b);
+    st.Zb *= r;
+    st.U *= r;
     st.Bm = b;
   }
-  st.Zb += expf(b - st.Bm);
+  const float eb = expf(b - st.Bm);
+  st.Zb += eb;
+  st.U = fmaf(eb, expm1f(a - b), st.U);
 }
 
 __device__ __forceinline__ void stat_merge(ColStat& x, const ColStat& y) {
@@ -182,6 +187,7 @@ __device__ __forceinline__ void stat_merge(ColStat& x, const ColStat& y) {
   const float qx = x.Bm == Bm ? 1.f : expf(x.Bm - Bm);
   const float qy = y.Bm == Bm ? 1.f : expf(y.Bm - Bm);
   x.Zb = x.Zb * qx + y.Zb * qy;
+  x.U = x.U * qx + y.U * qy;
   x.Bm = Bm;
 }
 
@@ -224,7 +230,7 @@ __global__ __launch_bounds__(kStrip * kRowGroups) void fgkd_kl_kernel(
   const float invT = 1.f / T;
 
   ColStat st;
-  st.A = -INFINITY; st.Za = 0.f; st.S = 0.f; st.Bm = -INFINITY; st.Zb = 0.f;
+  st.A = -INFINITY; st.Za = 0.f; st.S = 0.f; st.Bm = -INFINITY; st.Zb = 0.f; st.U = 0.f;
   for (int h = rg; h < H; h += kRowGroups) {
     float a = 0.f, b = 0.f, ftv = 0.f;
     short o = -1;
@@ -251,8 +257,11 @@ __global__ __launch_bounds__(kStrip * kRowGroups) void fgkd_kl_kernel(
   for (int g = 1; g < kRowGroups; ++g) stat_merge(cs, s_st[g * kStrip + col]);
   float klcol = 0.f;
   if (wv && rg == 0) {
-    // sum_h t_h (log t_h - log p_h) = S/Za - (A + log Za) + (Bm + log Zb)
-    klcol = cs.S / cs.Za - (cs.A + logf(cs.Za)) + (cs.Bm + logf(cs.Zb));
+    // sum_h t_h (log t_h - log p_h) = sum_h t_h d_h - (lse(a) - lse(b)),  d = a - b.
+    // lse(a) - lse(b) = log1p(sum_h p_h expm1(d_h)): both terms are O(d) while the KL is
+    // O(d^2); the naive lse difference of two O(log H) numbers loses ~1% here in fp32
+    // (as the reference's own fp32 evaluation does -- see tests).
+    klcol = cs.S / cs.Za - log1pf(cs.U / cs.Zb);
     klcol *= T * T / (float)H;
   }
   if (rg == 0) {

@@ -98,15 +98,19 @@ __device__ __forceinline__ void point_params(float lx_n, float ly_n, float a, in
   }
 }
 
+// NOTE: __builtin_bit_cast applied directly to a vector ELEMENT lvalue (v.y, v[1]) reads
+// element 0 with this compiler (hipcc 7.2); always go through a scalar by-value helper.
+__device__ __forceinline__ float as_f32(unsigned u) { return __builtin_bit_cast(float, u); }
+
 __device__ __forceinline__ void unpack_bf16x8(const u32x4& v, float* f) {
-  f[0] = __builtin_bit_cast(float, v.x << 16);
-  f[1] = __builtin_bit_cast(float, v.x & 0xFFFF0000u);
-  f[2] = __builtin_bit_cast(float, v.y << 16);
-  f[3] = __builtin_bit_cast(float, v.y & 0xFFFF0000u);
-  f[4] = __builtin_bit_cast(float, v.z << 16);
-  f[5] = __builtin_bit_cast(float, v.z & 0xFFFF0000u);
-  f[6] = __builtin_bit_cast(float, v.w << 16);
-  f[7] = __builtin_bit_cast(float, v.w & 0xFFFF0000u);
+  f[0] = as_f32(v.x << 16);
+  f[1] = as_f32(v.x & 0xFFFF0000u);
+  f[2] = as_f32(v.y << 16);
+  f[3] = as_f32(v.y & 0xFFFF0000u);
+  f[4] = as_f32(v.z << 16);
+  f[5] = as_f32(v.z & 0xFFFF0000u);
+  f[6] = as_f32(v.w << 16);
+  f[7] = as_f32(v.w & 0xFFFF0000u);
 }
 
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
@@ -117,12 +121,13 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 
 template <typename T>
 __device__ __forceinline__ void load_vals(__amdgpu_buffer_rsrc_t rsrc, int voff, float* f) {
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+  // the builtin returns a GCC vector_size type: cast explicitly
+  const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
   if constexpr (sizeof(T) == 4) {
-    f[0] = __builtin_bit_cast(float, v.x);
-    f[1] = __builtin_bit_cast(float, v.y);
-    f[2] = __builtin_bit_cast(float, v.z);
-    f[3] = __builtin_bit_cast(float, v.w);
+    f[0] = as_f32(v.x);
+    f[1] = as_f32(v.y);
+    f[2] = as_f32(v.z);
+    f[3] = as_f32(v.w);
   } else {
     unpack_bf16x8(v, f);
   }

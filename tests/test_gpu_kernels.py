@@ -261,19 +261,29 @@ def _fg_inputs(B, shapes, seed, n_t, img_hw):
 
 @pytest.mark.parametrize("B,shapes,n_t", [(1, [(13, 21), (7, 11)], 3), (2, [(25, 42), (13, 21), (7, 11), (4, 6)], 6)])
 def test_fgkd_vs_oracle(B, shapes, n_t):
+    """The KL of two near-equal softmaxes is O(d^2) computed from O(log H) terms: the
+    reference's own fp32 evaluation carries ~1% rounding noise at these magnitudes (asserted
+    below against its float64 evaluation).  The HIP kernel is held to rtol 1e-4 of the float64
+    evaluation of the oracle (SURVEY.md section 8d tolerance) and the gradient to rtol 1e-3."""
     img_hw = [(200 - 7 * b, 333 - 5 * b) for b in range(B)]
     fs, ft, boxes, hs_s, hs_t, labels, keep, prev = _fg_inputs(B, shapes, 200 + B, n_t, img_hw)
-    x = hs_s.clone().requires_grad_(True)
-    ref = dskd_losses_ref.fgkd_loss(fs, ft, boxes, img_hw, hs_t, keep, x, labels, prev, 2.0, 1.0)
+    x32 = hs_s.clone().requires_grad_(True)
+    ref32 = dskd_losses_ref.fgkd_loss(fs, ft, boxes, img_hw, hs_t, keep, x32, labels, prev, 2.0, 1.0)
+    ref32.backward()
+    x = hs_s.double().requires_grad_(True)
+    ref = dskd_losses_ref.fgkd_loss([f.double() for f in fs], [f.double() for f in ft], [b.double() for b in boxes],
+                                    img_hw, hs_t.double(), keep, x, labels, prev, 2.0, 1.0)
     ref.backward()
+    torch.testing.assert_close(ref32.detach().double(), ref.detach(), rtol=5e-2, atol=0)   # reference noise floor
     xd = hs_s.to(DEV).requires_grad_(True)
     out, status = native.fgkd_loss([f.to(DEV) for f in fs], [f.to(DEV) for f in ft], [b.to(DEV) for b in boxes],
                                    img_hw, hs_t.to(DEV), keep.to(DEV), xd, labels.to(DEV), prev.to(DEV), 2.0, 1.0,
                                    return_status=True)
     out.backward()
     assert int(status.item()) == 0
-    torch.testing.assert_close(out.cpu(), ref.detach(), rtol=1e-4, atol=1e-6)
-    torch.testing.assert_close(xd.grad.cpu(), x.grad, rtol=1e-3, atol=1e-7)
+    torch.testing.assert_close(out.detach().cpu().double(), ref.detach(), rtol=1e-4, atol=1e-9)
+    torch.testing.assert_close(xd.grad.cpu().double(), x.grad, rtol=1e-3, atol=1e-9)
+    torch.testing.assert_close(xd.grad.cpu(), x32.grad, rtol=1e-3, atol=1e-8)
 
 
 def test_fgkd_full_size_properties():
@@ -287,9 +297,9 @@ def test_fgkd_full_size_properties():
     out = native.fgkd_loss(fsd, fsd, [b.to(DEV) for b in boxes], img_hw, hs_t.to(DEV), keep.to(DEV), xd,
                            labels.to(DEV), prev.to(DEV), 2.0, 1.0)
     out.backward()
-    assert abs(float(out)) < 1e-3
+    assert abs(float(out.detach())) < 1e-6
     assert float(xd.grad.abs().max()) < 1e-5
     # real case is positive and finite
     out2 = native.fgkd_loss(fsd, [f.to(DEV) for f in ft], [b.to(DEV) for b in boxes], img_hw, hs_t.to(DEV),
                             keep.to(DEV), xd, labels.to(DEV), prev.to(DEV), 2.0, 1.0)
-    assert float(out2) > 0 and np.isfinite(float(out2))
+    assert float(out2.detach()) > 0 and np.isfinite(float(out2.detach()))
