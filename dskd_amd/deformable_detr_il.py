@@ -1,0 +1,217 @@
+"""``DeformableDETR_il``: student detector holding a frozen, un-registered teacher copy.
+
+Restated from /root/reference/mmdet/models/detectors/deformable_detr_il.py
+(ctor :36-77, ``set_teacher`` :79-114, ``out_teacher`` :116-152, ``set_student`` :154-160,
+``set_datainfo`` :172-181, ``extract_feat`` :183-188, ``_parse_losses`` :210-253,
+``forward_train`` :255-318, ``train_step`` :419-450, ``cuda`` / ``train`` /
+``__setattr__`` :467-496).  ``_parse_losses`` keeps the reference's key set and values but
+reduces all log scalars with one collective and one device->host copy."""
+import copy
+from collections import OrderedDict
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from .builder import DETECTORS, build_backbone, build_head, build_neck
+from .dist import allreduce_scalars
+
+
+@DETECTORS.register_module()
+class DeformableDETR_il(nn.Module):
+    def __init__(self, backbone, neck, bbox_head, teacher_config=None, teacher_ckpt=None, eval_teacher=True,
+                 teacher_test_cfg=None, train_cfg=None, test_cfg=None, pretrained=None, init_cfg=None):
+        super().__init__()
+        object.__setattr__(self, "has_teacher", bool(teacher_config and teacher_ckpt))
+        backbone = dict(backbone)
+        if pretrained:
+            backbone["pretrained"] = pretrained
+        self.backbone = build_backbone(backbone)
+        self.neck = build_neck(dict(neck)) if neck is not None else None
+        bbox_head = dict(bbox_head)
+        bbox_head.update(train_cfg=train_cfg, test_cfg=test_cfg, has_teacher=self.has_teacher)
+        self.bbox_head = build_head(bbox_head)
+        self.train_cfg, self.test_cfg, self.teacher_test_cfg = train_cfg, test_cfg, teacher_test_cfg
+        self.Label2CatNameId = dict()
+        self.LableInPCNTask = {"prev": [], "curr": [], "next": []}
+        self.eval_teacher = eval_teacher
+        self.teacher_model = None
+        if self.has_teacher:
+            raise NotImplementedError("build the teacher with set_teacher(model=...) (config+ckpt loading is "
+                                      "the mmcv checkpoint path, SURVEY.md section 8f item 3)")
+        self.lazy_log = False   # True: train_step returns device log vars (no host sync)
+
+    @property
+    def with_neck(self):
+        return self.neck is not None
+
+    def init_weights(self):
+        self.backbone.init_weights()
+        if self.with_neck:
+            self.neck.init_weights()
+        self.bbox_head.init_weights()
+
+    # ------------------------------------------------------------------ teacher / task state
+    def set_teacher(self, config=None, ckptfile=None, model=None, trainval="val"):
+        """:79-114."""
+        if (config is None or ckptfile is None) and model is None:
+            self.has_teacher = False
+            self.bbox_head.has_teacher = False
+            return None
+        if model is None:
+            from .builder import build_detector
+            from .config import Config
+            if isinstance(config, str):
+                config = Config.fromfile(config)
+            model = build_detector(config["model"])
+            sd = torch.load(ckptfile, map_location="cpu")
+            model.load_state_dict(sd.get("state_dict", sd), strict=False)
+        self.has_teacher = True          # before the assignment: keeps it out of nn.Module registration
+        self.teacher_model = model
+        if trainval == "val":
+            self.eval_teacher = True
+            self.teacher_model.train(False)
+            for _, p in self.teacher_model.named_parameters():
+                p.requires_grad = False
+        else:
+            self.eval_teacher = False
+            self.teacher_model.train(True)
+        if getattr(self.teacher_model, "teacher_model", None) is not None:
+            object.__setattr__(self.teacher_model, "teacher_model", None)
+        if getattr(self.teacher_model, "has_teacher", False):
+            self.teacher_model.has_teacher = False
+            self.teacher_model.bbox_head.has_teacher = False
+        self.bbox_head.has_teacher = True
+        return self.teacher_model
+
+    def set_student(self, ckptfile=None):
+        if ckptfile is not None:
+            sd = torch.load(ckptfile, map_location="cpu")
+            self.load_state_dict(sd.get("state_dict", sd), strict=False)
+        return self
+
+    def load_student(self, ckptfile):
+        self.set_student(ckptfile)
+        if self.teacher_model is not None:
+            self.teacher_model = None
+            self.has_teacher = False
+        return None
+
+    def set_datainfo(self, cat2id, cat2label, pred_cat=[], load_cat=[], task_cat=[]):
+        """:172-181."""
+        catid2catname = {v: k for k, v in cat2id.items()}
+        self.Label2CatNameId = {v: [catid2catname[k], k] for k, v in cat2label.items()}
+        all_cat = []
+        for cat in task_cat:
+            all_cat.extend(cat)
+        prev_label = [cat2label[cat2id[cat]] for cat in list(set(pred_cat) - set(load_cat))]
+        curr_label = [cat2label[cat2id[cat]] for cat in load_cat]
+        next_label = [cat2label[cat2id[cat]] for cat in list(set(all_cat) - set(pred_cat))]
+        self.LableInPCNTask = {"prev": prev_label, "curr": curr_label, "next": next_label}
+
+    def __setattr__(self, name, value):
+        """:485-496 -- the teacher is a plain attribute: not in parameters(), state_dict(), DDP."""
+        if name in ("teacher_model", "has_teacher") and (name == "has_teacher" or self.__dict__.get("has_teacher")):
+            object.__setattr__(self, name, value)
+        else:
+            super().__setattr__(name, value)
+
+    def cuda(self, device=None):
+        if self.has_teacher and self.teacher_model is not None:
+            self.teacher_model.cuda(device=device)
+        return super().cuda(device=device)
+
+    def to(self, *args, **kwargs):
+        if self.has_teacher and self.teacher_model is not None:
+            self.teacher_model.to(*args, **kwargs)
+        return super().to(*args, **kwargs)
+
+    def train(self, mode=True):
+        if self.has_teacher and self.teacher_model is not None:
+            self.teacher_model.train(False if self.eval_teacher else mode)
+        return super().train(mode)
+
+    # ------------------------------------------------------------------ forward
+    def extract_feat(self, img):
+        x = self.backbone(img)
+        if self.with_neck:
+            x = self.neck(x)
+        return x
+
+    def out_teacher(self, img, img_metas, cat_keepid=True):
+        """:116-152."""
+        assert self.has_teacher, "no teacher model is set"
+        with torch.no_grad():
+            neck_feat = self.teacher_model.extract_feat(img)
+            head_outs = self.teacher_model.bbox_head.forward(neck_feat, img_metas)
+            cfg = self.teacher_test_cfg if self.teacher_test_cfg is not None else self.test_cfg
+            pred_outs = self.teacher_model.bbox_head.get_bboxes(*head_outs, img_metas=img_metas, rescale=False,
+                                                                cfg=cfg, need_logits=True)
+            pred_bboxes = [r[0][:, 0:4].detach() for r in pred_outs]
+            pred_scores = [r[0][:, 4:5].flatten().detach() for r in pred_outs]
+            pred_labels = [r[1].detach() for r in pred_outs]
+            pred_logits = [r[2].detach() for r in pred_outs]
+            pred_keepid = [r[3].detach() for r in pred_outs]
+            if cat_keepid:
+                pred_keepid = torch.cat([pk + i * head_outs[0].shape[2] for i, pk in enumerate(pred_keepid)])
+        return neck_feat, head_outs, pred_keepid, pred_logits, pred_labels, pred_scores, pred_bboxes
+
+    def forward(self, img, img_metas, return_loss=True, **kwargs):
+        if return_loss:
+            return self.forward_train(img, img_metas, **kwargs)
+        return self.simple_test(img, img_metas, **kwargs)
+
+    def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None, teacher_info=None):
+        """:255-318.  ``teacher_info`` may be injected (bench / tests: synthetic teacher
+        detections through the same dict); otherwise it is produced by
+        ``out_teacher``."""
+        for m in img_metas:
+            m.setdefault("batch_input_shape", tuple(img.size()[-2:]))
+        if teacher_info is None:
+            teacher_info = {k: None for k in ("neck_feats", "head_outs", "pred_keepid", "pred_logits", "pred_scores",
+                                              "pred_labels", "pred_bboxes")}
+            if self.has_teacher:
+                feats, outs, keepid, logits, labels, scores, bboxes = self.out_teacher(img, img_metas, cat_keepid=True)
+                teacher_info = {"neck_feats": feats if self.bbox_head.feats_distill else None, "head_outs": outs,
+                                "pred_keepid": keepid, "pred_logits": logits or None, "pred_scores": scores,
+                                "pred_labels": labels, "pred_bboxes": bboxes}
+        x = self.extract_feat(img)
+        return self.bbox_head.forward_train(x, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore, proposal_cfg=None,
+                                            teacher_info=teacher_info, task_labels=self.LableInPCNTask)
+
+    def simple_test(self, img, img_metas, rescale=False):
+        feat = self.extract_feat(img)
+        return self.bbox_head.simple_test(feat, img_metas, rescale=rescale)
+
+    # ------------------------------------------------------------------ step
+    def _parse_losses(self, losses):
+        """:210-253.  Same keys / values; all log scalars are averaged over ranks by ONE
+        all-reduce and fetched with ONE device->host copy (the reference: one blocking
+        all-reduce + .item() per key)."""
+        log_vars = OrderedDict()
+        for name, value in losses.items():
+            if isinstance(value, torch.Tensor):
+                log_vars[name] = value.mean()
+            elif isinstance(value, list):
+                log_vars[name] = sum(v.mean() for v in value)
+            else:
+                raise TypeError(f"{name} is not a tensor or list of tensors")
+        loss = sum(v for k, v in log_vars.items() if "loss" in k)
+        log_vars["loss"] = loss
+        keys = list(log_vars.keys())
+        flat = allreduce_scalars([torch.as_tensor(float(len(keys)), device=loss.device)] + [log_vars[k] for k in keys])
+        if self.lazy_log:
+            return loss, OrderedDict(_keys=keys, _flat=flat)
+        host = flat.cpu().tolist()
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        assert abs(host[0] - len(keys)) < 1e-6, "loss log variables are different across GPUs!\n" + ",".join(keys)
+        del world
+        return loss, OrderedDict((k, v) for k, v in zip(keys, host[1:]))
+
+    def train_step(self, data, optimizer=None):
+        """:419-450."""
+        losses = self(**data)
+        loss, log_vars = self._parse_losses(losses)
+        return dict(loss=loss, log_vars=log_vars, num_samples=len(data["img_metas"]))
+
+    val_step = train_step

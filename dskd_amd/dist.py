@@ -1,0 +1,62 @@
+"""Distributed helpers: one process per GPU, ``torch.distributed`` over RCCL/xGMI
+(backend "nccl" is RCCL on ROCm; "gloo" for the CPU tests).
+
+Counterparts in the reference: ``init_dist`` (/root/reference/tools/train_increment.py:146-153,
+ext-mmcv), ``reduce_mean`` (/root/reference/mmdet/core/utils/dist_utils.py:68-74), the
+``MMDistributedDataParallel`` wrap (/root/reference/tools/train_increment.py:301-303) and
+the per-key logging all-reduces of ``_parse_losses``
+(/root/reference/mmdet/models/detectors/deformable_detr_il.py:236-251), which are replaced
+by ONE coalesced all-reduce (``allreduce_scalars``)."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def get_dist_info():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def init_dist(launcher="pytorch", backend="nccl", **kwargs):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torchrun)."""
+    if dist.is_initialized():
+        return
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", rank))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+    dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+
+
+def reduce_mean(tensor):
+    """dist_utils.py:68-74."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return tensor
+    tensor = tensor.clone()
+    dist.all_reduce(tensor.div_(dist.get_world_size()), op=dist.ReduceOp.SUM)
+    return tensor
+
+
+def allreduce_scalars(values):
+    """Mean over ranks of a list of 0-dim tensors with ONE collective; returns a 1-D tensor."""
+    flat = torch.stack([v.detach().float().reshape(()) for v in values])
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat.div_(dist.get_world_size()))
+    return flat
+
+
+def wrap_ddp(model, device_ids=None, bucket_cap_mb=50, find_unused_parameters=True, **kwargs):
+    """DDP over RCCL with bucketed gradient all-reduce overlapped with backward
+    (train_increment.py:301-303 uses broadcast_buffers=False, find_unused_parameters=True:
+    the ``prototype`` embedding never receives a gradient).  xGMI is point-to-point
+    (7 links x ~153 GB/s per GPU): ~160 MB of fp32 gradients in 50 MB buckets keeps several
+    ring steps in flight per link while the backward still runs."""
+    from torch.nn.parallel import DistributedDataParallel
+    return DistributedDataParallel(model, device_ids=device_ids, broadcast_buffers=False,
+                                   find_unused_parameters=find_unused_parameters, bucket_cap_mb=bucket_cap_mb,
+                                   gradient_as_bucket_view=True, **kwargs)

@@ -1,0 +1,397 @@
+"""``GFLDeformableDETRHead_il``: the incremental GFL-style Deformable-DETR head with the two
+DSKD losses, restated from
+/root/reference/mmdet/models/dense_heads/gfl_deformable_detr_head_il.py
+(``Integral_average`` :23-60, ctor :85-143, ``_init_layers`` :145-178, ``init_weights``
+:180-194, ``forward`` :196-281, ``forward_train`` :324-368, ``loss`` :411-1195,
+``correlation_mat`` :1197-1222, ``loss_single_split`` :1379-1533, ``get_bboxes`` /
+``_get_bboxes_single`` :1535-1668, ``get_targets`` / ``_get_target_single`` :1670-1797) and
+its parent constructor /root/reference/mmdet/models/dense_heads/detr_head.py:52-150.
+
+What is different from the reference (same numbers, different execution):
+  * targets for all 6 decoder layers x B images come from ONE fused cost launch and ONE
+    batched on-device Hungarian launch (``GFLHungarianAssigner.assign_batch``) instead of
+    6*B device->host->device round trips;
+  * the per-layer losses are written on dense tensors with masks (no ``nonzero``), the
+    normaliser ``num_total_pos`` is known on the host from the GT counts, and its
+    cross-rank mean is ONE all-reduce per step kept on the device (the reference issues
+    12 blocking scalar all-reduces with ``.item()``, :1484-1492);
+  * ``loss_corr`` and ``loss_fg_feature`` (decode_v1) are the HIP kernels behind
+    ``native.proto_corr_loss`` / ``native.fgkd_loss``.
+Only the branches the DSKD configs enable are built ('hard' + 'teacher-first',
+'corr + fg_info + decode_v1'); other ``*_distill`` strings raise NotImplementedError.
+"""
+import copy
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import native
+from .bbox import bbox_cxcywh_to_xyxy, bbox_overlaps, bbox_xyxy_to_cxcywh
+from .builder import HEADS, build_assigner, build_loss, build_positional_encoding, build_sampler, build_transformer
+from .dist import reduce_mean
+from .transformer import inverse_sigmoid
+
+
+def multi_apply(func, *args, **kwargs):
+    """/root/reference/mmdet/core/utils/misc.py:11-30."""
+    from functools import partial
+    pfunc = partial(func, **kwargs) if kwargs else func
+    return tuple(map(list, zip(*map(pfunc, *args))))
+
+
+def filter_scores_and_topk(scores, score_thr, topk, results=None):
+    """/root/reference/mmdet/core/utils/misc.py:119-165 (results=None form)."""
+    valid_mask = scores > score_thr
+    scores = scores[valid_mask]
+    valid_idxs = torch.nonzero(valid_mask)
+    num_topk = min(topk, valid_idxs.size(0))
+    scores, idxs = scores.sort(descending=True)
+    scores = scores[:num_topk]
+    topk_idxs = valid_idxs[idxs[:num_topk]]
+    keep_idxs, labels = topk_idxs.unbind(dim=1)
+    return scores, labels, keep_idxs, None
+
+
+class Integral_average(nn.Module):
+    """:23-60 -- x / sum(x) weighted by k / reg_max / 2, then (l+r, t+b)."""
+
+    def __init__(self, reg_max=16):
+        super().__init__()
+        self.reg_max = reg_max
+
+    def forward(self, x):
+        x = x.reshape(-1, self.reg_max + 1)
+        x = x / x.sum(1).unsqueeze(1).repeat(1, self.reg_max + 1)
+        space = torch.linspace(0, self.reg_max, self.reg_max + 1).to(x.device)
+        space = space / self.reg_max / 2
+        x = x * space
+        return x.sum(1).reshape(-1, 2, 2).sum(2)
+
+
+@HEADS.register_module()
+class GFLDeformableDETRHead_il(nn.Module):
+    _version = 2
+
+    def __init__(self, num_classes, in_channels, num_query=100, num_reg_fcs=2, transformer=None,
+                 sync_cls_avg_factor=False,
+                 positional_encoding=dict(type="SinePositionalEncoding", num_feats=128, normalize=True),
+                 loss_cls=dict(type="QualityFocalLoss", use_sigmoid=True, beta=2.0, loss_weight=2.0),
+                 loss_bbox=dict(type="L1Loss", loss_weight=5.0), loss_iou=dict(type="GIoULoss", loss_weight=2.0),
+                 train_cfg=dict(assigner=dict(type="GFLHungarianAssigner",
+                                              cls_cost=dict(type="QualityFocalLossCost", weight=2.0),
+                                              reg_cost=dict(type="BBoxL1Cost", weight=5.0, box_format="xywh"),
+                                              iou_cost=dict(type="IoUCost", iou_mode="giou", weight=2.0))),
+                 test_cfg=dict(max_per_img=100), init_cfg=None,
+                 with_box_refine=False, as_two_stage=False, reg_max=16, temp=0.5,
+                 loss_dfl=dict(type="DistributionFocalLoss", loss_weight=0.25),
+                 cates_distill="", locat_distill="", memory_distill="", feats_distill="",
+                 loss_kd=dict(type="KnowledgeDistillationKLDivLoss", loss_weight=10, T=2),
+                 loss_ld_bbox=dict(type="SmoothL1Loss", loss_weight=10, reduction="mean"),
+                 loss_ld_logit=dict(type="KnowledgeDistillationKLDivLoss", loss_weight=0.25, T=10),
+                 loss_fd=dict(type="KnowledgeDistillationKLDivLoss", loss_weight=10, T=2),
+                 loss_memory=dict(type="KnowledgeDistillationKLDivLoss", loss_weight=1, T=2),
+                 loss_fg_feature=dict(type="KnowledgeDistillationKLDivLoss", loss_weight=1, T=2, reduction="sum"),
+                 loss_bg_feature=dict(type="KnowledgeDistillationKLDivLoss", loss_weight=1, T=2, reduction="sum"),
+                 loss_corr=dict(type="MSELoss", loss_weight=1, reduction="sum"), **kwargs):
+        super().__init__()
+        assert not as_two_stage and not with_box_refine, "two-stage / box-refine are off in the DSKD configs"
+        self.with_box_refine, self.as_two_stage = with_box_refine, as_two_stage
+        self.reg_max, self.temp = reg_max, temp
+        self.has_teacher = kwargs.pop("has_teacher", False)
+        # ---- DETRHead.__init__ (detr_head.py:83-150)
+        self.bg_cls_weight = 0
+        self.sync_cls_avg_factor = sync_cls_avg_factor
+        if train_cfg:
+            assert "assigner" in train_cfg, "assigner should be provided when train_cfg is set."
+            assigner = train_cfg["assigner"]
+            assert loss_cls["loss_weight"] == assigner["cls_cost"]["weight"], \
+                "The classification weight for loss and matcher should be exactly the same."
+            assert loss_bbox["loss_weight"] == assigner["reg_cost"]["weight"], \
+                "The regression L1 weight for loss and matcher should be exactly the same."
+            assert loss_iou["loss_weight"] == assigner["iou_cost"]["weight"], \
+                "The regression iou weight for loss and matcher should be exactly the same."
+            self.assigner = build_assigner(dict(assigner))
+            self.sampler = build_sampler(dict(type="PseudoSampler"), context=self)
+        self.num_query, self.num_classes, self.in_channels = num_query, num_classes, in_channels
+        self.num_reg_fcs, self.train_cfg, self.test_cfg = num_reg_fcs, train_cfg, test_cfg
+        self.fp16_enabled = False
+        self.loss_cls = build_loss(dict(loss_cls))
+        self.loss_bbox = build_loss(dict(loss_bbox))
+        self.loss_iou = build_loss(dict(loss_iou))
+        self.cls_out_channels = num_classes if self.loss_cls.use_sigmoid else num_classes + 1
+        self.positional_encoding = build_positional_encoding(dict(positional_encoding))
+        self.transformer = build_transformer(dict(transformer))
+        self.embed_dims = self.transformer.embed_dims
+        assert "num_feats" in positional_encoding
+        assert positional_encoding["num_feats"] * 2 == self.embed_dims, \
+            f"embed_dims should be exactly 2 times of num_feats. Found {self.embed_dims} and {positional_encoding['num_feats']}."
+        self._init_layers()
+        # ---- IL head (:128-143)
+        self.integral_average = Integral_average(self.reg_max)
+        self.loss_dfl = build_loss(dict(loss_dfl))
+        self.cates_distill, self.locat_distill = cates_distill, locat_distill
+        self.feats_distill, self.memory_distill = feats_distill, memory_distill
+        self.loss_kd = build_loss(dict(loss_kd)) if cates_distill else None
+        self.loss_ld_bbox = build_loss(dict(loss_ld_bbox)) if "bbox" in locat_distill else None
+        self.loss_ld_logit = build_loss(dict(loss_ld_logit)) if "logit" in locat_distill else None
+        self.loss_fd = build_loss(dict(loss_fd)) if "kldv" in feats_distill else None
+        self.loss_memory = build_loss(dict(loss_memory)) if "memory" in memory_distill else None
+        self.loss_fg_feature = build_loss(dict(loss_fg_feature)) if "fg_info" in feats_distill else None
+        self.loss_bg_feature = build_loss(dict(loss_bg_feature)) if "bg_info" in feats_distill else None
+        self.loss_corr = build_loss(dict(loss_corr)) if "corr" in feats_distill else None
+        self.last_lsap_status = None
+
+    def _init_layers(self):
+        """:145-178 -- cls / reg branches are SHARED across decoder layers (no box refine)."""
+        fc_cls = nn.Linear(self.embed_dims, self.cls_out_channels)
+        reg_branch = []
+        for _ in range(self.num_reg_fcs):
+            reg_branch += [nn.Linear(self.embed_dims, self.embed_dims), nn.ReLU()]
+        reg_branch.append(nn.Linear(self.embed_dims, 2 + 4 * (self.reg_max + 1)))
+        reg_branch = nn.Sequential(*reg_branch)
+        num_pred = self.transformer.decoder.num_layers
+        self.cls_branches = nn.ModuleList([fc_cls for _ in range(num_pred)])
+        self.reg_branches = nn.ModuleList([reg_branch for _ in range(num_pred)])
+        self.query_embedding = nn.Embedding(self.num_query, self.embed_dims * 2)
+        self.prototype = nn.Embedding(self.cls_out_channels, self.embed_dims)   # never used in forward (:178)
+
+    def init_weights(self):
+        """:180-194."""
+        self.transformer.init_weights()
+        if self.loss_cls.use_sigmoid:
+            bias_init = float(-torch.log(torch.tensor((1 - 0.01) / 0.01)))
+            for m in self.cls_branches:
+                nn.init.constant_(m.bias, bias_init)
+        for m in self.reg_branches:
+            nn.init.constant_(m[-1].weight, 0)
+            nn.init.constant_(m[-1].bias, 0)
+        nn.init.constant_(self.reg_branches[0][-1].bias.data[2:], -2.0)
+        nn.init.constant_(self.prototype.weight, 0)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, mlvl_feats, img_metas):
+        """:196-281.  Returns (cls [nb_dec,B,Q,C], box [nb_dec,B,Q,2+4*(reg_max+1)] sigmoid,
+        (memory, spatial_shapes), hs [nb_dec,B,Q,D])."""
+        batch_size = mlvl_feats[0].size(0)
+        input_img_h, input_img_w = img_metas[0]["batch_input_shape"]
+        full = all(tuple(m["img_shape"][:2]) == (input_img_h, input_img_w) for m in img_metas)
+        img_masks = mlvl_feats[0].new_zeros((batch_size, input_img_h, input_img_w), dtype=torch.float32) if full else \
+            mlvl_feats[0].new_ones((batch_size, input_img_h, input_img_w), dtype=torch.float32)
+        if not full:
+            for img_id in range(batch_size):
+                img_h, img_w, _ = img_metas[img_id]["img_shape"]
+                img_masks[img_id, :img_h, :img_w] = 0
+        mlvl_masks, mlvl_positional_encodings = [], []
+        for feat in mlvl_feats:
+            mlvl_masks.append(F.interpolate(img_masks[None], size=feat.shape[-2:]).to(torch.bool).squeeze(0))
+            mlvl_positional_encodings.append(self.positional_encoding(mlvl_masks[-1]))
+        hs, init_reference, inter_references, memory, _, _ = self.transformer(
+            mlvl_feats, mlvl_masks, self.query_embedding.weight, mlvl_positional_encodings,
+            reg_branches=None, cls_branches=None)
+        hs = hs.permute(0, 2, 1, 3)
+        # cls / reg branches are shared and the reference point never moves without box
+        # refinement: run the six per-layer heads as one batched GEMM each.
+        reference = inverse_sigmoid(init_reference)
+        outputs_classes = self.cls_branches[0](hs)
+        tmp = self.reg_branches[0](hs).float()
+        assert reference.shape[-1] == 2
+        tmp = torch.cat([tmp[..., :2] + reference.float()[None], tmp[..., 2:]], -1)
+        outputs_coords = tmp.sigmoid()
+        return outputs_classes.float(), outputs_coords, memory, hs.float()
+
+    def forward_train(self, x, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=None, proposal_cfg=None,
+                      task_labels=None, **kwargs):
+        """:324-368."""
+        teacher_info = kwargs.pop("teacher_info", {})
+        student_feat = x if self.has_teacher and self.feats_distill else []
+        outs = self.forward(x, img_metas)
+        assert gt_labels is not None
+        losses = self.loss(*outs, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=gt_bboxes_ignore,
+                           student_feat=student_feat, teacher_info=teacher_info, task_labels=task_labels)
+        if proposal_cfg is None:
+            return losses
+        return losses, self.get_bboxes(*outs, img_metas=img_metas, cfg=proposal_cfg)
+
+    # ------------------------------------------------------------------ targets
+    def get_targets_all_layers(self, all_cls_scores, bbox_cxcywh, gt_bboxes_list, gt_labels_list, img_metas):
+        """Targets of every (layer, image) problem (``get_targets`` / ``_get_target_single``
+        :1670-1797 for all layers at once).  Returns dense tensors:
+        labels [nl, B*Q] (bg = num_classes), bbox_targets [nl, B*Q, 4] (normalised cxcywh, 0 for
+        negatives), pos mask [nl, B*Q], and num_total_pos (python int, same for every layer)."""
+        nl, B, Q, _ = all_cls_scores.shape
+        gt_inds, assigned_labels, status = self.assigner.assign_batch(
+            bbox_cxcywh.reshape(nl * B, Q, 4), all_cls_scores.reshape(nl * B, Q, -1), gt_bboxes_list,
+            gt_labels_list, img_metas)
+        self.last_lsap_status = status
+        pos = gt_inds > 0                                                 # [P, Q]
+        labels = torch.where(pos, assigned_labels, torch.full_like(assigned_labels, self.num_classes))
+        G = [int(g.shape[0]) for g in gt_bboxes_list]
+        num_total_pos = sum(min(Q, g) for g in G)
+        if sum(G) > 0:
+            norm = []
+            for i, g in enumerate(gt_bboxes_list):
+                img_h, img_w, _ = img_metas[i]["img_shape"]
+                factor = g.new_tensor([img_w, img_h, img_w, img_h]).unsqueeze(0)
+                norm.append(bbox_xyxy_to_cxcywh(g.reshape(-1, 4) / factor))
+            gt_norm = torch.cat(norm, 0)                                  # [sum G, 4]
+            starts = [0]
+            for g in G[:-1]:
+                starts.append(starts[-1] + g)
+            start_img = torch.tensor(starts, device=gt_norm.device).repeat(nl)[:, None]   # [P,1]
+            idx = (start_img + gt_inds - 1).clamp(min=0)
+            bbox_targets = torch.where(pos[..., None], gt_norm[idx], gt_norm.new_zeros(()))
+        else:
+            bbox_targets = bbox_cxcywh.new_zeros((nl * B, Q, 4))
+        return (labels.view(nl, B * Q), bbox_targets.view(nl, B * Q, 4), pos.view(nl, B * Q), num_total_pos)
+
+    # ------------------------------------------------------------------ losses
+    def loss_single_dense(self, cls_scores, bbox_cxcywh, bbox_lrtb, labels, bbox_targets, pos, factors, avg_pos):
+        """One decoder layer, all images: the arithmetic of ``loss_single_split`` :1453-1529 on
+        precomputed dense targets.  cls_scores [N,C], bbox_cxcywh [N,4], bbox_lrtb [N,4*(reg_max+1)],
+        labels [N], bbox_targets [N,4], pos [N] bool, factors [N,4]; avg_pos = clamp(mean
+        num_total_pos, 1) (python float or 0-dim tensor)."""
+        posf = pos.to(bbox_cxcywh.dtype)
+        bbox_weights = posf[:, None].expand(-1, 4)
+        # IoU quality of the positives (:1459-1466); gradient flows into the boxes as in the
+        # reference (index_put of a graph tensor into `score`).
+        iou = bbox_overlaps(bbox_cxcywh_to_xyxy(bbox_cxcywh), bbox_cxcywh_to_xyxy(bbox_targets), is_aligned=True)
+        score = torch.where(pos, iou, torch.zeros_like(iou))
+        loss_cls = self.loss_cls(cls_scores, (labels, score), None, avg_factor=avg_pos)
+        bboxes = bbox_cxcywh_to_xyxy(bbox_cxcywh) * factors
+        bboxes_gt = bbox_cxcywh_to_xyxy(bbox_targets) * factors
+        loss_iou = self.loss_iou(bboxes, bboxes_gt, bbox_weights, avg_factor=avg_pos)
+        loss_bbox = self.loss_bbox(bbox_cxcywh, bbox_targets, bbox_weights, avg_factor=avg_pos)
+        pred_corners = bbox_lrtb.reshape(-1, self.reg_max + 1)
+        target_corners = bbox_targets[:, 2:].unsqueeze(2).repeat(1, 1, 2).reshape(-1) / 2
+        loss_dfl = self.loss_dfl(pred_corners, target_corners, weight=bbox_weights.reshape(-1), avg_factor=avg_pos * 4)
+        return loss_cls, loss_bbox, loss_iou, loss_dfl
+
+    def loss(self, all_cls_scores, all_bbox_preds, info_all, hs, gt_bboxes_list, gt_labels_list, img_metas,
+             gt_bboxes_ignore=None, student_feat=[], teacher_info={}, task_labels={}):
+        """:411-1195 for the DSKD configuration."""
+        assert gt_bboxes_ignore is None, f"{self.__class__.__name__} only supports for gt_bboxes_ignore setting to None."
+        for name, val, ok in (("cates_distill", self.cates_distill, ("", "hard", "hard + teacher-first")),
+                              ("locat_distill", self.locat_distill, ("",)), ("memory_distill", self.memory_distill, ("",)),
+                              ("feats_distill", self.feats_distill, ("", "corr + fg_info + decode_v1", "corr",
+                                                                     "fg_info + decode_v1"))):
+            if val not in ok:
+                raise NotImplementedError(f"{name}={val!r}: only the DSKD configuration is implemented {ok}")
+        gt_bboxes_list = list(gt_bboxes_list)
+        gt_labels_list = list(gt_labels_list)
+        if self.has_teacher and "hard" in self.cates_distill:            # :462-465 teacher boxes first
+            for i in range(len(img_metas)):
+                gt_labels_list[i] = torch.cat([teacher_info["pred_labels"][i], gt_labels_list[i]], dim=0)
+                gt_bboxes_list[i] = torch.cat([teacher_info["pred_bboxes"][i], gt_bboxes_list[i]], dim=0)
+
+        nl, B, Q, _ = all_cls_scores.shape
+        all_cls_scores = all_cls_scores.float()
+        all_bbox_preds = all_bbox_preds.float()
+        bbox_lrtb = all_bbox_preds[..., 2:]
+        bbox_wh = self.integral_average(bbox_lrtb).reshape(nl, B, Q, 2)   # :1429-1432
+        bbox_cxcywh = torch.cat((all_bbox_preds[..., :2], bbox_wh), dim=-1)
+
+        labels, bbox_targets, pos, num_total_pos = self.get_targets_all_layers(
+            all_cls_scores, bbox_cxcywh, gt_bboxes_list, gt_labels_list, img_metas)
+
+        # normaliser: clamp(reduce_mean(num_total_pos), 1) (:1491-1492); identical for every
+        # layer, so one all-reduce per step; stays on the device when distributed.
+        avg_pos = reduce_mean(all_cls_scores.new_tensor([float(num_total_pos)])).clamp(min=1)[0] \
+            if _dist_on() else max(float(num_total_pos), 1.0)
+
+        factors = torch.cat([all_bbox_preds.new_tensor([m["img_shape"][1], m["img_shape"][0], m["img_shape"][1],
+                                                        m["img_shape"][0]]).unsqueeze(0).repeat(Q, 1)
+                             for m in img_metas], 0)
+        losses_cls, losses_bbox, losses_iou, losses_dfl = [], [], [], []
+        for l in range(nl):
+            lc, lb, li, ld = self.loss_single_dense(
+                all_cls_scores[l].reshape(-1, self.cls_out_channels), bbox_cxcywh[l].reshape(-1, 4),
+                bbox_lrtb[l].reshape(B * Q, -1), labels[l], bbox_targets[l], pos[l], factors, avg_pos)
+            losses_cls.append(lc)
+            losses_bbox.append(lb)
+            losses_iou.append(li)
+            losses_dfl.append(ld)
+
+        loss_dict = dict()
+        prev_mask = None
+        if self.has_teacher:
+            prev_mask = torch.zeros(self.cls_out_channels, dtype=torch.bool)
+            prev_mask[list(task_labels["prev"])] = True
+            prev_mask = prev_mask.to(hs.device)
+            self.last_prev_mask = prev_mask
+        if self.has_teacher and self.loss_corr is not None:               # :525-555
+            hs_student = hs[-1].reshape(-1, hs.shape[-1])
+            hs_teacher = teacher_info["head_outs"][3][-1].reshape(-1, hs.shape[-1])
+            teacher_labels_all = torch.cat(list(teacher_info["pred_labels"]), 0)
+            assert self.loss_corr.reduction == "mean", "correlation loss is MSE(mean)/L in the DSKD configs"
+            loss_dict["loss_corr"] = native.proto_corr_loss(
+                hs_student, labels[-1], prev_mask, hs_teacher, teacher_info["pred_keepid"], teacher_labels_all,
+                len(task_labels["prev"]), float(self.loss_corr.loss_weight))
+
+        loss_dict["loss_cls"] = losses_cls[-1]
+        loss_dict["loss_bbox"] = losses_bbox[-1]
+        loss_dict["loss_iou"] = losses_iou[-1]
+        loss_dict["loss_dfl"] = losses_dfl[-1]
+        for i in range(nl - 1):
+            loss_dict[f"d{i}.loss_cls"] = losses_cls[i]
+            loss_dict[f"d{i}.loss_bbox"] = losses_bbox[i]
+            loss_dict[f"d{i}.loss_iou"] = losses_iou[i]
+            loss_dict[f"d{i}.loss_dfl"] = losses_dfl[i]
+
+        if self.has_teacher and "fg_info" in self.feats_distill and "bg_info" not in self.feats_distill \
+                and "decode_v1" in self.feats_distill:                    # :664-718
+            assert self.loss_fg_feature.reduction == "sum"
+            hs_soft = teacher_info["head_outs"][3][-1].reshape(-1, hs.shape[-1])
+            hs_pred = hs[-1].reshape(-1, hs.shape[-1])
+            img_hw = [(m["img_shape"][0], m["img_shape"][1]) for m in img_metas]
+            loss_dict["loss_fg_feature"] = native.fgkd_loss(
+                list(student_feat), list(teacher_info["neck_feats"]), list(teacher_info["pred_bboxes"]), img_hw,
+                hs_soft, teacher_info["pred_keepid"], hs_pred, labels[-1], prev_mask,
+                float(self.loss_fg_feature.T), float(self.loss_fg_feature.loss_weight))
+        self.last_labels = labels
+        return loss_dict
+
+    # ------------------------------------------------------------------ teacher decode
+    def get_bboxes(self, all_cls_scores, all_bbox_preds, enc_cls_scores, enc_bbox_preds, img_metas, rescale=False,
+                   cfg=None, **kwargs):
+        """:1535-1587."""
+        cls_scores, bbox_preds = all_cls_scores[-1], all_bbox_preds[-1]
+        return [self._get_bboxes_single(cls_scores[i], bbox_preds[i], img_metas[i]["img_shape"],
+                                        img_metas[i].get("scale_factor", 1.0), rescale, cfg, **kwargs)
+                for i in range(len(img_metas))]
+
+    def _get_bboxes_single(self, cls_score, bbox_pred, img_shape, scale_factor, rescale=False, cfg=None, **kwargs):
+        """:1589-1668 (sigmoid branch)."""
+        assert len(cls_score) == len(bbox_pred)
+        cfg = self.test_cfg if cfg is None else cfg
+        max_per_img = cfg.get("max_per_img", self.num_query)
+        score_thr = cfg.get("score_thr", 0)
+        assert self.loss_cls.use_sigmoid
+        cls_score = cls_score.sigmoid()
+        scores, det_labels, bbox_index, _ = filter_scores_and_topk(cls_score, score_thr, max_per_img)
+        bbox_pred = bbox_pred[bbox_index]
+        det_logits = cls_score[bbox_index]
+        bbox_wh = self.integral_average(bbox_pred[:, 2:])
+        bbox_cxcywh = torch.cat((bbox_pred[:, :2], bbox_wh.reshape(-1, 2)), dim=1)
+        det_bboxes = bbox_cxcywh_to_xyxy(bbox_cxcywh)
+        det_bboxes[:, 0::2] = det_bboxes[:, 0::2] * img_shape[1]
+        det_bboxes[:, 1::2] = det_bboxes[:, 1::2] * img_shape[0]
+        det_bboxes[:, 0::2].clamp_(min=0, max=img_shape[1])
+        det_bboxes[:, 1::2].clamp_(min=0, max=img_shape[0])
+        if rescale:
+            det_bboxes /= det_bboxes.new_tensor(scale_factor)
+        det_bboxes = torch.cat((det_bboxes, scores.unsqueeze(1)), -1)
+        if kwargs.get("need_logits", False):
+            return det_bboxes, det_labels, det_logits, bbox_index
+        return det_bboxes, det_labels
+
+    def simple_test_bboxes(self, feats, img_metas, rescale=False):
+        outs = self.forward(feats, img_metas)
+        return self.get_bboxes(*outs, img_metas, rescale=rescale)
+
+    simple_test = simple_test_bboxes
+
+
+def _dist_on():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1

@@ -1,0 +1,472 @@
+"""Deformable-DETR transformer with the reference's config surface.
+
+Structure follows /root/reference/mmdet/models/utils/transformer.py
+(``DeformableDetrTransformer`` :712-1055, ``DeformableDetrTransformerDecoder`` :624-709,
+``inverse_sigmoid`` :388-404) and the ext-mmcv building blocks it configures
+(``BaseTransformerLayer``, ``FFN``, ``MultiheadAttention``, ``MultiScaleDeformableAttention``;
+mmcv-full 1.3.17..1.6.2, not in the reference tree -- behaviour restated from SURVEY.md
+section 3.3).  Parameter names match mmcv's so reference checkpoints load.
+
+MI355X notes: activations stay batch-first ``[B, N, C]`` inside (the reference's
+``(N, B, C)`` layout and its permutes exist only at the module boundary as views); the
+sampling+aggregation core is the HIP kernel behind ``native.ms_deform_attn``; all dense
+projections are plain ``nn.Linear`` -> hipBLASLt/MFMA (bf16 under autocast).
+"""
+import copy
+import math
+import warnings
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import native
+from .builder import (ATTENTION, FEEDFORWARD_NETWORK, POSITIONAL_ENCODING, TRANSFORMER, TRANSFORMER_LAYER,
+                      TRANSFORMER_LAYER_SEQUENCE, build_attention, build_feedforward_network,
+                      build_transformer_layer, build_transformer_layer_sequence)
+
+
+def inverse_sigmoid(x, eps=1e-5):
+    """transformer.py:388-404."""
+    x = x.clamp(min=0, max=1)
+    x1 = x.clamp(min=eps)
+    x2 = (1 - x).clamp(min=eps)
+    return torch.log(x1 / x2)
+
+
+@POSITIONAL_ENCODING.register_module()
+class SinePositionalEncoding(nn.Module):
+    """/root/reference/mmdet/models/utils/positional_encoding.py:11-100."""
+
+    def __init__(self, num_feats, temperature=10000, normalize=False, scale=2 * math.pi, eps=1e-6, offset=0.,
+                 init_cfg=None):
+        super().__init__()
+        if normalize:
+            assert isinstance(scale, (float, int))
+        self.num_feats, self.temperature, self.normalize = num_feats, temperature, normalize
+        self.scale, self.eps, self.offset = scale, eps, offset
+
+    def forward(self, mask):
+        mask = mask.to(torch.int)
+        not_mask = 1 - mask
+        y_embed = not_mask.cumsum(1, dtype=torch.float32)
+        x_embed = not_mask.cumsum(2, dtype=torch.float32)
+        if self.normalize:
+            y_embed = (y_embed + self.offset) / (y_embed[:, -1:, :] + self.eps) * self.scale
+            x_embed = (x_embed + self.offset) / (x_embed[:, :, -1:] + self.eps) * self.scale
+        dim_t = torch.arange(self.num_feats, dtype=torch.float32, device=mask.device)
+        dim_t = self.temperature ** (2 * (dim_t // 2) / self.num_feats)
+        pos_x = x_embed[:, :, :, None] / dim_t
+        pos_y = y_embed[:, :, :, None] / dim_t
+        B, H, W = mask.size()
+        pos_x = torch.stack((pos_x[:, :, :, 0::2].sin(), pos_x[:, :, :, 1::2].cos()), dim=4).view(B, H, W, -1)
+        pos_y = torch.stack((pos_y[:, :, :, 0::2].sin(), pos_y[:, :, :, 1::2].cos()), dim=4).view(B, H, W, -1)
+        return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2)
+
+
+@ATTENTION.register_module()
+class MultiScaleDeformableAttention(nn.Module):
+    """ext-mmcv ``MultiScaleDeformableAttention``.  ``forward`` takes
+    and returns ``(num_query, bs, embed_dims)`` tensors unless ``batch_first``."""
+
+    def __init__(self, embed_dims=256, num_heads=8, num_levels=4, num_points=4, im2col_step=64, dropout=0.1,
+                 batch_first=False, norm_cfg=None, init_cfg=None):
+        super().__init__()
+        if embed_dims % num_heads != 0:
+            raise ValueError(f"embed_dims must be divisible by num_heads, but got {embed_dims} and {num_heads}")
+        self.norm_cfg = norm_cfg
+        self.dropout = nn.Dropout(dropout)
+        self.batch_first = batch_first
+        self.im2col_step = im2col_step
+        self.embed_dims, self.num_levels, self.num_heads, self.num_points = embed_dims, num_levels, num_heads, num_points
+        self.sampling_offsets = nn.Linear(embed_dims, num_heads * num_levels * num_points * 2)
+        self.attention_weights = nn.Linear(embed_dims, num_heads * num_levels * num_points)
+        self.value_proj = nn.Linear(embed_dims, embed_dims)
+        self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self.init_weights()
+
+    def init_weights(self):
+        nn.init.constant_(self.sampling_offsets.weight, 0.)
+        thetas = torch.arange(self.num_heads, dtype=torch.float32) * (2.0 * math.pi / self.num_heads)
+        grid_init = torch.stack([thetas.cos(), thetas.sin()], -1)
+        grid_init = (grid_init / grid_init.abs().max(-1, keepdim=True)[0]).view(
+            self.num_heads, 1, 1, 2).repeat(1, self.num_levels, self.num_points, 1)
+        for i in range(self.num_points):
+            grid_init[:, :, i, :] *= i + 1
+        with torch.no_grad():
+            self.sampling_offsets.bias.copy_(grid_init.view(-1))
+        nn.init.constant_(self.attention_weights.weight, 0.)
+        nn.init.constant_(self.attention_weights.bias, 0.)
+        nn.init.xavier_uniform_(self.value_proj.weight)
+        nn.init.constant_(self.value_proj.bias, 0.)
+        nn.init.xavier_uniform_(self.output_proj.weight)
+        nn.init.constant_(self.output_proj.bias, 0.)
+
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,
+                reference_points=None, spatial_shapes=None, level_start_index=None, **kwargs):
+        if value is None:
+            value = query
+        if identity is None:
+            identity = query
+        if query_pos is not None:
+            query = query + query_pos
+        if not self.batch_first:
+            query = query.permute(1, 0, 2)
+            value = value.permute(1, 0, 2)
+        bs, num_query, _ = query.shape
+        bs, num_value, _ = value.shape
+        shapes = spatial_shapes.tolist() if isinstance(spatial_shapes, torch.Tensor) else list(spatial_shapes)
+        assert sum(h * w for h, w in shapes) == num_value
+
+        value = self.value_proj(value)
+        if key_padding_mask is not None:
+            value = value.masked_fill(key_padding_mask[..., None], 0.0)
+        value = value.view(bs, num_value, self.num_heads, -1)
+        sampling_offsets = self.sampling_offsets(query).view(
+            bs, num_query, self.num_heads, self.num_levels, self.num_points, 2).float()
+        attention_weights = self.attention_weights(query).view(
+            bs, num_query, self.num_heads, self.num_levels * self.num_points).float()
+        attention_weights = attention_weights.softmax(-1).view(
+            bs, num_query, self.num_heads, self.num_levels, self.num_points)
+        if reference_points.shape[-1] == 2:
+            normalizer = sampling_offsets.new_tensor([[w, h] for h, w in shapes])
+            sampling_locations = reference_points[:, :, None, :, None, :].float() \
+                + sampling_offsets / normalizer[None, None, None, :, None, :]
+        elif reference_points.shape[-1] == 4:
+            sampling_locations = reference_points[:, :, None, :, None, :2] \
+                + sampling_offsets / self.num_points * reference_points[:, :, None, :, None, 2:] * 0.5
+        else:
+            raise ValueError(f"Last dim of reference_points must be 2 or 4, but get {reference_points.shape[-1]}")
+        output = native.ms_deform_attn(value, shapes, sampling_locations, attention_weights)
+        output = self.output_proj(output)
+        if not self.batch_first:
+            output = output.permute(1, 0, 2)
+        return self.dropout(output) + identity
+
+
+@ATTENTION.register_module()
+class MultiheadAttention(nn.Module):
+    """ext-mmcv wrapper around ``nn.MultiheadAttention`` with identity + dropout; the
+    deprecated ``dropout`` kwarg sets both attn_drop and the dropout layer (as mmcv does)."""
+
+    def __init__(self, embed_dims, num_heads, attn_drop=0., proj_drop=0., dropout_layer=dict(type="Dropout", drop_prob=0.),
+                 init_cfg=None, batch_first=False, **kwargs):
+        super().__init__()
+        dropout_layer = dict(dropout_layer) if dropout_layer else None
+        if "dropout" in kwargs:
+            warnings.warn("The arguments `dropout` in MultiheadAttention has been deprecated", DeprecationWarning)
+            attn_drop = kwargs["dropout"]
+            dropout_layer["drop_prob"] = kwargs.pop("dropout")
+        self.embed_dims, self.num_heads, self.batch_first = embed_dims, num_heads, batch_first
+        self.attn = nn.MultiheadAttention(embed_dims, num_heads, attn_drop, **kwargs)
+        self.proj_drop = nn.Dropout(proj_drop)
+        self.dropout_layer = nn.Dropout(dropout_layer["drop_prob"]) if dropout_layer else nn.Identity()
+
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_pos=None, attn_mask=None,
+                key_padding_mask=None, **kwargs):
+        if key is None:
+            key = query
+        if value is None:
+            value = key
+        if identity is None:
+            identity = query
+        if key_pos is None and query_pos is not None and query_pos.shape == key.shape:
+            key_pos = query_pos
+        if query_pos is not None:
+            query = query + query_pos
+        if key_pos is not None:
+            key = key + key_pos
+        if self.batch_first:
+            query, key, value = query.transpose(0, 1), key.transpose(0, 1), value.transpose(0, 1)
+        out = self.attn(query=query, key=key, value=value, attn_mask=attn_mask, key_padding_mask=key_padding_mask,
+                        need_weights=False)[0]
+        if self.batch_first:
+            out = out.transpose(0, 1)
+        return identity + self.dropout_layer(self.proj_drop(out))
+
+
+@FEEDFORWARD_NETWORK.register_module()
+class FFN(nn.Module):
+    """ext-mmcv FFN: Sequential(Linear, act, Dropout) x (num_fcs-1), Linear, Dropout + identity."""
+
+    def __init__(self, embed_dims=256, feedforward_channels=1024, num_fcs=2, act_cfg=dict(type="ReLU", inplace=True),
+                 ffn_drop=0., dropout_layer=None, add_identity=True, init_cfg=None, **kwargs):
+        super().__init__()
+        assert num_fcs >= 2
+        self.embed_dims, self.feedforward_channels, self.num_fcs = embed_dims, feedforward_channels, num_fcs
+        act = {"ReLU": lambda: nn.ReLU(inplace=True), "GELU": nn.GELU}[act_cfg.get("type", "ReLU")]
+        layers, cin = [], embed_dims
+        for _ in range(num_fcs - 1):
+            layers.append(nn.Sequential(nn.Linear(cin, feedforward_channels), act(), nn.Dropout(ffn_drop)))
+            cin = feedforward_channels
+        layers += [nn.Linear(feedforward_channels, embed_dims), nn.Dropout(ffn_drop)]
+        self.layers = nn.Sequential(*layers)
+        self.dropout_layer = nn.Dropout(dropout_layer["drop_prob"]) if dropout_layer else nn.Identity()
+        self.add_identity = add_identity
+
+    def forward(self, x, identity=None):
+        out = self.layers(x)
+        if not self.add_identity:
+            return self.dropout_layer(out)
+        if identity is None:
+            identity = x
+        return identity + self.dropout_layer(out)
+
+
+@TRANSFORMER_LAYER.register_module()
+class BaseTransformerLayer(nn.Module):
+    """ext-mmcv ``BaseTransformerLayer``: runs ``operation_order`` over attentions/ffns/norms."""
+
+    def __init__(self, attn_cfgs=None, ffn_cfgs=dict(type="FFN", embed_dims=256, feedforward_channels=1024, num_fcs=2,
+                                                     ffn_drop=0., act_cfg=dict(type="ReLU", inplace=True)),
+                 operation_order=None, norm_cfg=dict(type="LN"), init_cfg=None, batch_first=False, **kwargs):
+        super().__init__()
+        ffn_cfgs = copy.deepcopy(dict(ffn_cfgs))
+        for old, new in dict(feedforward_channels="feedforward_channels", ffn_dropout="ffn_drop",
+                             ffn_num_fcs="num_fcs").items():
+            if old in kwargs:
+                ffn_cfgs[new] = kwargs[old]
+        self.batch_first = batch_first
+        assert set(operation_order) <= {"self_attn", "norm", "ffn", "cross_attn"}
+        num_attn = operation_order.count("self_attn") + operation_order.count("cross_attn")
+        if isinstance(attn_cfgs, dict):
+            attn_cfgs = [copy.deepcopy(attn_cfgs) for _ in range(num_attn)]
+        else:
+            assert num_attn == len(attn_cfgs)
+        self.num_attn = num_attn
+        self.operation_order = operation_order
+        self.norm_cfg = norm_cfg
+        self.pre_norm = operation_order[0] == "norm"
+        self.attentions = nn.ModuleList()
+        idx = 0
+        for op in operation_order:
+            if op in ("self_attn", "cross_attn"):
+                cfg = dict(attn_cfgs[idx])
+                cfg.setdefault("batch_first", batch_first)
+                att = build_attention(cfg)
+                att.operation_name = op
+                self.attentions.append(att)
+                idx += 1
+        self.embed_dims = self.attentions[0].embed_dims
+        self.ffns = nn.ModuleList()
+        num_ffns = operation_order.count("ffn")
+        if isinstance(ffn_cfgs, dict):
+            ffn_cfgs = [copy.deepcopy(ffn_cfgs) for _ in range(num_ffns)]
+        for i in range(num_ffns):
+            c = dict(ffn_cfgs[i])
+            c.setdefault("embed_dims", self.embed_dims)
+            c.setdefault("type", "FFN")
+            self.ffns.append(build_feedforward_network(c))
+        self.norms = nn.ModuleList(nn.LayerNorm(self.embed_dims) for _ in range(operation_order.count("norm")))
+
+    def forward(self, query, key=None, value=None, query_pos=None, key_pos=None, attn_masks=None,
+                query_key_padding_mask=None, key_padding_mask=None, **kwargs):
+        norm_index = attn_index = ffn_index = 0
+        identity = query
+        if attn_masks is None:
+            attn_masks = [None] * self.num_attn
+        elif isinstance(attn_masks, torch.Tensor):
+            attn_masks = [copy.deepcopy(attn_masks) for _ in range(self.num_attn)]
+        for layer in self.operation_order:
+            if layer == "self_attn":
+                temp_key = temp_value = query
+                query = self.attentions[attn_index](
+                    query, temp_key, temp_value, identity if self.pre_norm else None, query_pos=query_pos,
+                    key_pos=query_pos, attn_mask=attn_masks[attn_index], key_padding_mask=query_key_padding_mask,
+                    **kwargs)
+                attn_index += 1
+                identity = query
+            elif layer == "norm":
+                query = self.norms[norm_index](query)
+                norm_index += 1
+            elif layer == "cross_attn":
+                query = self.attentions[attn_index](
+                    query, key, value, identity if self.pre_norm else None, query_pos=query_pos, key_pos=key_pos,
+                    attn_mask=attn_masks[attn_index], key_padding_mask=key_padding_mask, **kwargs)
+                attn_index += 1
+                identity = query
+            elif layer == "ffn":
+                query = self.ffns[ffn_index](query, identity if self.pre_norm else None)
+                ffn_index += 1
+        return query
+
+
+@TRANSFORMER_LAYER.register_module()
+class DetrTransformerDecoderLayer(BaseTransformerLayer):
+    """transformer.py:407-458."""
+
+    def __init__(self, attn_cfgs, feedforward_channels, ffn_dropout=0.0, operation_order=None,
+                 act_cfg=dict(type="ReLU", inplace=True), norm_cfg=dict(type="LN"), ffn_num_fcs=2, **kwargs):
+        super().__init__(attn_cfgs=attn_cfgs, feedforward_channels=feedforward_channels, ffn_dropout=ffn_dropout,
+                         operation_order=operation_order, norm_cfg=norm_cfg, ffn_num_fcs=ffn_num_fcs, **kwargs)
+        assert len(operation_order) == 6
+        assert set(operation_order) == {"self_attn", "norm", "cross_attn", "ffn"}
+
+
+class TransformerLayerSequence(nn.Module):
+    def __init__(self, transformerlayers=None, num_layers=None, init_cfg=None):
+        super().__init__()
+        if isinstance(transformerlayers, dict):
+            transformerlayers = [copy.deepcopy(transformerlayers) for _ in range(num_layers)]
+        else:
+            assert isinstance(transformerlayers, list) and len(transformerlayers) == num_layers
+        self.num_layers = num_layers
+        self.layers = nn.ModuleList(build_transformer_layer(dict(c)) for c in transformerlayers)
+        self.embed_dims = self.layers[0].embed_dims
+        self.pre_norm = self.layers[0].pre_norm
+
+    def forward(self, query, key, value, query_pos=None, key_pos=None, attn_masks=None,
+                query_key_padding_mask=None, key_padding_mask=None, **kwargs):
+        for layer in self.layers:
+            query = layer(query, key, value, query_pos=query_pos, key_pos=key_pos, attn_masks=attn_masks,
+                          query_key_padding_mask=query_key_padding_mask, key_padding_mask=key_padding_mask, **kwargs)
+        return query
+
+
+@TRANSFORMER_LAYER_SEQUENCE.register_module()
+class DetrTransformerEncoder(TransformerLayerSequence):
+    """transformer.py:461-497 (post_norm only when pre_norm)."""
+
+    def __init__(self, *args, post_norm_cfg=dict(type="LN"), **kwargs):
+        super().__init__(*args, **kwargs)
+        self.post_norm = nn.LayerNorm(self.embed_dims) if (post_norm_cfg is not None and self.pre_norm) else None
+
+    def forward(self, *args, **kwargs):
+        x = super().forward(*args, **kwargs)
+        if self.post_norm is not None:
+            x = self.post_norm(x)
+        return x
+
+
+@TRANSFORMER_LAYER_SEQUENCE.register_module()
+class DeformableDetrTransformerDecoder(TransformerLayerSequence):
+    """transformer.py:624-709."""
+
+    def __init__(self, *args, return_intermediate=False, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.return_intermediate = return_intermediate
+
+    def forward(self, query, *args, reference_points=None, valid_ratios=None, reg_branches=None, **kwargs):
+        output = query
+        intermediate, intermediate_reference_points = [], []
+        for lid, layer in enumerate(self.layers):
+            if reference_points.shape[-1] == 4:
+                reference_points_input = reference_points[:, :, None] * \
+                    torch.cat([valid_ratios, valid_ratios], -1)[:, None]
+            else:
+                assert reference_points.shape[-1] == 2
+                reference_points_input = reference_points[:, :, None] * valid_ratios[:, None]
+            output = layer(output, *args, reference_points=reference_points_input, **kwargs)
+            output = output.permute(1, 0, 2)
+            if reg_branches is not None:
+                tmp = reg_branches[lid](output)
+                if reference_points.shape[-1] == 4:
+                    new_reference_points = (tmp + inverse_sigmoid(reference_points)).sigmoid()
+                else:
+                    new_reference_points = tmp
+                    new_reference_points[..., :2] = tmp[..., :2] + inverse_sigmoid(reference_points)
+                    new_reference_points = new_reference_points.sigmoid()
+                reference_points = new_reference_points.detach()
+            output = output.permute(1, 0, 2)
+            if self.return_intermediate:
+                intermediate.append(output)
+                intermediate_reference_points.append(reference_points)
+        if self.return_intermediate:
+            return torch.stack(intermediate), torch.stack(intermediate_reference_points)
+        return output, reference_points
+
+
+@TRANSFORMER.register_module()
+class DeformableDetrTransformer(nn.Module):
+    """transformer.py:712-1055 (single-stage path; ``as_two_stage`` is off in every DSKD
+    config and is not built).  Returns the fork's 6-tuple (:1053-1055)."""
+
+    def __init__(self, encoder=None, decoder=None, as_two_stage=False, num_feature_levels=4,
+                 two_stage_num_proposals=300, init_cfg=None, **kwargs):
+        super().__init__()
+        assert not as_two_stage, "as_two_stage is not used by the DSKD configs and is not implemented"
+        self.encoder = build_transformer_layer_sequence(dict(encoder))
+        self.decoder = build_transformer_layer_sequence(dict(decoder))
+        self.embed_dims = self.encoder.embed_dims
+        self.as_two_stage = as_two_stage
+        self.num_feature_levels = num_feature_levels
+        self.two_stage_num_proposals = two_stage_num_proposals
+        self.level_embeds = nn.Parameter(torch.zeros(self.num_feature_levels, self.embed_dims))
+        self.reference_points = nn.Linear(self.embed_dims, 2)
+
+    def init_weights(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, MultiScaleDeformableAttention):
+                m.init_weights()
+        nn.init.xavier_uniform_(self.reference_points.weight)
+        nn.init.constant_(self.reference_points.bias, 0.)
+        nn.init.normal_(self.level_embeds)
+
+    @staticmethod
+    def get_reference_points(spatial_shapes, valid_ratios, device):
+        """:830-863."""
+        pts = []
+        for lvl, (H, W) in enumerate(spatial_shapes):
+            ref_y, ref_x = torch.meshgrid(torch.linspace(0.5, H - 0.5, H, dtype=torch.float32, device=device),
+                                          torch.linspace(0.5, W - 0.5, W, dtype=torch.float32, device=device),
+                                          indexing="ij")
+            ref_y = ref_y.reshape(-1)[None] / (valid_ratios[:, None, lvl, 1] * H)
+            ref_x = ref_x.reshape(-1)[None] / (valid_ratios[:, None, lvl, 0] * W)
+            pts.append(torch.stack((ref_x, ref_y), -1))
+        reference_points = torch.cat(pts, 1)
+        return reference_points[:, :, None] * valid_ratios[:, None]
+
+    def get_valid_ratio(self, mask):
+        """:865-873."""
+        _, H, W = mask.shape
+        valid_H = torch.sum(~mask[:, :, 0], 1)
+        valid_W = torch.sum(~mask[:, 0, :], 1)
+        return torch.stack([valid_W.float() / W, valid_H.float() / H], -1)
+
+    def forward(self, mlvl_feats, mlvl_masks, query_embed, mlvl_pos_embeds, reg_branches=None, cls_branches=None,
+                **kwargs):
+        assert query_embed is not None
+        feat_flatten, mask_flatten, lvl_pos_embed_flatten, spatial_shapes = [], [], [], []
+        for lvl, (feat, mask, pos_embed) in enumerate(zip(mlvl_feats, mlvl_masks, mlvl_pos_embeds)):
+            bs, c, h, w = feat.shape
+            spatial_shapes.append((h, w))
+            feat_flatten.append(feat.flatten(2).transpose(1, 2))
+            mask_flatten.append(mask.flatten(1))
+            lvl_pos_embed_flatten.append(pos_embed.flatten(2).transpose(1, 2) + self.level_embeds[lvl].view(1, 1, -1))
+        feat_flatten = torch.cat(feat_flatten, 1)
+        mask_flatten = torch.cat(mask_flatten, 1)
+        lvl_pos_embed_flatten = torch.cat(lvl_pos_embed_flatten, 1)
+        device = feat_flatten.device
+        level_start_index = [0]
+        for h, w in spatial_shapes[:-1]:
+            level_start_index.append(level_start_index[-1] + h * w)
+        valid_ratios = torch.stack([self.get_valid_ratio(m) for m in mlvl_masks], 1)
+        reference_points = self.get_reference_points(spatial_shapes, valid_ratios, device=device)
+
+        feat_flatten = feat_flatten.permute(1, 0, 2)                  # (sum HW, bs, C) views
+        lvl_pos_embed_flatten = lvl_pos_embed_flatten.permute(1, 0, 2)
+        memory = self.encoder(query=feat_flatten, key=None, value=None, query_pos=lvl_pos_embed_flatten,
+                              query_key_padding_mask=mask_flatten, spatial_shapes=spatial_shapes,
+                              reference_points=reference_points, level_start_index=level_start_index,
+                              valid_ratios=valid_ratios, **kwargs)
+        memory = memory.permute(1, 0, 2)
+        bs, _, c = memory.shape
+        query_pos, query = torch.split(query_embed, c, dim=1)
+        query_pos = query_pos.unsqueeze(0).expand(bs, -1, -1)
+        query = query.unsqueeze(0).expand(bs, -1, -1)
+        reference_points = self.reference_points(query_pos).sigmoid()
+        init_reference_out = reference_points
+
+        query = query.permute(1, 0, 2)
+        memory = memory.permute(1, 0, 2)
+        query_pos = query_pos.permute(1, 0, 2)
+        inter_states, inter_references = self.decoder(
+            query=query, key=None, value=memory, query_pos=query_pos, key_padding_mask=mask_flatten,
+            reference_points=reference_points, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
+            valid_ratios=valid_ratios, reg_branches=reg_branches, **kwargs)
+        spatial_shapes_t = torch.as_tensor(spatial_shapes, dtype=torch.long, device=device)
+        info_all = (memory, spatial_shapes_t)
+        return inter_states, init_reference_out, inter_references, info_all, None, None

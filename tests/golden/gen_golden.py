@@ -1,0 +1,309 @@
+"""Generates the golden vectors under tests/golden/ by running the REFERENCE's own functions
+(read-only checkout at /root/reference) in this container.  The fixtures (.npz: inputs and
+expected outputs only) are committed; this script documents how they were made and is only
+runnable where /root/reference exists (never on the GPU box).
+
+The reference package cannot be imported as a whole (``import mmdet`` needs the
+un-vendored ``mmcv``).  Its LEAF files for this path are loaded by
+module path with a minimal stand-in for the few mmcv symbols they touch -- identity
+decorators (``mmcv.jit``, ``force_fp32``, ``auto_fp16``) and a ``Registry`` -- none of which
+takes part in the arithmetic.  What runs is the reference's code:
+``GFLDeformableDETRHead_il.loss`` (Hungarian via the local scipy, QFL/DFL/L1/GIoU,
+``loss_corr``, ``decode_v1``), ``GFLHungarianAssigner.assign``, ``bbox_overlaps``,
+``Integral_average`` and the loss modules.
+
+    python tests/golden/gen_golden.py        # rewrites tests/golden/*.npz
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+# ----------------------------------------------------------------------------- loader
+def _identity_decorator(*a, **k):
+    if len(a) == 1 and callable(a[0]) and not k:
+        return a[0]
+    return lambda f: f
+
+
+class _Registry:
+    def __init__(self, name, **kw):
+        self.name, self.module_dict = name, {}
+
+    def register_module(self, name=None, force=False, module=None):
+        def deco(cls):
+            self.module_dict[name or cls.__name__] = cls
+            return cls
+        return deco if module is None else module
+
+    def build(self, cfg, default_args=None):
+        return build_from_cfg(cfg, self, default_args)
+
+    def get(self, k):
+        return self.module_dict.get(k)
+
+
+def build_from_cfg(cfg, registry, default_args=None):
+    args = dict(cfg)
+    if default_args:
+        for k, v in default_args.items():
+            args.setdefault(k, v)
+    return registry.get(args.pop("type"))(**args)
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def _pkg(name, path=None):
+    m = types.ModuleType(name)
+    m.__path__ = [path] if path else []
+    sys.modules[name] = m
+    return m
+
+
+def _load(name, relpath):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, relpath))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+def load_reference():
+    class _Dummy(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+    models_reg = _Registry("models")
+    mmcv = _mod("mmcv", jit=_identity_decorator)
+    _mod("mmcv.utils", Registry=_Registry, build_from_cfg=build_from_cfg)
+    mmcv.utils = sys.modules["mmcv.utils"]
+    _mod("mmcv.cnn", MODELS=models_reg, Linear=nn.Linear, bias_init_with_prob=lambda p: float(-np.log((1 - p) / p)),
+         constant_init=lambda m, v, bias=0: None)
+    _mod("mmcv.runner", force_fp32=_identity_decorator, auto_fp16=_identity_decorator, BaseModule=_Dummy)
+    _mod("mmcv.ops", batched_nms=None)
+
+    for p in ("mmdet", "mmdet.core", "mmdet.core.bbox", "mmdet.core.bbox.assigners", "mmdet.core.bbox.samplers",
+              "mmdet.core.bbox.match_costs", "mmdet.core.bbox.iou_calculators", "mmdet.core.utils", "mmdet.models",
+              "mmdet.models.losses", "mmdet.models.dense_heads", "mmdet.models.utils", "mmdet.utils"):
+        _pkg(p, os.path.join(REF, *p.split(".")))
+    # registries (the reference's builder files only need mmcv's Registry)
+    _load("mmdet.models.builder", "mmdet/models/builder.py")
+    _load("mmdet.core.bbox.builder", "mmdet/core/bbox/builder.py")
+    _load("mmdet.core.bbox.match_costs.builder", "mmdet/core/bbox/match_costs/builder.py")
+    iou = _load("mmdet.core.bbox.iou_calculators.iou2d_calculator", "mmdet/core/bbox/iou_calculators/iou2d_calculator.py")
+    sys.modules["mmdet.core.bbox.iou_calculators"].bbox_overlaps = iou.bbox_overlaps
+    sys.modules["mmdet.core.bbox.iou_calculators"].BboxOverlaps2D = iou.BboxOverlaps2D
+    tr = _load("mmdet.core.bbox.transforms", "mmdet/core/bbox/transforms.py")
+    mc = _load("mmdet.core.bbox.match_costs.match_cost", "mmdet/core/bbox/match_costs/match_cost.py")
+    sys.modules["mmdet.core.bbox.match_costs"].build_match_cost = sys.modules["mmdet.core.bbox.match_costs.builder"].build_match_cost
+    _load("mmdet.utils.util_mixins", "mmdet/utils/util_mixins.py")
+    ar = _load("mmdet.core.bbox.assigners.assign_result", "mmdet/core/bbox/assigners/assign_result.py")
+    ba = _load("mmdet.core.bbox.assigners.base_assigner", "mmdet/core/bbox/assigners/base_assigner.py")
+    ga = _load("mmdet.core.bbox.assigners.gfl_hungarian_assigner", "mmdet/core/bbox/assigners/gfl_hungarian_assigner.py")
+    _load("mmdet.core.bbox.samplers.sampling_result", "mmdet/core/bbox/samplers/sampling_result.py")
+    _load("mmdet.core.bbox.samplers.base_sampler", "mmdet/core/bbox/samplers/base_sampler.py")
+    ps = _load("mmdet.core.bbox.samplers.pseudo_sampler", "mmdet/core/bbox/samplers/pseudo_sampler.py")
+    _pkg("mmdet.core.mask")            # misc.py only imports two mask classes for isinstance checks
+    _mod("mmdet.core.mask.structures", BitmapMasks=type("BitmapMasks", (), {}), PolygonMasks=type("PolygonMasks", (), {}))
+    misc = _load("mmdet.core.utils.misc", "mmdet/core/utils/misc.py")
+    du = types.ModuleType("mmdet.core.utils.dist_utils")
+    du.reduce_mean = lambda t: t           # single process: dist_utils.py:68-74 returns the tensor
+    sys.modules["mmdet.core.utils.dist_utils"] = du
+    cu = sys.modules["mmdet.core.utils"]
+    cu.filter_scores_and_topk, cu.multi_apply, cu.reduce_mean = misc.filter_scores_and_topk, misc.multi_apply, du.reduce_mean
+    core = sys.modules["mmdet.core"]
+    bb = sys.modules["mmdet.core.bbox.builder"]
+    for k, v in dict(bbox_cxcywh_to_xyxy=tr.bbox_cxcywh_to_xyxy, bbox_xyxy_to_cxcywh=tr.bbox_xyxy_to_cxcywh,
+                     build_assigner=bb.build_assigner, build_sampler=bb.build_sampler, multi_apply=misc.multi_apply,
+                     reduce_mean=du.reduce_mean, anchor_inside_flags=None, bbox_overlaps=iou.bbox_overlaps,
+                     images_to_levels=None, unmap=None, build_bbox_coder=None).items():
+        setattr(core, k, v)
+    sys.modules["mmdet.core.bbox"].bbox_overlaps = iou.bbox_overlaps
+    _load("mmdet.models.losses.utils", "mmdet/models/losses/utils.py")
+    losses = {n: _load(f"mmdet.models.losses.{n}", f"mmdet/models/losses/{n}.py")
+              for n in ("kd_loss", "mse_loss", "gfocal_loss", "iou_loss", "smooth_l1_loss")}
+    _mod("mmdet.models.utils.transformer",
+         inverse_sigmoid=lambda x, eps=1e-5: torch.log(x.clamp(0, 1).clamp(min=eps) / (1 - x.clamp(0, 1)).clamp(min=eps)))
+    _mod("mmdet.models.dense_heads.detr_head", DETRHead=_Dummy)
+    head = _load("mmdet.models.dense_heads.gfl_deformable_detr_head_il",
+                 "mmdet/models/dense_heads/gfl_deformable_detr_head_il.py")
+    return dict(iou=iou, tr=tr, mc=mc, ga=ga, ps=ps, misc=misc, losses=losses, head=head)
+
+
+# ----------------------------------------------------------------------------- synthetic inputs
+def make_loss_inputs(B, L, seed, shapes, img_hw, n_t=4, n_gt=3, Q=300, C=80, D=256, nl=3):
+    g = torch.Generator().manual_seed(seed)
+    cls = torch.randn(nl, B, Q, C, generator=g) * 2 - 3
+    box = torch.rand(nl, B, Q, 70, generator=g) * 0.9 + 0.05
+    hs = torch.randn(1, B, Q, D, generator=g)          # loss() reads only hs[-1]
+    hs_t = hs + 0.2 * torch.randn(1, B, Q, D, generator=g)
+    feats_s = [torch.randn(B, D, h, w, generator=g) for h, w in shapes]
+    feats_t = [f + 0.3 * torch.randn(f.shape, generator=g) for f in feats_s]
+    gt_b, gt_l, t_b, t_l, keep = [], [], [], [], []
+    for b in range(B):
+        H, W = img_hw[b]
+
+        def boxes(n):
+            xy = torch.rand(n, 2, generator=g) * torch.tensor([0.6 * W, 0.6 * H])
+            sz = torch.rand(n, 2, generator=g) * torch.tensor([0.35 * W, 0.35 * H]) + 8
+            bx = torch.cat([xy, xy + sz], 1)
+            bx[:, 0::2].clamp_(0, W)
+            bx[:, 1::2].clamp_(0, H)
+            return bx
+        gt_b.append(boxes(n_gt))
+        gt_l.append(torch.randint(L, C, (n_gt,), generator=g))
+        t_b.append(boxes(n_t))
+        t_l.append(torch.randint(0, L, (n_t,), generator=g))
+        keep.append(b * Q + torch.randperm(Q, generator=g)[:n_t])
+    return dict(cls=cls, box=box, hs=hs, hs_t=hs_t, feats_s=feats_s, feats_t=feats_t, gt_b=gt_b, gt_l=gt_l, t_b=t_b,
+                t_l=t_l, keep=torch.cat(keep))
+
+
+def run_reference_loss(ref, inp, L, img_hw, shapes):
+    """Calls the reference's GFLDeformableDETRHead_il.loss on a namespace `self`."""
+    H = ref["head"]
+    L_ = ref["losses"]
+    cls_ = H.GFLDeformableDETRHead_il
+    self = types.SimpleNamespace()
+    self.has_teacher = True
+    self.cates_distill, self.feats_distill = "hard + teacher-first", "corr + fg_info + decode_v1"
+    self.locat_distill, self.memory_distill = "", ""
+    self.num_classes = self.cls_out_channels = 80
+    self.bg_cls_weight, self.sync_cls_avg_factor, self.reg_max = 0, True, 16
+    self.integral_average = H.Integral_average(16)
+    self.assigner = ref["ga"].GFLHungarianAssigner(
+        cls_cost=dict(type="QualityFocalLossCost", weight=2.0), reg_cost=dict(type="BBoxL1Cost", weight=5.0, box_format="xywh"),
+        iou_cost=dict(type="IoUCost", iou_mode="giou", weight=2.0))
+    self.sampler = ref["ps"].PseudoSampler()
+    self.loss_cls = L_["gfocal_loss"].QualityFocalLoss(use_sigmoid=True, beta=2.0, loss_weight=2.0)
+    self.loss_dfl = L_["gfocal_loss"].DistributionFocalLoss(loss_weight=0.5)
+    self.loss_bbox = L_["smooth_l1_loss"].L1Loss(loss_weight=5.0)
+    self.loss_iou = L_["iou_loss"].GIoULoss(loss_weight=2.0)
+    self.loss_fg_feature = L_["kd_loss"].KnowledgeDistillationKLDivLoss(loss_weight=1, T=2, reduction="sum")
+    self.loss_corr = L_["mse_loss"].MSELoss(loss_weight=1, reduction="mean")
+    for name in ("loss_single_split", "get_targets", "_get_target_single", "correlation_mat"):
+        setattr(self, name, types.MethodType(getattr(cls_, name), self))
+    B = inp["cls"].shape[1]
+    metas = [dict(img_shape=(img_hw[b][0], img_hw[b][1], 3)) for b in range(B)]
+    cls = inp["cls"].clone().requires_grad_(True)
+    box = inp["box"].clone().requires_grad_(True)
+    hs = inp["hs"].clone().requires_grad_(True)
+    fs = [f.clone().requires_grad_(True) for f in inp["feats_s"]]
+    teacher_info = dict(neck_feats=inp["feats_t"], head_outs=(None, None, None, inp["hs_t"]), pred_keepid=inp["keep"],
+                        pred_labels=[t.clone() for t in inp["t_l"]], pred_bboxes=[t.clone() for t in inp["t_b"]])
+    spatial = torch.tensor(shapes)
+    losses = cls_.loss(self, cls, box, (None, spatial), hs, [b.clone() for b in inp["gt_b"]], [l.clone() for l in inp["gt_l"]],
+                       metas, gt_bboxes_ignore=None, student_feat=fs, teacher_info=teacher_info,
+                       task_labels={"prev": list(range(L)), "curr": list(range(L, 80)), "next": []})
+    total = sum(v for k, v in losses.items() if "loss" in k)
+    total.backward()
+    out = {f"loss/{k}": v.detach().numpy() for k, v in losses.items()}
+    out["grad/cls"] = cls.grad.numpy()
+    out["grad/box"] = box.grad.numpy()
+    out["grad/hs"] = hs.grad.numpy()
+    out["grad/feats_s_absmax"] = np.array([0.0 if f.grad is None else float(f.grad.abs().max()) for f in fs])
+    # per-term gradients w.r.t. hs for the two DSKD losses
+    for key in ("loss_corr", "loss_fg_feature"):
+        hs2 = inp["hs"].clone().requires_grad_(True)
+        l2 = cls_.loss(self, inp["cls"].clone(), inp["box"].clone(), (None, spatial), hs2, [b.clone() for b in inp["gt_b"]],
+                       [l.clone() for l in inp["gt_l"]], metas, gt_bboxes_ignore=None,
+                       student_feat=[f.clone() for f in inp["feats_s"]], teacher_info=teacher_info,
+                       task_labels={"prev": list(range(L)), "curr": list(range(L, 80)), "next": []})
+        l2[key].backward()
+        out[f"grad_hs/{key}"] = hs2.grad[-1].numpy()
+    return out
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(4)
+    ref = load_reference()
+
+    # 1. known answers of the reference's own tests
+    b1 = torch.FloatTensor([[0, 0, 10, 10], [10, 10, 20, 20], [32, 32, 38, 42]])
+    b2 = torch.FloatTensor([[0, 0, 10, 20], [0, 10, 10, 19], [10, 10, 20, 20]])
+    giou = ref["iou"].bbox_overlaps(b1, b2, "giou", is_aligned=True, eps=1e-7)
+    kd = ref["losses"]["kd_loss"].KnowledgeDistillationKLDivLoss(loss_weight=1.0, T=1)
+    kd_eq = kd(torch.Tensor([[100.0, 100.0]]), torch.Tensor([[1.0, 1.0]]))            # test_losses.py:98-102
+    kd_w = kd(torch.Tensor([[100.0, -100.0], [100.0, 100.0]]), torch.Tensor([[1.0, 0.0], [1.0, 1.0]]),
+              torch.Tensor([0.0, 1.0]))                                                # test_losses.py:104-110
+    np.savez(os.path.join(OUT, "known_answers.npz"), b1=b1.numpy(), b2=b2.numpy(), giou=giou.numpy(),
+             kd_equal=kd_eq.numpy(), kd_weighted=kd_w.numpy())
+
+    # 2. cost matrices + assignments from the reference assigner (local scipy inside)
+    g = torch.Generator().manual_seed(5)
+    assigner = ref["ga"].GFLHungarianAssigner(
+        cls_cost=dict(type="QualityFocalLossCost", weight=2.0), reg_cost=dict(type="BBoxL1Cost", weight=5.0, box_format="xywh"),
+        iou_cost=dict(type="IoUCost", iou_mode="giou", weight=2.0))
+    cases = {}
+    for k, (Q, G, w, h) in enumerate([(300, 17, 1333, 800), (300, 1, 640, 480), (300, 60, 1333, 800), (20, 25, 200, 100)]):
+        bbox = torch.rand(Q, 4, generator=g) * torch.tensor([1, 1, 0.5, 0.5])
+        cls = torch.randn(Q, 80, generator=g) * 3
+        xy = torch.rand(G, 2, generator=g) * torch.tensor([0.6 * w, 0.6 * h])
+        sz = torch.rand(G, 2, generator=g) * torch.tensor([0.35 * w, 0.35 * h]) + 8
+        gt = torch.cat([xy, xy + sz], 1)
+        lab = torch.randint(0, 80, (G,), generator=g)
+        meta = dict(img_shape=(h, w, 3))
+        # the cost as the reference builds it (lines 120-140 of its assign())
+        factor = gt.new_tensor([w, h, w, h]).unsqueeze(0)
+        ngt = gt / factor
+        cost = assigner.cls_cost(cls, lab, ref["tr"].bbox_cxcywh_to_xyxy(bbox), ngt) + assigner.reg_cost(bbox, ngt) + \
+            assigner.iou_cost(ref["tr"].bbox_cxcywh_to_xyxy(bbox) * factor, gt)
+        res = assigner.assign(bbox, cls, gt, lab, torch.zeros(Q, 68), meta)
+        cases.update({f"c{k}/bbox": bbox.numpy(), f"c{k}/cls": cls.numpy(), f"c{k}/gt": gt.numpy(), f"c{k}/lab": lab.numpy(),
+                      f"c{k}/wh": np.array([w, h], dtype=np.float32), f"c{k}/cost": cost.numpy(),
+                      f"c{k}/gt_inds": res.gt_inds.numpy(), f"c{k}/labels": res.labels.numpy()})
+    np.savez_compressed(os.path.join(OUT, "assign_cases.npz"), **cases)
+
+    # 3. Integral_average + elementwise loss modules
+    ia = ref["head"].Integral_average(16)
+    x = torch.rand(12, 68, generator=g)
+    pred = torch.randn(16, 80, generator=g)
+    lab = torch.randint(0, 81, (16,), generator=g)
+    sc = torch.rand(16, generator=g)
+    qfl = ref["losses"]["gfocal_loss"].QualityFocalLoss(use_sigmoid=True, beta=2.0, loss_weight=2.0)
+    dfl = ref["losses"]["gfocal_loss"].DistributionFocalLoss(loss_weight=0.5)
+    dp = torch.rand(24, 17, generator=g)
+    dl = torch.rand(24, generator=g) * 0.4
+    dw = (torch.rand(24, generator=g) > 0.5).float()
+    np.savez(os.path.join(OUT, "elementwise.npz"), ia_in=x.numpy(), ia_out=ia(x).numpy(), qfl_pred=pred.numpy(),
+             qfl_label=lab.numpy(), qfl_score=sc.numpy(), qfl_out=qfl(pred, (lab, sc), None, avg_factor=3.0).numpy(),
+             dfl_pred=dp.numpy(), dfl_label=dl.numpy(), dfl_w=dw.numpy(), dfl_out=dfl(dp, dl, weight=dw, avg_factor=12.0).numpy())
+
+    # 4. the reference loss() end to end (two cases)
+    for name, B, L, shapes, img_hw in [("loss_b1_l40", 1, 40, [(13, 21), (7, 11), (4, 6), (2, 3)], [(100, 167)]),
+                                       ("loss_b2_l70", 2, 70, [(9, 14), (5, 7)], [(72, 112), (70, 100)])]:
+        inp = make_loss_inputs(B, L, 11 + B, shapes, img_hw)
+        out = run_reference_loss(ref, inp, L, img_hw, shapes)
+        flat = {"B": np.array(B), "L": np.array(L), "shapes": np.array(shapes), "img_hw": np.array(img_hw),
+                "cls": inp["cls"].numpy(), "box": inp["box"].numpy(), "hs": inp["hs"].numpy(),
+                "hs_t_last": inp["hs_t"][-1].numpy(), "keep": inp["keep"].numpy()}
+        for i in range(len(shapes)):
+            flat[f"feat_s{i}"] = inp["feats_s"][i].numpy()
+            flat[f"feat_t{i}"] = inp["feats_t"][i].numpy()
+        for b in range(B):
+            flat[f"gt_b{b}"], flat[f"gt_l{b}"] = inp["gt_b"][b].numpy(), inp["gt_l"][b].numpy()
+            flat[f"t_b{b}"], flat[f"t_l{b}"] = inp["t_b"][b].numpy(), inp["t_l"][b].numpy()
+        flat.update(out)
+        # keep fixtures small: float16 would change inputs, so only drop what is re-derivable
+        flat.pop("grad/cls")
+        flat["grad/cls_sum_abs"] = np.abs(out["grad/cls"]).sum(axis=-1)
+        np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **flat)
+        print(name, {k: float(v) for k, v in out.items() if k.startswith("loss/")})
+
+
+if __name__ == "__main__":
+    main()
