@@ -1,0 +1,237 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec of one full teacher+student DSKD distillation training step
+(BASELINE.json metric) on synthetic COCO-shaped 800x1333 batches.
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+Workload (config.workload): BASELINE.json configs[1] -- Deformable-DETR R50 70+10 incremental,
+bf16 autocast for conv/GEMM (fp32 losses, costs, LSAP, MSDA accumulation), batch 4 per GPU.
+A step = teacher forward (no grad) + student forward + Hungarian targets + detection losses +
+both DSKD losses + backward + gradient all-reduce (N>1) + grad-clip + AdamW update; nothing is
+skipped or cached.  Inputs are resident in HBM before the timed region.  An untrained teacher
+emits no score > 0.3, so 10 synthetic teacher detections per image are injected through the
+same ``teacher_info`` dict after the real teacher forward + decode.
+
+The JSON line carries ``roofline`` (dominant hand-written kernel: MSDeformAttn, algorithmic
+bytes of SURVEY.md section 8d / measured HIP-event time of that launch) and ``cpu_baseline``
+(the CPU oracle restatement of the same step, B=1, timed on this host; rank 0, N=1 only).
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import dskd_amd  # noqa: E402,F401
+from dskd_amd import native  # noqa: E402
+from dskd_amd.builder import build_detector  # noqa: E402
+from dskd_amd.config import Config  # noqa: E402
+from dskd_amd.runner import build_optimizer  # noqa: E402
+
+CONFIG = os.path.join(ROOT, "configs", "dskd_gfl_deformable_detr_r50_70_10.py")
+IMG_H, IMG_W = 800, 1333
+LEVELS = [(100, 167), (50, 84), (25, 42), (13, 21)]
+NV = sum(h * w for h, w in LEVELS)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s float4-copy measured)
+
+
+def msda_algorithmic_bytes(kind, B, Nq, esz):
+    """compulsory unique bytes of one launch (esz = value/out element
+    size; loc 1024 B and attn 512 B per query are fp32)."""
+    fwd = B * (NV * 256 * esz + Nq * 1024 + Nq * 512 + Nq * 256 * esz)
+    if kind == "fwd":
+        return fwd
+    # bwd = fwd - out + grad_out + grad_value(fp32) + grad_loc + grad_attn
+    return fwd + B * (NV * 256 * 4 + Nq * 1024 + Nq * 512)
+
+
+def build_models(device, seed, dropout):
+    cfg = Config.fromfile(CONFIG)
+    torch.manual_seed(seed)
+    model = build_detector(cfg.model)
+    model.init_weights()
+    if dropout is not None:
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = dropout
+            if isinstance(m, torch.nn.MultiheadAttention):
+                m.dropout = dropout
+    teacher = copy.deepcopy(model)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for p in teacher.parameters():
+            p.add_(torch.randn(p.shape, generator=g) * 1e-3)     # so that hs_t != hs_s
+    model.set_teacher(model=teacher)
+    prev = list(range(cfg.num_prev))
+    model.LableInPCNTask = {"prev": prev, "curr": list(range(cfg.num_prev, 80)), "next": []}
+    model.to(device)
+    model.train()
+    return cfg, model
+
+
+def make_batch(B, num_prev, seed, device, n_gt=7, n_t=10):
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randn(B, 3, IMG_H, IMG_W, generator=g)
+
+    def boxes(n):
+        xy = torch.rand(n, 2, generator=g) * torch.tensor([0.6 * IMG_W, 0.6 * IMG_H])
+        lo, hi = torch.tensor([8.0, 8.0]), torch.tensor([0.35 * IMG_W, 0.35 * IMG_H])
+        wh = lo + torch.rand(n, 2, generator=g) * (hi - lo)
+        return torch.cat([xy, torch.minimum(xy + wh, torch.tensor([float(IMG_W), float(IMG_H)]))], 1)
+    gt_b = [boxes(n_gt).to(device) for _ in range(B)]
+    gt_l = [torch.randint(num_prev, 80, (n_gt,), generator=g).to(device) for _ in range(B)]
+    t_b = [boxes(n_t).to(device) for _ in range(B)]
+    t_l = [torch.randint(0, num_prev, (n_t,), generator=g).to(device) for _ in range(B)]
+    keep = torch.cat([b * 300 + torch.randperm(300, generator=g)[:n_t] for b in range(B)]).to(device)
+    metas = [dict(img_shape=(IMG_H, IMG_W, 3), batch_input_shape=(IMG_H, IMG_W), scale_factor=1.0) for _ in range(B)]
+    return dict(img=img.to(device), img_metas=metas, gt_bboxes=gt_b, gt_labels=gt_l), dict(t_b=t_b, t_l=t_l, keep=keep)
+
+
+def train_step(model, wrapped, optimizer, data, synth, amp_dtype, max_norm=0.1):
+    module = model
+    dev = data["img"].device
+    optimizer.zero_grad(set_to_none=True)
+    with torch.autocast(device_type=dev.type, dtype=amp_dtype, enabled=amp_dtype is not None):
+        feats, outs, keepid, logits, labels, scores, bboxes = module.out_teacher(data["img"], data["img_metas"])
+        teacher_info = {"neck_feats": feats, "head_outs": outs, "pred_keepid": synth["keep"], "pred_logits": None,
+                        "pred_scores": None, "pred_labels": synth["t_l"], "pred_bboxes": synth["t_b"]}
+        losses = wrapped(img=data["img"], img_metas=data["img_metas"], gt_bboxes=data["gt_bboxes"],
+                         gt_labels=data["gt_labels"], teacher_info=teacher_info)
+        loss, log_vars = module._parse_losses(losses)
+    loss.backward()
+    params = [p for gr in optimizer.param_groups for p in gr["params"] if p.grad is not None]
+    torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm, norm_type=2)
+    optimizer.step()
+    return loss, log_vars
+
+
+def cpu_baseline(seed, num_prev):
+    """The CPU oracle path of the same step (PyTorch CPU kernels + grid_sample MSDA + oracle
+    LSAP + loop DSKD losses), B=1 at 800x1333, 1 step, all host cores.  Bounded sample: one
+    image-step (~10-30 s of CPU work)."""
+    from oracle.checker import OracleChecker
+    native.install_cpu_checker(OracleChecker())
+    try:
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        cfg, model = build_models(torch.device("cpu"), seed, dropout=None)
+        opt = build_optimizer(model, cfg.optimizer[0])
+        data, synth = make_batch(1, num_prev, seed, torch.device("cpu"))
+        t0 = time.time()
+        train_step(model, model, opt, data, synth, None)
+        dt = time.time() - t0
+        return {"value": round(1.0 / dt, 5), "unit": "images/sec", "cores": cores, "kind": "port",
+                "sample": f"1 full distillation step, B=1, 800x1333, fp32, oracle CPU path ({dt:.1f} s)"}
+    finally:
+        native.install_cpu_checker(None)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="images per GPU (weak scaling)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dropout", type=float, default=None, help="override dropout p (default: config, 0.1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=111)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP hot path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    native.load()
+
+    torch.backends.cudnn.benchmark = True
+    amp_dtype = torch.bfloat16 if args.dtype == "bf16" else None
+    cfg, model = build_models(device, args.seed, args.dropout)
+    model = model.to(memory_format=torch.channels_last)
+    model.teacher_model.to(memory_format=torch.channels_last)
+    model.lazy_log = True                      # log scalars stay on the device inside the timed loop
+    wrapped = model
+    if world > 1:
+        from dskd_amd.dist import wrap_ddp
+        wrapped = wrap_ddp(model, device_ids=[local_rank])
+    optimizer = build_optimizer(model, cfg.optimizer[0])
+    data, synth = make_batch(args.batch, cfg.num_prev, args.seed + rank, device)
+    data["img"] = data["img"].contiguous(memory_format=torch.channels_last)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss, lv = train_step(model, wrapped, optimizer, data, synth, amp_dtype)
+    sync()
+    native.timing_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, lv = train_step(model, wrapped, optimizer, data, synth, amp_dtype)
+    sync()
+    dt = time.perf_counter() - t0
+    kt = native.timing_collect()
+    native.timing_enable(False)
+
+    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    final_loss = float(loss.detach().float().item())
+    if model.bbox_head.last_lsap_status is not None:
+        native.raise_for_lsap_status(model.bbox_head.last_lsap_status)
+
+    if rank == 0:
+        esz = 2 if args.dtype == "bf16" else 4
+        kernels = {}
+        for tag, (n, ms) in kt.items():
+            kind = "fwd" if "fwd" in tag else "bwd"
+            nq = NV if tag.endswith("enc") else 300
+            byts = msda_algorithmic_bytes(kind, args.batch, nq, esz)
+            avg_ms = ms / max(n, 1)
+            kernels[tag] = {"launches": n, "avg_us": round(avg_ms * 1e3, 2), "algorithmic_MB": round(byts / 1e6, 2),
+                            "achieved_GBs": round(byts / (avg_ms * 1e-3) / 1e9, 1), "total_ms": round(ms, 2)}
+        dom = max(kernels, key=lambda k: kernels[k]["total_ms"]) if kernels else None
+        roofline = None
+        if dom:
+            a = kernels[dom]["achieved_GBs"]
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(a / HBM_PEAK_GBS, 4), "traffic": None, "kernels": kernels}
+        ips = args.batch * world * args.steps / dt
+        out = {"metric": "images/sec (teacher+student distill step), DefDETR-R50 COCO 800x1333", "value": round(ips, 3),
+               "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": args.dtype,
+               "data": "synthetic (N(0,1) images 800x1333, 7 GT + 10 injected teacher detections per image, "
+                       "random-init weights, teacher = perturbed copy)",
+               "config": {"workload": "Deformable-DETR R50 70+10 incremental DSKD distillation step "
+                                      "(BASELINE.json configs[1])", "global_batch": args.batch * world,
+                          "per_gpu_batch": args.batch, "image": [IMG_H, IMG_W], "queries": 300, "prev_classes": cfg.num_prev,
+                          "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
+               "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.seed, cfg.num_prev)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -121,6 +121,47 @@ def _dispatch_cpu(name: str, t: torch.Tensor):
     return getattr(_cpu_checker, name)
 
 
+# --------------------------------------------------------------------------- live kernel timing
+class _KernelTiming:
+    """HIP-event brackets around individual kernel launches (bench.py roofline): events are
+    recorded on the stream the kernel is launched on (torch's current stream)."""
+    enabled = False
+    records = []
+
+
+def timing_enable(on: bool = True) -> None:
+    _KernelTiming.enabled = on
+    _KernelTiming.records = []
+
+
+def timing_collect():
+    """-> {tag: (launches, total_ms)}; call after a device synchronize."""
+    out = {}
+    for tag, e0, e1 in _KernelTiming.records:
+        n, t = out.get(tag, (0, 0.0))
+        out[tag] = (n + 1, t + e0.elapsed_time(e1))
+    _KernelTiming.records = []
+    return out
+
+
+class _timed:
+    def __init__(self, tag):
+        self.tag = tag
+
+    def __enter__(self):
+        if _KernelTiming.enabled:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _KernelTiming.enabled:
+            self.e1.record()
+            _KernelTiming.records.append((self.tag, self.e0, self.e1))
+        return False
+
+
 # --------------------------------------------------------------------------- MSDA
 def _geom(spatial_shapes: Sequence[Tuple[int, int]]):
     flat, starts, acc = [], [], 0
@@ -140,8 +181,9 @@ def msda_forward_raw(value, shapes, loc, attn):
     dt = {torch.float32: DTYPE_F32, torch.bfloat16: DTYPE_BF16}[value.dtype]
     value, loc, attn = value.contiguous(), loc.contiguous().float(), attn.contiguous().float()
     out = torch.empty((B, Nq, heads * ch), dtype=value.dtype, device=value.device)
-    rc = load().dskd_msda_fwd(value.data_ptr(), ss, ls, loc.data_ptr(), attn.data_ptr(), out.data_ptr(),
-                              B, Nv, Nq, heads, ch, L, P, dt, _stream(value))
+    with _timed("msda_fwd_enc" if Nq == Nv else "msda_fwd_dec"):
+        rc = load().dskd_msda_fwd(value.data_ptr(), ss, ls, loc.data_ptr(), attn.data_ptr(), out.data_ptr(),
+                                  B, Nv, Nq, heads, ch, L, P, dt, _stream(value))
     _check(rc, "dskd_msda_fwd")
     return out
 
@@ -157,9 +199,10 @@ def msda_backward_raw(value, shapes, loc, attn, grad_out):
     gv = torch.zeros((B, Nv, heads, ch), dtype=torch.float32, device=value.device)
     gl = torch.empty_like(loc)
     ga = torch.empty_like(attn)
-    rc = load().dskd_msda_bwd(value.data_ptr(), ss, ls, loc.data_ptr(), attn.data_ptr(), grad_out.data_ptr(),
-                              gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), B, Nv, Nq, heads, ch, L, P, dt,
-                              _stream(value))
+    with _timed("msda_bwd_enc" if Nq == Nv else "msda_bwd_dec"):
+        rc = load().dskd_msda_bwd(value.data_ptr(), ss, ls, loc.data_ptr(), attn.data_ptr(), grad_out.data_ptr(),
+                                  gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), B, Nv, Nq, heads, ch, L, P, dt,
+                                  _stream(value))
     _check(rc, "dskd_msda_bwd")
     return gv, gl, ga
 
