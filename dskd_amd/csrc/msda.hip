@@ -28,6 +28,7 @@
 //    full-rate shape, MI355X_MICROARCH.md "Global float atomics"); grad_loc / grad_attn
 //    come from per-head dot products reduced with DPP inside 8- / 4-lane groups.
 #include "common.h"
+#include <stdlib.h>
 
 namespace dskd {
 namespace {
@@ -46,9 +47,16 @@ struct LevelGeom {
   int start[kMaxLevels];
 };
 
-__device__ __forceinline__ int sel4(const int* a, int i) {
-  return i == 0 ? a[0] : (i == 1 ? a[1] : (i == 2 ? a[2] : a[3]));
+// Per-lane selection among four scalars.  Arrays inside kernel-argument structs must only be
+// indexed with compile-time constants (a runtime index sends the whole struct to scratch).
+__device__ __forceinline__ int sel4v(int a0, int a1, int a2, int a3, int i) {
+  return i == 0 ? a0 : (i == 1 ? a1 : (i == 2 ? a2 : a3));
 }
+#define SEL4(arr, i) sel4v((arr)[0], (arr)[1], (arr)[2], (arr)[3], (i))
+__device__ __forceinline__ float sel4f(float a0, float a1, float a2, float a3, int i) {
+  return i == 0 ? a0 : (i == 1 ? a1 : (i == 2 ? a2 : a3));
+}
+#define SEL4F(arr, i) sel4f((arr)[0], (arr)[1], (arr)[2], (arr)[3], (i))
 
 template <typename T>
 struct Traits;
@@ -73,7 +81,7 @@ template <int ROWB>
 __device__ __forceinline__ void point_params(float lx_n, float ly_n, float a, int lvl,
                                              const LevelGeom& g, i32x4& off, f32x4& w,
                                              f32x4& aux) {
-  const int H = sel4(g.H, lvl), W = sel4(g.W, lvl), st = sel4(g.start, lvl);
+  const int H = SEL4(g.H, lvl), W = SEL4(g.W, lvl), st = SEL4(g.start, lvl);
   const float x = lx_n * (float)W - 0.5f;
   const float y = ly_n * (float)H - 0.5f;
   off = i32x4{kOOB, kOOB, kOOB, kOOB};
@@ -248,7 +256,7 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_kernel(
 }
 
 // ------------------------------------------------------------------ backward
-template <typename T>
+template <typename T, bool WITH_VALUE>
 __global__ __launch_bounds__(kWaves * 64) void msda_bwd_kernel(
     const T* __restrict__ value, const float* __restrict__ loc,
     const float* __restrict__ attn, const T* __restrict__ grad_out,
@@ -331,7 +339,7 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_kernel(
       if (qv && part == (s & (TR::LPH - 1))) {
         const float lx = ax.x, ly = ax.y, a = ax.z;
         const int lvl = (int)ax.w;
-        const float Wf = (float)sel4(g.W, lvl), Hf = (float)sel4(g.H, lvl);
+        const float Wf = (float)SEL4(g.W, lvl), Hf = (float)SEL4(g.H, lvl);
         const float hx = 1.f - lx, hy = 1.f - ly;
         const float ga = w.x * d0 + w.y * d1 + w.z * d2 + w.w * d3;
         const float gx = Wf * a * (hy * (d1 - d0) + ly * (d3 - d2));
@@ -341,6 +349,10 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_kernel(
       }
     }
 
+    if constexpr (!WITH_VALUE) {
+      wave_lds_sync();
+      continue;
+    }
     // ---- phase B: grad_value scatter.  Lane = (corner parity, channel): one wave
     // instruction adds two complete 128-B head lines.
     const int ch = lane & 31;
@@ -376,6 +388,314 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_kernel(
     }
     wave_lds_sync();
   }
+}
+
+
+// ------------------------------------------------------------------ backward, grad_value (encoder)
+// In the encoder the queries ARE the pixels (Nq == Nv) and every sampling location is the
+// pixel's own centre plus a few-pixel offset, so the scatter of d(out)/d(value) is spatially
+// local.  v1 above pays one global float atomic per (corner, channel): 1.46 GB of atomic bytes
+// per image and call against a chip-wide rate of ~1.3 TB/s (MI355X_MICROARCH.md "Global float
+// atomics") -> ~1.04 ms per image, 10x everything else in this op, with thousands of adders
+// per row on the coarse levels.  Here a workgroup owns a REGION of the image (32x32 level-0
+// pixels, the queries of all four levels whose centre falls inside it), one head and an
+// 8-channel slice, and accumulates into LDS windows (region footprint + margin on every
+// level, ~116 KB); only the windows' non-zero entries reach HBM as atomics (~20x fewer atomic
+// bytes).  Samples that leave the window (large learned offsets) fall back to a direct global
+// atomic, so the result is correct for ANY sampling locations.
+//  * LDS float atomics are not usable for this on gfx950: measured (scratch/ubench/
+//    lds_atomics.hip) ds_add_f32 = 193 cycles per wave instruction per CU against 5.2 for
+//    ds_add_u32 -- the f32 form is serialised per lane.  The windows therefore accumulate in
+//    32-bit FIXED POINT with integer atomics: scale = 2^30 / (max|grad_out| * sum|attn|) over
+//    the workgroup's own queries (a proven bound of any cell's magnitude, so no overflow),
+//    i.e. >= 19 bits below that bound per contribution at 1360 queries; the sum itself is
+//    exact, hence independent of the arrival order (bitwise reproducible inside a window).
+//  * lane = (point parity, corner, channel): ONE ds_add per two sampling points, and with the
+//    window width == 2 (mod 4) and the channel-plane stride == 4 (mod 32) the 32 lanes of a
+//    half-wave (4 corners x 8 channels) hit 32 distinct banks: conflict-free.
+//  * the per-point arithmetic (floor, weights, window address) is done once per point by one
+//    lane and broadcast through the wave's LDS slice.
+constexpr int kRegion = 32;     // region edge, level-0 pixels
+constexpr int kMarginLo = 5;    // window margin below / above the region footprint
+constexpr int kMarginHi = 6;
+constexpr int kSlice = 8;       // channels per workgroup
+constexpr int kVWaves = 16;
+constexpr int kMaxReg = 16;     // regions per axis
+constexpr int kSkip = 0x7FFFFFF0;
+
+struct ValueGeom {
+  int H[kMaxLevels], W[kMaxLevels], start[kMaxLevels];
+  int ww[kMaxLevels], wh[kMaxLevels], base[kMaxLevels];
+  int NP, npos, RX, RY, levels;
+};
+
+// floor(x + 0.5) in ONE VALU instruction (v_cvt_rpi_i32_f32; checked on gfx950).  Plain
+// truncation would bias every contribution towards zero, which shows on the coarse levels
+// where a cell sums hundreds of them.
+__device__ __forceinline__ int cvt_round(float x) {
+  int r;
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
+__host__ __device__ inline int floor_div(int a, int b) {  // b > 0
+  const int q = a / b;
+  return (a % b != 0 && a < 0) ? q - 1 : q;
+}
+
+__device__ __forceinline__ int win_origin(int r, int Sl, int S0) {
+  // floor(r * kRegion * Sl / S0 - 0.5) - margin, in exact integer arithmetic
+  return floor_div(2 * kRegion * r * Sl - S0, 2 * S0) - kMarginLo;
+}
+
+// First query coordinate of region r on a level of extent Sl (finest level S0): the query x
+// belongs to region floor(((2x+1) * S0) / (2 * Sl)) / kRegion, so the range starts at
+// ceil((2 * kRegion * r * Sl - S0) / (2 * S0)), clamped to [0, Sl].
+__host__ __device__ inline int region_begin(int r, int Sl, int S0) {
+  const int v = floor_div(2 * kRegion * r * Sl - S0 + 2 * S0 - 1, 2 * S0);
+  return v < 0 ? 0 : (v > Sl ? Sl : v);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kVWaves * 64) void msda_bwd_value_kernel(
+    const float* __restrict__ loc, const float* __restrict__ attn,
+    const T* __restrict__ grad_out, float* __restrict__ grad_value, ValueGeom g, int Nq,
+    int LP, int points) {
+  extern __shared__ float smem[];
+  int* win = reinterpret_cast<int*>(smem);                     // [kSlice][NP] fixed point
+  int* s_off = win + kSlice * g.NP;                            // [waves][64][4]
+  float* s_w = reinterpret_cast<float*>(s_off + kVWaves * 64 * 4);
+  int* s_q = reinterpret_cast<int*>(s_w + kVWaves * 64 * 4);   // [waves][4]
+  float* s_red = reinterpret_cast<float*>(s_q + kVWaves * 4);  // [2 * waves] block reductions
+  float* s_g = s_red + 2 * kVWaves;                            // [waves][4][8] scaled grad_out
+  int* s_fb = reinterpret_cast<int*>(s_g + kVWaves * 32);      // [waves] fallback flag
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  int vb = xcd_remap(blockIdx.x, gridDim.x);
+  const int hs = vb & 31;          // (head, slice): the 32 workgroups of a region are adjacent
+  vb >>= 5;
+  const int rx = vb % g.RX; vb /= g.RX;
+  const int ry = vb % g.RY;
+  const int b = vb / g.RY;
+  const int h = hs >> 2, slice = hs & 3;
+  const int chbase = h * kCh + slice * kSlice;
+
+  // queries of this region, per level
+  int cum[kMaxLevels + 1], qxa[kMaxLevels], qdx[kMaxLevels], qya[kMaxLevels];
+  int wx0[kMaxLevels], wy0[kMaxLevels];
+  cum[0] = 0;
+#pragma unroll
+  for (int l = 0; l < kMaxLevels; ++l) {
+    const bool on = l < g.levels;
+    qxa[l] = region_begin(rx, g.W[l], g.W[0]);
+    qya[l] = region_begin(ry, g.H[l], g.H[0]);
+    qdx[l] = on ? region_begin(rx + 1, g.W[l], g.W[0]) - qxa[l] : 0;
+    const int dy = on ? region_begin(ry + 1, g.H[l], g.H[0]) - qya[l] : 0;
+    cum[l + 1] = cum[l] + qdx[l] * dy;
+    wx0[l] = win_origin(rx, g.W[l], g.W[0]);
+    wy0[l] = win_origin(ry, g.H[l], g.H[0]);
+  }
+  const int nq = cum[kMaxLevels];
+  float qinv[kMaxLevels];
+#pragma unroll
+  for (int l = 0; l < kMaxLevels; ++l) qinv[l] = 1.0f / (float)(qdx[l] > 0 ? qdx[l] : 1);
+
+  for (int i = tid * 4; i < kSlice * g.NP; i += kVWaves * 64 * 4)
+    *reinterpret_cast<i32x4*>(win + i) = i32x4{0, 0, 0, 0};
+
+  float* gvb = grad_value + (size_t)b * Nq * (kHeads * kCh) + chbase;
+  const T* gob = grad_out + (size_t)b * Nq * (kHeads * kCh) + chbase;
+
+  // ---- fixed-point scale: bound of any window cell = max|grad_out| * sum|attn| over the region
+  float gmax = 0.f, asum = 0.f;
+  for (int i = tid; i < nq * kSlice; i += kVWaves * 64) {
+    const int qi = i >> 3;
+    int lq = 0;
+#pragma unroll
+    for (int l = 1; l < kMaxLevels; ++l) lq += qi >= cum[l];
+    const int rem = qi - SEL4(cum, lq);
+    const int dx = SEL4(qdx, lq);
+    const int yy = (int)(((float)rem + 0.5f) * SEL4F(qinv, lq));
+    const int qg = SEL4(g.start, lq) + (SEL4(qya, lq) + yy) * SEL4(g.W, lq) + SEL4(qxa, lq) + (rem - yy * dx);
+    gmax = fmaxf(gmax, fabsf((float)gob[(size_t)qg * (kHeads * kCh) + (i & 7)]));
+    const float* ap = attn + (((size_t)b * Nq + qg) * kHeads + h) * (size_t)LP;
+    for (int s2 = (i & 7); s2 < LP; s2 += kSlice) asum += fabsf(ap[s2]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    gmax = fmaxf(gmax, __shfl_xor(gmax, o));
+    asum += __shfl_xor(asum, o);
+  }
+  if (lane == 0) { s_red[wave] = gmax; s_red[kVWaves + wave] = asum; }
+  __syncthreads();
+  gmax = 0.f; asum = 0.f;
+#pragma unroll
+  for (int w2 = 0; w2 < kVWaves; ++w2) { gmax = fmaxf(gmax, s_red[w2]); asum += s_red[kVWaves + w2]; }
+  const float bound = gmax * asum;
+  if (bound == 0.f) return;   // nothing to scatter from this region (uniform across the workgroup)
+  // NaN / inf gradients: accumulate nothing here and let them through the float fallback below
+  const bool fx_ok = bound > 0.f && bound < 3.0e38f;
+  const float fx_scale = fx_ok ? 1.0e9f / bound : 0.f;        // 1e9 < 2^30: headroom for rounding
+  const float fx_inv = fx_ok ? bound * 1.0e-9f : 0.f;
+  int* my_off = s_off + wave * 64 * 4;
+  float* my_w = s_w + wave * 64 * 4;
+  int* my_q = s_q + wave * 4;
+  float* my_g = s_g + wave * 32;
+  const int half = lane >> 5, corner = (lane >> 3) & 3, ch = lane & 7;
+  char* win_ch = reinterpret_cast<char*>(win + ch * g.NP);
+  const unsigned dummy = (unsigned)(g.npos + corner + 4 * half) * 4u;   // 8 spare slots per channel plane
+
+  for (int qbase = wave * 4; qbase < nq; qbase += kVWaves * 4) {
+    // ---- phase 1: one lane per sampling point (4 queries x 16 points)
+    {
+      const int qi = qbase + (lane >> 4);
+      const int s = lane & 15;
+      // LDS byte offsets; kSkip (and the negative fallback codes) are clamped onto the
+      // consumer lane's dummy slot by an unsigned min in phase 2
+      i32x4 off = i32x4{kSkip, kSkip, kSkip, kSkip};
+      f32x4 w = f32x4{0.f, 0.f, 0.f, 0.f};
+      bool is_fb = false;
+      int qg = -1;
+      if (qi < nq) {
+        int lq = 0;
+#pragma unroll
+        for (int l = 1; l < kMaxLevels; ++l) lq += qi >= cum[l];
+        const int rem = qi - SEL4(cum, lq);
+        const int xa = SEL4(qxa, lq);
+        const int dx = SEL4(qdx, lq);
+        const int ya = SEL4(qya, lq);
+        // exact: the fractional part of (rem + 0.5) / dx is at least 0.5/dx away from an integer
+        const int yy = (int)(((float)rem + 0.5f) * SEL4F(qinv, lq));
+        qg = SEL4(g.start, lq) + (ya + yy) * SEL4(g.W, lq) + xa + (rem - yy * dx);
+        if (s < LP) {
+          const size_t base = (((size_t)b * Nq + qg) * kHeads + h) * (size_t)LP + s;
+          const f32x2 xy = *reinterpret_cast<const f32x2*>(loc + base * 2);
+          const float a = attn[base];
+          const int lvl = points == 4 ? s >> 2 : s / points;
+          const int H = SEL4(g.H, lvl), W = SEL4(g.W, lvl), st = SEL4(g.start, lvl);
+          const float x = xy.x * (float)W - 0.5f;
+          const float y = xy.y * (float)H - 0.5f;
+          if (x > -1.f && y > -1.f && x < (float)W && y < (float)H) {
+            const float xf = floorf(x), yf = floorf(y);
+            const int x0 = (int)xf, y0 = (int)yf;
+            const float lx = x - xf, ly = y - yf, hx = 1.f - lx, hy = 1.f - ly;
+            const bool vx0 = x0 >= 0, vx1 = x0 + 1 <= W - 1, vy0 = y0 >= 0, vy1 = y0 + 1 <= H - 1;
+            w = f32x4{(vy0 && vx0) ? hy * hx * a : 0.f, (vy0 && vx1) ? hy * lx * a : 0.f,
+                      (vy1 && vx0) ? ly * hx * a : 0.f, (vy1 && vx1) ? ly * lx * a : 0.f};
+            const int wwl = SEL4(g.ww, lvl), whl = SEL4(g.wh, lvl);
+            const int wx = x0 - SEL4(wx0, lvl), wy = y0 - SEL4(wy0, lvl);
+            if (fx_ok && wx >= 0 && wx + 1 < wwl && wy >= 0 && wy + 1 < whl) {
+              const int pb = (SEL4(g.base, lvl) + wy * wwl + wx) * 4;
+              off = i32x4{pb, pb + 4, pb + wwl * 4, pb + wwl * 4 + 4};
+            } else {  // outside the LDS window: direct global atomics, rows encoded as -(2+row)
+              const int r00 = st + y0 * W + x0;
+              off = i32x4{(vy0 && vx0) ? -(2 + r00) : -1, (vy0 && vx1) ? -(2 + r00 + 1) : -1,
+                          (vy1 && vx0) ? -(2 + r00 + W) : -1, (vy1 && vx1) ? -(2 + r00 + W + 1) : -1};
+              is_fb = true;
+            }
+          }
+        }
+      }
+      const bool any_fb = __any(is_fb);
+      *reinterpret_cast<i32x4*>(my_off + lane * 4) = off;
+      *reinterpret_cast<f32x4*>(my_w + lane * 4) = w;
+      if ((lane & 15) == 0) my_q[lane >> 4] = qg;
+      if ((lane & 15) < kSlice)   // stage the four queries' grad_out slice, pre-scaled
+        my_g[(lane >> 4) * kSlice + (lane & 7)] =
+            qg >= 0 ? (float)gob[(size_t)qg * (kHeads * kCh) + (lane & 7)] : 0.f;
+      if (lane == 0) s_fb[wave] = any_fb ? 1 : 0;
+    }
+    wave_lds_sync();
+
+    // ---- phase 2: lane = (point parity, corner, channel).  Every lane always adds (skipped
+    // and out-of-window corners are clamped onto a per-lane dummy slot by one unsigned min), so
+    // the loop is branch-free: per ds_add one LDS read, one multiply, one rounding convert, one
+    // address add.
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int offs[8];
+      float ws[8];
+      const float gs = my_g[k * kSlice + ch] * fx_scale;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int pt = 2 * (k * 8 + j) + half;
+        offs[j] = my_off[pt * 4 + corner];
+        ws[j] = my_w[pt * 4 + corner];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned o = min((unsigned)offs[j], dummy);
+        atomicAdd(reinterpret_cast<int*>(win_ch + o), cvt_round(ws[j] * gs));
+      }
+    }
+    if (s_fb[wave]) {   // rare: samples that left the window -> direct global atomics
+      for (int it = 0; it < 32; ++it) {
+        const int pt = 2 * it + half;
+        const int o = my_off[pt * 4 + corner];
+        if (o <= -2)
+          atomicAdd(gvb + (size_t)(-(o + 2)) * (kHeads * kCh) + ch,
+                    my_w[pt * 4 + corner] * my_g[(it >> 3) * kSlice + ch]);
+      }
+    }
+    wave_lds_sync();
+  }
+  __syncthreads();
+
+  // ---- flush the non-zero window entries
+  for (int p = tid >> 3; p < g.npos; p += kVWaves * 8) {
+    const int iv = win[ch * g.NP + p];
+    if (iv == 0) continue;
+    const float v = (float)iv * fx_inv;
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxLevels; ++k) l += (k < g.levels && p >= g.base[k]) ? 1 : 0;
+    const int rel = p - SEL4(g.base, l);
+    const int wwl = SEL4(g.ww, l);
+    const int wy = (int)(((float)rel + 0.5f) / (float)wwl), wx = rel - wy * wwl;
+    const int gx = SEL4(wx0, l) + wx, gy = SEL4(wy0, l) + wy;
+    if (gx >= 0 && gx < SEL4(g.W, l) && gy >= 0 && gy < SEL4(g.H, l))
+      atomicAdd(gvb + (size_t)(SEL4(g.start, l) + gy * SEL4(g.W, l) + gx) * (kHeads * kCh) + ch, v);
+  }
+}
+
+// Host side of the windowed kernel: per-level window extents and per-region query ranges.
+// Returns false when the geometry does not fit (then the v1 kernel is used).
+bool make_value_geom(const LevelGeom& lg, int levels, int Nq, ValueGeom* g, size_t* lds_bytes) {
+  int tot = 0;
+  for (int l = 0; l < levels; ++l) tot += lg.H[l] * lg.W[l];
+  if (tot != Nq) return false;
+  for (int l = 0; l < levels; ++l)
+    if (lg.start[l] != (l == 0 ? 0 : lg.start[l - 1] + lg.H[l - 1] * lg.W[l - 1])) return false;
+  const int W0 = lg.W[0], H0 = lg.H[0];
+  g->levels = levels;
+  g->RX = (W0 + kRegion - 1) / kRegion;
+  g->RY = (H0 + kRegion - 1) / kRegion;
+  if (g->RX > kMaxReg || g->RY > kMaxReg) return false;
+  int npos = 0;
+  for (int l = 0; l < kMaxLevels; ++l) {
+    if (l < levels) {
+      if (lg.W[l] > W0 || lg.H[l] > H0) return false;   // level 0 must be the finest
+      g->H[l] = lg.H[l]; g->W[l] = lg.W[l]; g->start[l] = lg.start[l];
+      int ww = (kRegion * lg.W[l] + W0 - 1) / W0 + 1 + kMarginLo + kMarginHi;
+      while ((ww & 3) != 2) ++ww;                        // bank spread of the 4 corners
+      const int wh = (kRegion * lg.H[l] + H0 - 1) / H0 + 1 + kMarginLo + kMarginHi;
+      g->ww[l] = ww; g->wh[l] = wh; g->base[l] = npos;
+      npos += ww * wh;
+    } else {
+      g->H[l] = 1; g->W[l] = 1; g->start[l] = 0; g->ww[l] = 2; g->wh[l] = 1; g->base[l] = npos;
+    }
+  }
+  g->npos = npos;
+  int NP = npos + 8;                                      // + dummy slots of the branch-free loop
+  while ((NP & 31) != 4) ++NP;                            // channel-plane stride: +4 banks per channel
+  g->NP = NP;
+  *lds_bytes = sizeof(float) * (size_t)kSlice * NP + (sizeof(int) + sizeof(float)) * kVWaves * 64 * 4 +
+               sizeof(int) * kVWaves * 4 + sizeof(float) * 2 * kVWaves + sizeof(float) * kVWaves * 32 +
+               sizeof(int) * kVWaves;
+  return *lds_bytes <= 156 * 1024;
 }
 
 int fill_geom(const int64_t* spatial_shapes, const int64_t* level_start, int levels, int Nv,
@@ -459,13 +779,46 @@ extern "C" int dskd_msda_bwd(const void* value, const int64_t* spatial_shapes,
   const int bpi = (Nq + kQPB - 1) / kQPB;
   const dim3 grid((unsigned)(B * bpi)), block(kWaves * 64);
   hipStream_t st = (hipStream_t)stream;
+  const int LP = levels * points;
+
+  // Encoder self-attention shape (queries == pixels): windowed LDS accumulation of grad_value.
+  ValueGeom vg;
+  size_t lds = 0;
+  const char* env = getenv("DSKD_MSDA_BWD");   // "v1" forces the plain-atomics kernel (A/B tests)
+  const bool force_v1 = env && env[0] == 'v' && env[1] == '1';
+  const bool windowed = !force_v1 && Nq == Nv && make_value_geom(g, levels, Nq, &vg, &lds);
+  if (windowed) {
+    const dim3 vgrid((unsigned)(B * vg.RY * vg.RX * 32)), vblock(kVWaves * 64);
+    if (dtype == DSKD_DTYPE_F32) {
+      static const hipError_t attr =
+          hipFuncSetAttribute((const void*)msda_bwd_value_kernel<float>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+      if (attr != hipSuccess) return fail(DSKD_ERR_LAUNCH, "dskd_msda_bwd: cannot reserve LDS");
+      hipLaunchKernelGGL((msda_bwd_kernel<float, false>), grid, block, 0, st, (const float*)value, loc, attn,
+                         (const float*)grad_out, grad_value, grad_loc, grad_attn, g, Nv, Nq, LP, points, kQPB,
+                         bpi);
+      hipLaunchKernelGGL(msda_bwd_value_kernel<float>, vgrid, vblock, lds, st, loc, attn,
+                         (const float*)grad_out, grad_value, vg, Nq, LP, points);
+    } else {
+      static const hipError_t attr =
+          hipFuncSetAttribute((const void*)msda_bwd_value_kernel<__bf16>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+      if (attr != hipSuccess) return fail(DSKD_ERR_LAUNCH, "dskd_msda_bwd: cannot reserve LDS");
+      hipLaunchKernelGGL((msda_bwd_kernel<__bf16, false>), grid, block, 0, st, (const __bf16*)value, loc, attn,
+                         (const __bf16*)grad_out, grad_value, grad_loc, grad_attn, g, Nv, Nq, LP, points, kQPB,
+                         bpi);
+      hipLaunchKernelGGL(msda_bwd_value_kernel<__bf16>, vgrid, vblock, lds, st, loc, attn,
+                         (const __bf16*)grad_out, grad_value, vg, Nq, LP, points);
+    }
+    return check_launch("dskd_msda_bwd");
+  }
   if (dtype == DSKD_DTYPE_F32)
-    hipLaunchKernelGGL(msda_bwd_kernel<float>, grid, block, 0, st, (const float*)value, loc,
+    hipLaunchKernelGGL((msda_bwd_kernel<float, true>), grid, block, 0, st, (const float*)value, loc,
                        attn, (const float*)grad_out, grad_value, grad_loc, grad_attn, g, Nv,
-                       Nq, levels * points, points, kQPB, bpi);
+                       Nq, LP, points, kQPB, bpi);
   else
-    hipLaunchKernelGGL(msda_bwd_kernel<__bf16>, grid, block, 0, st, (const __bf16*)value, loc,
+    hipLaunchKernelGGL((msda_bwd_kernel<__bf16, true>), grid, block, 0, st, (const __bf16*)value, loc,
                        attn, (const __bf16*)grad_out, grad_value, grad_loc, grad_attn, g, Nv,
-                       Nq, levels * points, points, kQPB, bpi);
+                       Nq, LP, points, kQPB, bpi);
   return check_launch("dskd_msda_bwd");
 }

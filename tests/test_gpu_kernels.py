@@ -116,6 +116,56 @@ def test_msda_full_size_properties():
     torch.testing.assert_close(ga, torch.full_like(ga, 32.0), atol=1e-3, rtol=1e-4)
 
 
+def _encoder_like_inputs(shapes, B, seed, sigma_px, dtype=torch.float32):
+    """Queries = pixels (Nq == Nv): reference point = pixel centre, offsets ~ N(0, sigma_px) pixels."""
+    g = torch.Generator().manual_seed(seed)
+    Nv = sum(h * w for h, w in shapes)
+    value = torch.randn(B, Nv, 8, 32, generator=g).to(dtype)
+    pts = []
+    for (H, W) in shapes:
+        ys, xs = torch.meshgrid((torch.arange(H) + 0.5) / H, (torch.arange(W) + 0.5) / W, indexing="ij")
+        pts.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], -1))
+    ref = torch.cat(pts, 0)[None].expand(B, -1, -1)
+    off = torch.randn(B, Nv, 8, len(shapes), 4, 2, generator=g) * sigma_px
+    norm = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32).view(1, 1, 1, len(shapes), 1, 2)
+    loc = (ref[:, :, None, None, None, :] + off / norm).contiguous()
+    attn = torch.softmax(torch.randn(B, Nv, 8, len(shapes) * 4, generator=g), -1).view(B, Nv, 8, len(shapes), 4)
+    go = torch.randn(B, Nv, 256, generator=g).to(dtype)
+    return value, loc, attn, go
+
+
+@pytest.mark.parametrize("shapes,sigma", [([(25, 42), (13, 21), (7, 11), (4, 6)], 2.0),
+                                          ([(40, 70), (20, 35), (10, 18), (5, 9)], 12.0),   # many window misses
+                                          ([(33, 47), (17, 24)], 3.0), ([(9, 5)], 1.0)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_msda_bwd_windowed_encoder_shape(shapes, sigma, dtype):
+    """Nq == Nv takes the windowed LDS-accumulation kernel: parity with autograd of the oracle,
+    including offsets far beyond the window margin (global-atomic fallback)."""
+    value, loc, attn, go = _encoder_like_inputs(shapes, 2, 31, sigma, dtype)
+    v = value.float().requires_grad_(True)
+    l = loc.clone().requires_grad_(True)
+    a = attn.clone().requires_grad_(True)
+    msda_ref.msda_grid_sample(v, shapes, l, a).backward(go.float())
+    gv, gl, ga = native.msda_backward_raw(value.to(DEV), shapes, loc.to(DEV), attn.to(DEV), go.to(DEV))
+    tol = dict(atol=2e-4, rtol=1e-3) if dtype == torch.float32 else dict(atol=4e-3, rtol=4e-3)
+    torch.testing.assert_close(gv.cpu(), v.grad, **tol)
+    torch.testing.assert_close(ga.cpu(), a.grad, **tol)
+
+
+def test_msda_bwd_windowed_matches_plain_atomics_full_size(monkeypatch):
+    """BASELINE size: the windowed kernel against the plain-atomics kernel (DSKD_MSDA_BWD=v1)."""
+    value, loc, attn, go = _encoder_like_inputs(SHAPES_FULL, 2, 41, 2.5)
+    args = (value.to(DEV), SHAPES_FULL, loc.to(DEV), attn.to(DEV), go.to(DEV))
+    gv2, gl2, ga2 = native.msda_backward_raw(*args)
+    monkeypatch.setenv("DSKD_MSDA_BWD", "v1")
+    gv1, gl1, ga1 = native.msda_backward_raw(*args)
+    monkeypatch.delenv("DSKD_MSDA_BWD")
+    torch.testing.assert_close(gv2, gv1, atol=2e-4, rtol=1e-3)
+    assert torch.equal(gl2, gl1) and torch.equal(ga2, ga1)
+    # conservation: sum over value rows of grad_value == sum_q sum_inside-samples attn * grad_out
+    torch.testing.assert_close(gv2.sum(dim=(1,)), gv1.sum(dim=(1,)), atol=5e-2, rtol=1e-3)
+
+
 # ----------------------------------------------------------------------------- LSAP
 def _lsap_device(mats):
     flat = torch.cat([torch.from_numpy(m).reshape(-1) for m in mats]).to(DEV)
