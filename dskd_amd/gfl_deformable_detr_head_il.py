@@ -176,19 +176,24 @@ class GFLDeformableDETRHead_il(nn.Module):
         batch_size = mlvl_feats[0].size(0)
         input_img_h, input_img_w = img_metas[0]["batch_input_shape"]
         full = all(tuple(m["img_shape"][:2]) == (input_img_h, input_img_w) for m in img_metas)
-        img_masks = mlvl_feats[0].new_zeros((batch_size, input_img_h, input_img_w), dtype=torch.float32) if full else \
-            mlvl_feats[0].new_ones((batch_size, input_img_h, input_img_w), dtype=torch.float32)
-        if not full:
+        key = (full, batch_size, input_img_h, input_img_w, tuple(f.shape[-2:] for f in mlvl_feats), mlvl_feats[0].device)
+        if full and getattr(self, "_pe_key", None) == key:
+            # un-padded batch: masks are all False and the sine encodings are constants
+            mlvl_masks, mlvl_positional_encodings = self._pe_cache
+        else:
+            img_masks = mlvl_feats[0].new_ones((batch_size, input_img_h, input_img_w), dtype=torch.float32)
             for img_id in range(batch_size):
                 img_h, img_w, _ = img_metas[img_id]["img_shape"]
                 img_masks[img_id, :img_h, :img_w] = 0
-        mlvl_masks, mlvl_positional_encodings = [], []
-        for feat in mlvl_feats:
-            mlvl_masks.append(F.interpolate(img_masks[None], size=feat.shape[-2:]).to(torch.bool).squeeze(0))
-            mlvl_positional_encodings.append(self.positional_encoding(mlvl_masks[-1]))
+            mlvl_masks, mlvl_positional_encodings = [], []
+            for feat in mlvl_feats:
+                mlvl_masks.append(F.interpolate(img_masks[None], size=feat.shape[-2:]).to(torch.bool).squeeze(0))
+                mlvl_positional_encodings.append(self.positional_encoding(mlvl_masks[-1]))
+            if full:
+                self._pe_key, self._pe_cache = key, (mlvl_masks, mlvl_positional_encodings)
         hs, init_reference, inter_references, memory, _, _ = self.transformer(
             mlvl_feats, mlvl_masks, self.query_embedding.weight, mlvl_positional_encodings,
-            reg_branches=None, cls_branches=None)
+            reg_branches=None, cls_branches=None, all_valid=full)
         hs = hs.permute(0, 2, 1, 3)
         # cls / reg branches are shared and the reference point never moves without box
         # refinement: run the six per-layer heads as one batched GEMM each.

@@ -103,15 +103,23 @@ class MultiScaleDeformableAttention(nn.Module):
         nn.init.constant_(self.output_proj.bias, 0.)
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,
-                reference_points=None, spatial_shapes=None, level_start_index=None, **kwargs):
+                reference_points=None, spatial_shapes=None, level_start_index=None, tokens_batch_first=None,
+                value_batch_first=None, **kwargs):
+        """``tokens_batch_first`` / ``value_batch_first`` (set by DeformableDetrTransformer)
+        override the module's ``batch_first`` for query/output and for ``value``: the encoder
+        runs batch-first end to end so that no [B, 22k, 256] tensor is ever permuted+copied."""
+        q_bf = self.batch_first if tokens_batch_first is None else tokens_batch_first
+        v_bf = q_bf if value_batch_first is None else value_batch_first
         if value is None:
             value = query
+            v_bf = q_bf
         if identity is None:
             identity = query
         if query_pos is not None:
             query = query + query_pos
-        if not self.batch_first:
+        if not q_bf:
             query = query.permute(1, 0, 2)
+        if not v_bf:
             value = value.permute(1, 0, 2)
         bs, num_query, _ = query.shape
         bs, num_value, _ = value.shape
@@ -129,7 +137,10 @@ class MultiScaleDeformableAttention(nn.Module):
         attention_weights = attention_weights.softmax(-1).view(
             bs, num_query, self.num_heads, self.num_levels, self.num_points)
         if reference_points.shape[-1] == 2:
-            normalizer = sampling_offsets.new_tensor([[w, h] for h, w in shapes])
+            key = (tuple(map(tuple, shapes)), sampling_offsets.device)
+            if getattr(self, "_norm_key", None) != key:      # constant per geometry: build once
+                self._norm_key, self._norm = key, sampling_offsets.new_tensor([[w, h] for h, w in shapes])
+            normalizer = self._norm
             sampling_locations = reference_points[:, :, None, :, None, :].float() \
                 + sampling_offsets / normalizer[None, None, None, :, None, :]
         elif reference_points.shape[-1] == 4:
@@ -139,7 +150,7 @@ class MultiScaleDeformableAttention(nn.Module):
             raise ValueError(f"Last dim of reference_points must be 2 or 4, but get {reference_points.shape[-1]}")
         output = native.ms_deform_attn(value, shapes, sampling_locations, attention_weights)
         output = self.output_proj(output)
-        if not self.batch_first:
+        if not q_bf:
             output = output.permute(1, 0, 2)
         return self.dropout(output) + identity
 
@@ -427,32 +438,46 @@ class DeformableDetrTransformer(nn.Module):
         return torch.stack([valid_W.float() / W, valid_H.float() / H], -1)
 
     def forward(self, mlvl_feats, mlvl_masks, query_embed, mlvl_pos_embeds, reg_branches=None, cls_branches=None,
-                **kwargs):
+                all_valid=False, **kwargs):
+        """``all_valid=True`` (no image in the batch is padded, known on the host from
+        img_metas): the padding masks are all False, so they are not materialised, the
+        valid ratios are exactly 1 and the encoder reference points are a cached constant --
+        same numbers, fewer passes over the 22k-token tensors."""
         assert query_embed is not None
         feat_flatten, mask_flatten, lvl_pos_embed_flatten, spatial_shapes = [], [], [], []
         for lvl, (feat, mask, pos_embed) in enumerate(zip(mlvl_feats, mlvl_masks, mlvl_pos_embeds)):
             bs, c, h, w = feat.shape
             spatial_shapes.append((h, w))
             feat_flatten.append(feat.flatten(2).transpose(1, 2))
-            mask_flatten.append(mask.flatten(1))
+            if not all_valid:
+                mask_flatten.append(mask.flatten(1))
             lvl_pos_embed_flatten.append(pos_embed.flatten(2).transpose(1, 2) + self.level_embeds[lvl].view(1, 1, -1))
         feat_flatten = torch.cat(feat_flatten, 1)
-        mask_flatten = torch.cat(mask_flatten, 1)
+        mask_flatten = torch.cat(mask_flatten, 1) if not all_valid else None
         lvl_pos_embed_flatten = torch.cat(lvl_pos_embed_flatten, 1)
         device = feat_flatten.device
         level_start_index = [0]
         for h, w in spatial_shapes[:-1]:
             level_start_index.append(level_start_index[-1] + h * w)
-        valid_ratios = torch.stack([self.get_valid_ratio(m) for m in mlvl_masks], 1)
-        reference_points = self.get_reference_points(spatial_shapes, valid_ratios, device=device)
+        if all_valid:
+            bs0 = feat_flatten.shape[0]
+            key = (tuple(spatial_shapes), bs0, device)
+            if getattr(self, "_ref_key", None) != key:
+                vr = torch.ones((bs0, len(spatial_shapes), 2), dtype=torch.float32, device=device)
+                self._ref_key, self._ref_cache = key, (vr, self.get_reference_points(spatial_shapes, vr, device=device))
+            valid_ratios, reference_points = self._ref_cache
+            mask_flatten = None
+        else:
+            valid_ratios = torch.stack([self.get_valid_ratio(m) for m in mlvl_masks], 1)
+            reference_points = self.get_reference_points(spatial_shapes, valid_ratios, device=device)
 
-        feat_flatten = feat_flatten.permute(1, 0, 2)                  # (sum HW, bs, C) views
-        lvl_pos_embed_flatten = lvl_pos_embed_flatten.permute(1, 0, 2)
+        # The encoder runs batch-first [bs, sum HW, C] (the reference feeds (sum HW, bs, C) and
+        # MSDA permutes inside, transformer.py:983-995): LayerNorm / FFN / MSDA are per-token,
+        # so the numbers are identical and no 22k-token tensor is permuted + copied.
         memory = self.encoder(query=feat_flatten, key=None, value=None, query_pos=lvl_pos_embed_flatten,
                               query_key_padding_mask=mask_flatten, spatial_shapes=spatial_shapes,
                               reference_points=reference_points, level_start_index=level_start_index,
-                              valid_ratios=valid_ratios, **kwargs)
-        memory = memory.permute(1, 0, 2)
+                              valid_ratios=valid_ratios, tokens_batch_first=True, **kwargs)
         bs, _, c = memory.shape
         query_pos, query = torch.split(query_embed, c, dim=1)
         query_pos = query_pos.unsqueeze(0).expand(bs, -1, -1)
@@ -461,12 +486,11 @@ class DeformableDetrTransformer(nn.Module):
         init_reference_out = reference_points
 
         query = query.permute(1, 0, 2)
-        memory = memory.permute(1, 0, 2)
         query_pos = query_pos.permute(1, 0, 2)
         inter_states, inter_references = self.decoder(
             query=query, key=None, value=memory, query_pos=query_pos, key_padding_mask=mask_flatten,
             reference_points=reference_points, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
-            valid_ratios=valid_ratios, reg_branches=reg_branches, **kwargs)
+            valid_ratios=valid_ratios, reg_branches=reg_branches, value_batch_first=True, **kwargs)
         spatial_shapes_t = torch.as_tensor(spatial_shapes, dtype=torch.long, device=device)
-        info_all = (memory, spatial_shapes_t)
+        info_all = (memory.permute(1, 0, 2), spatial_shapes_t)      # reference layout (sum HW, bs, C), a view
         return inter_states, init_reference_out, inter_references, info_all, None, None

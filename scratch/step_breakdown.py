@@ -1,0 +1,29 @@
+import csv, collections, sys
+path=sys.argv[1]
+rows=list(csv.DictReader(open(path)))
+rows.sort(key=lambda r:int(r['Start_Timestamp']))
+naive=[i for i,r in enumerate(rows) if 'naive_conv' in r['Kernel_Name']]
+rs=rows[(max(naive)+1 if naive else 0):]
+adam=[i for i,r in enumerate(rs) if 'adam' in r['Kernel_Name'].lower()]
+groups=[]; prev=None
+for i in adam:
+    if prev is None or i-prev>50: groups.append([i])
+    else: groups[-1].append(i)
+    prev=i
+a=groups[-2][-1]+1; b=groups[-1][-1]+1
+step=rs[a:b]
+st=int(step[0]['Start_Timestamp']); en=int(step[-1]['End_Timestamp'])
+busy=sum(int(r['End_Timestamp'])-int(r['Start_Timestamp']) for r in step)
+print(f"last step: wall {(en-st)/1e6:.1f} ms, kernel busy {busy/1e6:.1f} ms, n kernels {len(step)}")
+agg=collections.defaultdict(lambda:[0,0])
+def cat(n):
+    if 'msda' in n: return n[n.index('msda'):][:40]
+    if n.startswith('Cijk') : return 'GEMM (hipBLASLt Cijk)'
+    if 'conv' in n.lower() or 'igemm' in n.lower() or 'gemm_xdl' in n or 'ck::' in n: return 'conv/ck: '+n[:50]
+    return n[:95]
+for r in step:
+    key=cat(r['Kernel_Name'])
+    agg[key][0]+=int(r['End_Timestamp'])-int(r['Start_Timestamp']); agg[key][1]+=1
+N=int(sys.argv[2]) if len(sys.argv)>2 else 40
+for k,(t,c) in sorted(agg.items(), key=lambda kv:-kv[1][0])[:N]:
+    print(f"{t/1e6:8.2f} ms {c:5d}  {k}")

@@ -1,0 +1,71 @@
+"""The C-ABI library loads (no GPU needed: hipcc cross-compiles, libamdhip64 is in the image)
+and exports every symbol include/dskd_hip.h declares; host-only entry points work."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from dskd_amd import native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "dskd_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dskd_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    assert _declared_symbols() == sorted(native.EXPORTED_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(native.lib_path())
+    for sym in _declared_symbols():
+        assert hasattr(lib, sym), sym
+    assert native.load().dskd_abi_version() == 1
+
+
+def test_cpu_tensors_fail_loudly_without_checker():
+    """The product path has no CPU fallback."""
+    native.install_cpu_checker(None)
+    v = torch.randn(1, 6, 8, 32)
+    loc = torch.rand(1, 2, 8, 1, 4, 2)
+    attn = torch.rand(1, 2, 8, 1, 4)
+    with pytest.raises(native.NativeError, match="no CPU fallback"):
+        native.ms_deform_attn(v, [(2, 3)], loc, attn)
+    with pytest.raises(native.NativeError):
+        native.msda_forward_raw(v, [(2, 3)], loc, attn)
+    with pytest.raises(native.NativeError):
+        native.proto_corr_loss(torch.randn(4, 8), torch.zeros(4, dtype=torch.long), torch.ones(3, dtype=torch.bool),
+                               torch.randn(4, 8), torch.zeros(1, dtype=torch.long), torch.zeros(1, dtype=torch.long), 2)
+
+
+def test_argument_validation_returns_error_codes():
+    lib = native.load()
+    # unsupported head geometry -> DSKD_ERR_INVALID_ARG with a message, no launch attempted
+    ss = (ctypes.c_int64 * 2)(2, 3)
+    ls = (ctypes.c_int64 * 1)(0)
+    rc = lib.dskd_msda_fwd(1, ss, ls, 1, 1, 1, 1, 6, 2, 4, 64, 1, 4, 0, None)
+    assert rc == -1 and b"heads=8" in lib.dskd_last_error()
+    rc = lib.dskd_lsap_batched(None, None, None, None, -1, None, None, None, None, None)
+    assert rc == -1
+
+
+def test_lsap_host_entry_matches_scipy():
+    from scipy.optimize import linear_sum_assignment as sp
+    rng = np.random.default_rng(3)
+    for shape in [(300, 17), (5, 9), (9, 5), (1, 1), (40, 40)]:
+        for integer in (False, True):
+            c = (rng.integers(0, 4, shape) if integer else rng.random(shape)).astype(np.float32)
+            r, cc = native.lsap_host(torch.from_numpy(c))
+            a = sp(c)
+            assert np.array_equal(r.numpy(), a[0]) and np.array_equal(cc.numpy(), a[1])
+    with pytest.raises(ValueError, match="invalid numeric"):
+        native.lsap_host(torch.tensor([[1.0, float("nan")]]))
+    with pytest.raises(ValueError, match="infeasible"):
+        native.lsap_host(torch.tensor([[float("inf"), float("inf")], [1.0, 2.0]]))

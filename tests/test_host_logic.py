@@ -1,0 +1,185 @@
+"""Host-side mirror of the reference's plugin surface: registry, config loading (the
+reference's own config files when /root/reference is present), detector state handling,
+optimizer grouping, LR schedule, the runner, and BASELINE config #1 (CPU plumbing)."""
+import copy
+import os
+
+import pytest
+import torch
+
+import dskd_amd
+from dskd_amd import builder
+from dskd_amd.config import Config
+from dskd_amd.datasets import SyntheticILDataset, build_dataloader
+from dskd_amd.runner import StepLrWarmup, TaskEpochBasedRunner, build_optimizer
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OWN_CFG = os.path.join(ROOT, "configs", "dskd_gfl_deformable_detr_r50_70_10.py")
+REF_CFG = "/root/reference/configs/deformable_detr/chaosuan_gfl_deformable_detr_40_r50_8x4_1x_qoqo_il.py"
+
+
+def test_registry_names_of_the_reference_resolve():
+    for reg, names in [(builder.DETECTORS, ["DeformableDETR_il"]), (builder.HEADS, ["GFLDeformableDETRHead_il"]),
+                       (builder.BBOX_ASSIGNERS, ["GFLHungarianAssigner"]), (builder.BBOX_SAMPLERS, ["PseudoSampler"]),
+                       (builder.MATCH_COST, ["QualityFocalLossCost", "BBoxL1Cost", "IoUCost"]),
+                       (builder.LOSSES, ["QualityFocalLoss", "DistributionFocalLoss", "L1Loss", "GIoULoss",
+                                         "KnowledgeDistillationKLDivLoss", "SmoothL1Loss", "MSELoss"]),
+                       (builder.BACKBONES, ["ResNet"]), (builder.NECKS, ["ChannelMapper"]),
+                       (builder.TRANSFORMER, ["DeformableDetrTransformer"]),
+                       (builder.TRANSFORMER_LAYER_SEQUENCE, ["DetrTransformerEncoder", "DeformableDetrTransformerDecoder"]),
+                       (builder.TRANSFORMER_LAYER, ["BaseTransformerLayer", "DetrTransformerDecoderLayer"]),
+                       (builder.ATTENTION, ["MultiScaleDeformableAttention", "MultiheadAttention"]),
+                       (builder.POSITIONAL_ENCODING, ["SinePositionalEncoding"])]:
+        for n in names:
+            assert reg.get(n) is not None, n
+    with pytest.raises(KeyError):
+        builder.build_loss(dict(type="NoSuchLoss"))
+    with pytest.raises(KeyError):
+        builder.DETECTORS.register_module()(builder.DETECTORS.get("DeformableDETR_il"))
+
+
+def test_own_config_loads_and_builds():
+    cfg = Config.fromfile(OWN_CFG)
+    assert cfg.model.type == "DeformableDETR_il" and cfg.data.train.catsplit == (70, 10)
+    assert isinstance(cfg.optimizer, list) and len(cfg.runner) == 2
+    cfg.merge_from_dict({"data.samples_per_gpu": 2, "model.bbox_head.num_query": 50})
+    assert cfg.data.samples_per_gpu == 2 and cfg.model.bbox_head.num_query == 50
+
+
+@pytest.mark.skipif(not os.path.isfile(REF_CFG), reason="reference checkout not present (GPU box)")
+def test_reference_config_files_load_unchanged():
+    import glob
+    files = sorted(glob.glob("/root/reference/configs/deformable_detr/*_il*.py"))
+    assert len(files) >= 8
+    for f in files:
+        cfg = Config.fromfile(f)          # _base_ chain (dataset + runtime) included
+        assert "model" in cfg and "data" in cfg, f
+    cfg = Config.fromfile(REF_CFG)
+    assert cfg.model.bbox_head.feats_distill == "corr + fg_info + decode_v1"
+    assert cfg.model.bbox_head.cates_distill == "hard + teacher-first"
+    assert cfg.dist_params["backend"] == "nccl" and cfg.checkpoint_config["interval"] == 1
+    cfg.model.backbone.init_cfg = None
+    model = builder.build_detector(cfg.model)
+    assert sum(p.numel() for p in model.parameters()) == 40156376
+
+
+def _tiny_model(num_query=20):
+    cfg = Config.fromfile(OWN_CFG)
+    cfg.model.bbox_head.num_query = num_query
+    torch.manual_seed(0)
+    m = builder.build_detector(cfg.model)
+    m.init_weights()
+    return cfg, m
+
+
+def test_head_ctor_checks_loss_and_matcher_weights():
+    cfg = Config.fromfile(OWN_CFG)
+    bad = copy.deepcopy(cfg.model)
+    bad.bbox_head.loss_bbox = dict(type="L1Loss", loss_weight=4.0)
+    with pytest.raises(AssertionError, match="regression L1 weight"):
+        builder.build_detector(bad)
+    bad = copy.deepcopy(cfg.model)
+    bad.bbox_head.positional_encoding = dict(type="SinePositionalEncoding", num_feats=64, normalize=True)
+    with pytest.raises(AssertionError, match="embed_dims"):
+        builder.build_detector(bad)
+
+
+def test_teacher_is_a_plain_attribute():
+    """deformable_detr_il.py:79-114, :467-496: teacher frozen, eval, not registered, not saved."""
+    cfg, m = _tiny_model()
+    n_params = sum(1 for _ in m.parameters())
+    keys = set(m.state_dict().keys())
+    t = copy.deepcopy(m)
+    assert m.set_teacher(config=None, ckptfile=None, model=None) is None and not m.has_teacher
+    m.set_teacher(model=t)
+    assert m.has_teacher and m.bbox_head.has_teacher and not t.has_teacher and not t.bbox_head.has_teacher
+    assert sum(1 for _ in m.parameters()) == n_params and set(m.state_dict().keys()) == keys
+    assert all(not p.requires_grad for p in t.parameters())
+    m.train()
+    assert m.training and not t.training                       # eval_teacher
+    # a second hand-over drops the nested teacher
+    m2 = copy.deepcopy(m)
+    m.set_teacher(model=m2)
+    assert getattr(m.teacher_model, "teacher_model", None) is None
+    m.set_datainfo(cat2id={"a": 1, "b": 2, "c": 3}, cat2label={1: 0, 2: 1, 3: 2}, pred_cat=["a", "b"], load_cat=["b"],
+                   task_cat=[["a"], ["b"], ["c"]])
+    assert m.LableInPCNTask == {"prev": [0], "curr": [1], "next": [2]}
+    # unused-in-forward parameter exists (reason for find_unused_parameters=True)
+    assert "bbox_head.prototype.weight" in keys
+    # frozen stem / stage 1 and every BN
+    assert not m.backbone.conv1.weight.requires_grad and not m.backbone.layer1[0].conv1.weight.requires_grad
+    assert m.backbone.layer2[0].conv1.weight.requires_grad and not m.backbone.layer2[0].bn1.weight.requires_grad
+    assert not m.backbone.layer2[0].bn1.training
+
+
+def test_optimizer_param_groups_follow_custom_keys():
+    cfg, m = _tiny_model()
+    opt = build_optimizer(m, cfg.optimizer[0])
+    lrs = sorted({g["lr"] for g in opt.param_groups})
+    assert lrs == [pytest.approx(2e-5), pytest.approx(2e-4)]
+    small = next(g for g in opt.param_groups if g["lr"] < 1e-4)
+    ids = {id(p) for p in small["params"]}
+    for n, p in m.named_parameters():
+        if p.requires_grad:
+            expect_small = ("backbone" in n) or ("sampling_offsets" in n) or ("reference_points" in n)
+            assert (id(p) in ids) == expect_small, n
+    assert all(p.requires_grad for g in opt.param_groups for p in g["params"])
+
+
+def test_step_lr_with_linear_warmup():
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=1.0)
+    sch = StepLrWarmup(opt, step=[8, 11], warmup="linear", warmup_iters=10, warmup_ratio=0.01)
+    sch.set(0, 0)
+    assert opt.param_groups[0]["lr"] == pytest.approx(0.01)
+    sch.set(0, 5)
+    assert opt.param_groups[0]["lr"] == pytest.approx(1 - 0.5 * 0.99)
+    sch.set(0, 10)
+    assert opt.param_groups[0]["lr"] == pytest.approx(1.0)
+    sch.set(8, 100)
+    assert opt.param_groups[0]["lr"] == pytest.approx(0.1)
+    sch.set(11, 100)
+    assert opt.param_groups[0]["lr"] == pytest.approx(0.01)
+
+
+def test_synthetic_il_dataset_surface():
+    ds = SyntheticILDataset(catsplit=(40, 40), catload=(0, 1), num_images=5, img_size=(64, 96), n_gt=3)
+    assert len(ds.TASK_CLASSES) == 2 and len(ds.LOAD_CLASSES) == 40 and len(ds.PRED_CLASSES) == 80
+    assert ds.cat2label[ds.ALL_CLASSES_IDS[ds.LOAD_CLASSES[0]]] == 40
+    item = ds[3]
+    assert item["img"].shape == (3, 64, 96) and item["gt_bboxes"].shape == (3, 4)
+    assert int(item["gt_labels"].min()) >= 40
+    assert torch.equal(ds[3]["img"], item["img"])                # deterministic per index
+    b = item["gt_bboxes"]
+    assert (b[:, 2] > b[:, 0]).all() and (b[:, 3] > b[:, 1]).all() and b[:, 2].max() <= 96 and b[:, 3].max() <= 64
+    loader = build_dataloader(ds, 2, 0, seed=1)
+    batch = next(iter(loader))
+    assert batch["img"].shape == (2, 3, 64, 96) and len(batch["img_metas"]) == 2
+
+
+def test_incremental_training_plumbing_cpu(cpu_ops, tmp_path):
+    """BASELINE.json configs[0]: two tasks on CPU through the driver, synthetic tensors; the
+    second task distils from the frozen copy of the first; checkpoints hold the student only."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("train_increment", os.path.join(ROOT, "tools", "train_increment.py"))
+    ti = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ti)
+    cfg_file = REF_CFG if os.path.isfile(REF_CFG) else OWN_CFG
+    runners = ti.main([cfg_file, "--device", "cpu", "--max-iters", "2", "--max-epochs", "1", "--work-dir", str(tmp_path),
+                       "--cfg-options", "data.samples_per_gpu=1", "data.workers_per_gpu=0", "data.train.num_images=2",
+                       "data.train.img_size=(64,96)", "data.train.n_gt=2", "model.bbox_head.num_query=30"])
+    assert len(runners) == 2
+    keys1, keys2 = set(runners[0].history[-1]), set(runners[1].history[-1])
+    det = {"loss_cls", "loss_bbox", "loss_iou", "loss_dfl"} | {f"d{i}.{k}" for i in range(5)
+                                                             for k in ("loss_cls", "loss_bbox", "loss_iou", "loss_dfl")}
+    assert det | {"loss"} <= keys1 and "loss_corr" not in keys1
+    assert det | {"loss", "loss_corr", "loss_fg_feature"} <= keys2
+    for r in runners:
+        assert all(torch.isfinite(torch.tensor(h["loss"])) for h in r.history)
+    ck = torch.load(os.path.join(str(tmp_path), "task_2_epoch_1.pth"), map_location="cpu")
+    assert not any(k.startswith("teacher") for k in ck["state_dict"])
+    assert ck["meta"] == dict(task=2, epoch=1, iter=2)
+    # resume restores epoch / iter
+    model = runners[1].module
+    r2 = TaskEpochBasedRunner(model, runners[1].optimizer, max_epochs=1)
+    assert r2.resume(os.path.join(str(tmp_path), "task_2_epoch_1.pth")) == dict(task=2, epoch=1, iter=2)
