@@ -119,8 +119,14 @@ def cpu_baseline(seed, num_prev):
     from oracle.checker import OracleChecker
     native.install_cpu_checker(OracleChecker())
     try:
-        cores = os.cpu_count() or 1
+        # the GPU box gives one GPU a 16-core CPU share; os.cpu_count() reports the whole host
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        cores = max(1, min(avail, 16))
         torch.set_num_threads(cores)
+        print(f"[bench] cpu_baseline: 1 step, B=1, {cores} threads ...", file=sys.stderr, flush=True)
         cfg, model = build_models(torch.device("cpu"), seed, dropout=None)
         opt = build_optimizer(model, cfg.optimizer[0])
         data, synth = make_batch(1, num_prev, seed, torch.device("cpu"))
