@@ -733,7 +733,16 @@ int check_shapes(const char* who, int B, int Nv, int Nq, int heads, int ch, int 
   return DSKD_OK;
 }
 
-constexpr int kQPB = 32;  // queries per workgroup (8 per wave)
+constexpr int kQPB = 32;  // queries per workgroup (8 per wave) when the grid is large
+
+// Few queries (decoder cross-attention: 300 per image) would leave most CUs idle at 32 queries
+// per workgroup; shrink the workgroup's share down to one wave pass so the grid covers the chip.
+inline int pick_qpb(int B, int Nq, int dtype) {
+  const int min_qpb = kWaves * (dtype == DSKD_DTYPE_BF16 ? 2 : 1);
+  int qpb = kQPB;
+  while (qpb > min_qpb && (long long)B * ((Nq + qpb - 1) / qpb) < 1024) qpb >>= 1;
+  return qpb < min_qpb ? min_qpb : qpb;
+}
 
 }  // namespace
 }  // namespace dskd
@@ -751,15 +760,16 @@ extern "C" int dskd_msda_fwd(const void* value, const int64_t* spatial_shapes,
   if (B == 0 || Nq == 0) return DSKD_OK;
   LevelGeom g;
   if (int rc = fill_geom(spatial_shapes, level_start, levels, Nv, &g)) return rc;
-  const int bpi = (Nq + kQPB - 1) / kQPB;
+  const int qpb = pick_qpb(B, Nq, dtype);
+  const int bpi = (Nq + qpb - 1) / qpb;
   const dim3 grid((unsigned)(B * bpi)), block(kWaves * 64);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DSKD_DTYPE_F32)
     hipLaunchKernelGGL(msda_fwd_kernel<float>, grid, block, 0, st, (const float*)value, loc,
-                       attn, (float*)out, g, Nv, Nq, levels * points, points, kQPB, bpi);
+                       attn, (float*)out, g, Nv, Nq, levels * points, points, qpb, bpi);
   else
     hipLaunchKernelGGL(msda_fwd_kernel<__bf16>, grid, block, 0, st, (const __bf16*)value, loc,
-                       attn, (__bf16*)out, g, Nv, Nq, levels * points, points, kQPB, bpi);
+                       attn, (__bf16*)out, g, Nv, Nq, levels * points, points, qpb, bpi);
   return check_launch("dskd_msda_fwd");
 }
 
@@ -776,7 +786,8 @@ extern "C" int dskd_msda_bwd(const void* value, const int64_t* spatial_shapes,
   if (B == 0 || Nq == 0) return DSKD_OK;
   LevelGeom g;
   if (int rc = fill_geom(spatial_shapes, level_start, levels, Nv, &g)) return rc;
-  const int bpi = (Nq + kQPB - 1) / kQPB;
+  const int qpb = pick_qpb(B, Nq, dtype);
+  const int bpi = (Nq + qpb - 1) / qpb;
   const dim3 grid((unsigned)(B * bpi)), block(kWaves * 64);
   hipStream_t st = (hipStream_t)stream;
   const int LP = levels * points;
@@ -795,7 +806,7 @@ extern "C" int dskd_msda_bwd(const void* value, const int64_t* spatial_shapes,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
       if (attr != hipSuccess) return fail(DSKD_ERR_LAUNCH, "dskd_msda_bwd: cannot reserve LDS");
       hipLaunchKernelGGL((msda_bwd_kernel<float, false>), grid, block, 0, st, (const float*)value, loc, attn,
-                         (const float*)grad_out, grad_value, grad_loc, grad_attn, g, Nv, Nq, LP, points, kQPB,
+                         (const float*)grad_out, grad_value, grad_loc, grad_attn, g, Nv, Nq, LP, points, qpb,
                          bpi);
       hipLaunchKernelGGL(msda_bwd_value_kernel<float>, vgrid, vblock, lds, st, loc, attn,
                          (const float*)grad_out, grad_value, vg, Nq, LP, points);
@@ -805,7 +816,7 @@ extern "C" int dskd_msda_bwd(const void* value, const int64_t* spatial_shapes,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
       if (attr != hipSuccess) return fail(DSKD_ERR_LAUNCH, "dskd_msda_bwd: cannot reserve LDS");
       hipLaunchKernelGGL((msda_bwd_kernel<__bf16, false>), grid, block, 0, st, (const __bf16*)value, loc, attn,
-                         (const __bf16*)grad_out, grad_value, grad_loc, grad_attn, g, Nv, Nq, LP, points, kQPB,
+                         (const __bf16*)grad_out, grad_value, grad_loc, grad_attn, g, Nv, Nq, LP, points, qpb,
                          bpi);
       hipLaunchKernelGGL(msda_bwd_value_kernel<__bf16>, vgrid, vblock, lds, st, loc, attn,
                          (const __bf16*)grad_out, grad_value, vg, Nq, LP, points);
@@ -815,10 +826,10 @@ extern "C" int dskd_msda_bwd(const void* value, const int64_t* spatial_shapes,
   if (dtype == DSKD_DTYPE_F32)
     hipLaunchKernelGGL((msda_bwd_kernel<float, true>), grid, block, 0, st, (const float*)value, loc,
                        attn, (const float*)grad_out, grad_value, grad_loc, grad_attn, g, Nv,
-                       Nq, LP, points, kQPB, bpi);
+                       Nq, LP, points, qpb, bpi);
   else
     hipLaunchKernelGGL((msda_bwd_kernel<__bf16, true>), grid, block, 0, st, (const __bf16*)value, loc,
                        attn, (const __bf16*)grad_out, grad_value, grad_loc, grad_attn, g, Nv,
-                       Nq, LP, points, kQPB, bpi);
+                       Nq, LP, points, qpb, bpi);
   return check_launch("dskd_msda_bwd");
 }

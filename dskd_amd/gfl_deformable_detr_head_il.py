@@ -30,7 +30,7 @@ from . import native
 from .bbox import bbox_cxcywh_to_xyxy, bbox_overlaps, bbox_xyxy_to_cxcywh
 from .builder import HEADS, build_assigner, build_loss, build_positional_encoding, build_sampler, build_transformer
 from .dist import reduce_mean
-from .transformer import inverse_sigmoid
+from .transformer import Linear, inverse_sigmoid
 
 
 def multi_apply(func, *args, **kwargs):
@@ -144,11 +144,11 @@ class GFLDeformableDETRHead_il(nn.Module):
 
     def _init_layers(self):
         """:145-178 -- cls / reg branches are SHARED across decoder layers (no box refine)."""
-        fc_cls = nn.Linear(self.embed_dims, self.cls_out_channels)
+        fc_cls = Linear(self.embed_dims, self.cls_out_channels)
         reg_branch = []
         for _ in range(self.num_reg_fcs):
-            reg_branch += [nn.Linear(self.embed_dims, self.embed_dims), nn.ReLU()]
-        reg_branch.append(nn.Linear(self.embed_dims, 2 + 4 * (self.reg_max + 1)))
+            reg_branch += [Linear(self.embed_dims, self.embed_dims), nn.ReLU()]
+        reg_branch.append(Linear(self.embed_dims, 2 + 4 * (self.reg_max + 1)))
         reg_branch = nn.Sequential(*reg_branch)
         num_pred = self.transformer.decoder.num_layers
         self.cls_branches = nn.ModuleList([fc_cls for _ in range(num_pred)])
@@ -251,25 +251,41 @@ class GFLDeformableDETRHead_il(nn.Module):
         return (labels.view(nl, B * Q), bbox_targets.view(nl, B * Q, 4), pos.view(nl, B * Q), num_total_pos)
 
     # ------------------------------------------------------------------ losses
-    def loss_single_dense(self, cls_scores, bbox_cxcywh, bbox_lrtb, labels, bbox_targets, pos, factors, avg_pos):
-        """One decoder layer, all images: the arithmetic of ``loss_single_split`` :1453-1529 on
-        precomputed dense targets.  cls_scores [N,C], bbox_cxcywh [N,4], bbox_lrtb [N,4*(reg_max+1)],
-        labels [N], bbox_targets [N,4], pos [N] bool, factors [N,4]; avg_pos = clamp(mean
-        num_total_pos, 1) (python float or 0-dim tensor)."""
+    def loss_layers_dense(self, cls_scores, bbox_cxcywh, bbox_lrtb, labels, bbox_targets, pos, factors, avg_pos):
+        """All decoder layers x all images at once: the arithmetic of ``loss_single_split``
+        :1453-1529 on precomputed dense targets, with the per-layer reductions done as one
+        ``sum(dim=1)`` (the reference loops over layers with ``multi_apply``; same per-layer
+        values, one sixth of the launches).  Shapes: cls_scores [nl,N,C], bbox_cxcywh [nl,N,4],
+        bbox_lrtb [nl,N,4*(reg_max+1)], labels [nl,N], bbox_targets [nl,N,4], pos [nl,N] bool,
+        factors [N,4]; avg_pos = clamp(mean num_total_pos, 1) (python float or 0-dim tensor).
+        Returns four tensors of shape [nl]."""
+        nl, N, C = cls_scores.shape
         posf = pos.to(bbox_cxcywh.dtype)
-        bbox_weights = posf[:, None].expand(-1, 4)
-        # IoU quality of the positives (:1459-1466); gradient flows into the boxes as in the
+        bbox_weights = posf[..., None].expand(-1, -1, 4)
+        # IoU quality of the positives (:1459-1466); the gradient flows into the boxes as in the
         # reference (index_put of a graph tensor into `score`).
         iou = bbox_overlaps(bbox_cxcywh_to_xyxy(bbox_cxcywh), bbox_cxcywh_to_xyxy(bbox_targets), is_aligned=True)
         score = torch.where(pos, iou, torch.zeros_like(iou))
-        loss_cls = self.loss_cls(cls_scores, (labels, score), None, avg_factor=avg_pos)
+        eps = torch.finfo(torch.float32).eps
+
+        def per_layer(elem, weight, avg):          # weight_reduce_loss('mean', avg_factor) per layer
+            if weight is not None:
+                elem = elem * weight
+            return elem.reshape(nl, -1).sum(1) / (avg + eps)
+
+        qfl = self.loss_cls(cls_scores.reshape(nl * N, C), (labels.reshape(-1), score.reshape(-1)), None,
+                            reduction_override="none").reshape(nl, N)
+        loss_cls = per_layer(qfl, None, avg_pos)
         bboxes = bbox_cxcywh_to_xyxy(bbox_cxcywh) * factors
         bboxes_gt = bbox_cxcywh_to_xyxy(bbox_targets) * factors
-        loss_iou = self.loss_iou(bboxes, bboxes_gt, bbox_weights, avg_factor=avg_pos)
-        loss_bbox = self.loss_bbox(bbox_cxcywh, bbox_targets, bbox_weights, avg_factor=avg_pos)
+        giou = self.loss_iou(bboxes.reshape(-1, 4), bboxes_gt.reshape(-1, 4), None, reduction_override="none")
+        loss_iou = per_layer(giou.reshape(nl, N), bbox_weights.mean(-1), avg_pos)
+        l1 = self.loss_bbox(bbox_cxcywh, bbox_targets, None, reduction_override="none")
+        loss_bbox = per_layer(l1, bbox_weights, avg_pos)
         pred_corners = bbox_lrtb.reshape(-1, self.reg_max + 1)
-        target_corners = bbox_targets[:, 2:].unsqueeze(2).repeat(1, 1, 2).reshape(-1) / 2
-        loss_dfl = self.loss_dfl(pred_corners, target_corners, weight=bbox_weights.reshape(-1), avg_factor=avg_pos * 4)
+        target_corners = bbox_targets[..., 2:].unsqueeze(-1).repeat(1, 1, 1, 2).reshape(-1) / 2
+        dfl = self.loss_dfl(pred_corners, target_corners, None, reduction_override="none")
+        loss_dfl = per_layer(dfl.reshape(nl, N, 4), bbox_weights, avg_pos * 4)
         return loss_cls, loss_bbox, loss_iou, loss_dfl
 
     def loss(self, all_cls_scores, all_bbox_preds, info_all, hs, gt_bboxes_list, gt_labels_list, img_metas,
@@ -307,15 +323,9 @@ class GFLDeformableDETRHead_il(nn.Module):
         factors = torch.cat([all_bbox_preds.new_tensor([m["img_shape"][1], m["img_shape"][0], m["img_shape"][1],
                                                         m["img_shape"][0]]).unsqueeze(0).repeat(Q, 1)
                              for m in img_metas], 0)
-        losses_cls, losses_bbox, losses_iou, losses_dfl = [], [], [], []
-        for l in range(nl):
-            lc, lb, li, ld = self.loss_single_dense(
-                all_cls_scores[l].reshape(-1, self.cls_out_channels), bbox_cxcywh[l].reshape(-1, 4),
-                bbox_lrtb[l].reshape(B * Q, -1), labels[l], bbox_targets[l], pos[l], factors, avg_pos)
-            losses_cls.append(lc)
-            losses_bbox.append(lb)
-            losses_iou.append(li)
-            losses_dfl.append(ld)
+        losses_cls, losses_bbox, losses_iou, losses_dfl = self.loss_layers_dense(
+            all_cls_scores.reshape(nl, B * Q, self.cls_out_channels), bbox_cxcywh.reshape(nl, B * Q, 4),
+            bbox_lrtb.reshape(nl, B * Q, -1), labels, bbox_targets, pos, factors, avg_pos)
 
         loss_dict = dict()
         prev_mask = None

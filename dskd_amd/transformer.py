@@ -26,6 +26,26 @@ from .builder import (ATTENTION, FEEDFORWARD_NETWORK, POSITIONAL_ENCODING, TRANS
                       build_transformer_layer, build_transformer_layer_sequence)
 
 
+class Linear(nn.Linear):
+    """nn.Linear that keeps a low-precision copy of FROZEN parameters under autocast.
+    torch.autocast caches weight casts only for leaf tensors that require grad, so the frozen
+    teacher (and any frozen student layer) would re-cast every weight on every call; trainable
+    parameters take the stock path (autocast's own per-step cache)."""
+
+    def forward(self, x):
+        dev = x.device.type
+        if torch.is_autocast_enabled(dev) and not self.weight.requires_grad and \
+                (self.bias is None or not self.bias.requires_grad):
+            dtype = torch.get_autocast_dtype(dev)
+            key = (self.weight._version, -1 if self.bias is None else self.bias._version, dtype, self.weight.device)
+            cache = self.__dict__.get("_lp")
+            if cache is None or cache[0] != key:
+                cache = (key, self.weight.detach().to(dtype), None if self.bias is None else self.bias.detach().to(dtype))
+                self.__dict__["_lp"] = cache
+            return F.linear(x, cache[1], cache[2])
+        return super().forward(x)
+
+
 def inverse_sigmoid(x, eps=1e-5):
     """transformer.py:388-404."""
     x = x.clamp(min=0, max=1)
@@ -79,10 +99,10 @@ class MultiScaleDeformableAttention(nn.Module):
         self.batch_first = batch_first
         self.im2col_step = im2col_step
         self.embed_dims, self.num_levels, self.num_heads, self.num_points = embed_dims, num_levels, num_heads, num_points
-        self.sampling_offsets = nn.Linear(embed_dims, num_heads * num_levels * num_points * 2)
-        self.attention_weights = nn.Linear(embed_dims, num_heads * num_levels * num_points)
-        self.value_proj = nn.Linear(embed_dims, embed_dims)
-        self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self.sampling_offsets = Linear(embed_dims, num_heads * num_levels * num_points * 2)
+        self.attention_weights = Linear(embed_dims, num_heads * num_levels * num_points)
+        self.value_proj = Linear(embed_dims, embed_dims)
+        self.output_proj = Linear(embed_dims, embed_dims)
         self.init_weights()
 
     def init_weights(self):
@@ -130,10 +150,28 @@ class MultiScaleDeformableAttention(nn.Module):
         if key_padding_mask is not None:
             value = value.masked_fill(key_padding_mask[..., None], 0.0)
         value = value.view(bs, num_value, self.num_heads, -1)
-        sampling_offsets = self.sampling_offsets(query).view(
-            bs, num_query, self.num_heads, self.num_levels, self.num_points, 2).float()
-        attention_weights = self.attention_weights(query).view(
-            bs, num_query, self.num_heads, self.num_levels * self.num_points).float()
+        # sampling offsets and attention logits: one GEMM on the concatenated weights (the query
+        # is read and cast once instead of twice); parameters keep their own names.
+        n_off = self.sampling_offsets.out_features
+        so, aw = self.sampling_offsets, self.attention_weights
+        frozen = not (so.weight.requires_grad or aw.weight.requires_grad or so.bias.requires_grad or aw.bias.requires_grad)
+        dev = query.device.type
+        if frozen:      # teacher: concatenate (and cast, under autocast) once
+            dtype = torch.get_autocast_dtype(dev) if torch.is_autocast_enabled(dev) else so.weight.dtype
+            key = (so.weight._version, aw.weight._version, so.bias._version, aw.bias._version, dtype, so.weight.device)
+            if getattr(self, "_cat_key", None) != key:
+                self._cat_key = key
+                self._cat = (torch.cat([so.weight, aw.weight], 0).detach().to(dtype),
+                             torch.cat([so.bias, aw.bias], 0).detach().to(dtype))
+            w_cat, b_cat = self._cat
+        else:
+            w_cat = torch.cat([so.weight, aw.weight], 0)
+            b_cat = torch.cat([so.bias, aw.bias], 0)
+        both = F.linear(query, w_cat, b_cat)
+        sampling_offsets = both[..., :n_off].float().view(
+            bs, num_query, self.num_heads, self.num_levels, self.num_points, 2)
+        attention_weights = both[..., n_off:].float().view(
+            bs, num_query, self.num_heads, self.num_levels * self.num_points)
         attention_weights = attention_weights.softmax(-1).view(
             bs, num_query, self.num_heads, self.num_levels, self.num_points)
         if reference_points.shape[-1] == 2:
@@ -208,9 +246,9 @@ class FFN(nn.Module):
         act = {"ReLU": lambda: nn.ReLU(inplace=True), "GELU": nn.GELU}[act_cfg.get("type", "ReLU")]
         layers, cin = [], embed_dims
         for _ in range(num_fcs - 1):
-            layers.append(nn.Sequential(nn.Linear(cin, feedforward_channels), act(), nn.Dropout(ffn_drop)))
+            layers.append(nn.Sequential(Linear(cin, feedforward_channels), act(), nn.Dropout(ffn_drop)))
             cin = feedforward_channels
-        layers += [nn.Linear(feedforward_channels, embed_dims), nn.Dropout(ffn_drop)]
+        layers += [Linear(feedforward_channels, embed_dims), nn.Dropout(ffn_drop)]
         self.layers = nn.Sequential(*layers)
         self.dropout_layer = nn.Dropout(dropout_layer["drop_prob"]) if dropout_layer else nn.Identity()
         self.add_identity = add_identity
@@ -403,7 +441,7 @@ class DeformableDetrTransformer(nn.Module):
         self.num_feature_levels = num_feature_levels
         self.two_stage_num_proposals = two_stage_num_proposals
         self.level_embeds = nn.Parameter(torch.zeros(self.num_feature_levels, self.embed_dims))
-        self.reference_points = nn.Linear(self.embed_dims, 2)
+        self.reference_points = Linear(self.embed_dims, 2)
 
     def init_weights(self):
         for p in self.parameters():
