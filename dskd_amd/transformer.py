@@ -26,6 +26,59 @@ from .builder import (ATTENTION, FEEDFORWARD_NETWORK, POSITIONAL_ENCODING, TRANS
                       build_transformer_layer, build_transformer_layer_sequence)
 
 
+_CHUNK_CACHE = {}
+
+
+def _token_chunk(T, out_elems=65536, lo=256, hi=4096):
+    """Largest divisor of T in [lo, hi] that still leaves enough chunks to fill the chip
+    (measured on MI355X: 256x256 outputs want >= 128 batches, 1024x256 ones >= 64)."""
+    min_batches = 128 if out_elems <= 131072 else 64
+    key = (T, min_batches)
+    if key not in _CHUNK_CACHE:
+        best = None
+        for c in range(lo, min(hi, T) + 1):
+            if T % c == 0 and T // c >= min_batches:
+                best = c
+        if best is None:                      # fewer, larger chunks are still better than one GEMM
+            for c in range(lo, min(hi, T) + 1):
+                if T % c == 0 and T // c >= 16:
+                    best = c
+        _CHUNK_CACHE[key] = best
+    return _CHUNK_CACHE[key]
+
+
+class _TallLinearFn(torch.autograd.Function):
+    """y = x W^T + b for a very tall x (tens of thousands of tokens, 256..1024 features).
+    Forward and dX are ordinary GEMMs.  dW = dY^T X has a tiny output (<= 1024 x 256) and a
+    huge reduction dimension (88 892 tokens at B=4): as one GEMM it runs on a handful of
+    workgroups (hipBLASLt: ~55 TFLOP/s measured).  Here the token axis is cut into chunks that
+    become the batch dimension of one bmm (hundreds of workgroups), followed by an fp32 sum of
+    the partial products -- a split-K GEMM expressed through the library."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, chunk):
+        ctx.chunk = chunk
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1])
+        x2 = x.reshape(-1, x.shape[-1])
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = (g2 @ weight).view(x.shape)
+        if ctx.needs_input_grad[1]:
+            nb = x2.shape[0] // ctx.chunk
+            part = torch.bmm(g2.view(nb, ctx.chunk, -1).transpose(1, 2), x2.view(nb, ctx.chunk, -1))
+            gw = part.float().sum(0).to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g2.float().sum(0).to(g.dtype)
+        return gx, gw, gb, None
+
+
 class Linear(nn.Linear):
     """nn.Linear that keeps a low-precision copy of FROZEN parameters under autocast.
     torch.autocast caches weight casts only for leaf tensors that require grad, so the frozen
@@ -43,7 +96,24 @@ class Linear(nn.Linear):
                 cache = (key, self.weight.detach().to(dtype), None if self.bias is None else self.bias.detach().to(dtype))
                 self.__dict__["_lp"] = cache
             return F.linear(x, cache[1], cache[2])
-        return super().forward(x)
+        return tall_linear(x, self.weight, self.bias)
+
+
+def tall_linear(x, weight, bias):
+    """F.linear, switching to the split-K weight gradient for very tall inputs."""
+    dev = x.device.type
+    tokens = x.numel() // max(x.shape[-1], 1)
+    if tokens >= 16384 and weight.requires_grad and torch.is_grad_enabled() and x.is_contiguous():
+        chunk = _token_chunk(tokens, weight.numel())
+        if chunk is not None:
+            if torch.is_autocast_enabled(dev):       # what autocast would do for F.linear
+                dtype = torch.get_autocast_dtype(dev)
+                x, weight = x.to(dtype), weight.to(dtype)
+                bias = None if bias is None else bias.to(dtype)
+                with torch.autocast(dev, enabled=False):
+                    return _TallLinearFn.apply(x, weight, bias, chunk)
+            return _TallLinearFn.apply(x, weight, bias, chunk)
+    return F.linear(x, weight, bias)
 
 
 def inverse_sigmoid(x, eps=1e-5):
@@ -167,7 +237,7 @@ class MultiScaleDeformableAttention(nn.Module):
         else:
             w_cat = torch.cat([so.weight, aw.weight], 0)
             b_cat = torch.cat([so.bias, aw.bias], 0)
-        both = F.linear(query, w_cat, b_cat)
+        both = tall_linear(query, w_cat, b_cat)
         sampling_offsets = both[..., :n_off].float().view(
             bs, num_query, self.num_heads, self.num_levels, self.num_points, 2)
         attention_weights = both[..., n_off:].float().view(
