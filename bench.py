@@ -33,6 +33,7 @@ import dskd_amd  # noqa: E402,F401
 from dskd_amd import native  # noqa: E402
 from dskd_amd.builder import build_detector  # noqa: E402
 from dskd_amd.config import Config  # noqa: E402
+from dskd_amd.graph_step import GraphedDistillStep  # noqa: E402
 from dskd_amd.runner import build_optimizer  # noqa: E402
 
 CONFIG = os.path.join(ROOT, "configs", "dskd_gfl_deformable_detr_r50_70_10.py")
@@ -148,6 +149,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--dropout", type=float, default=None, help="override dropout p (default: config, 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches + DDP instead of hipGraph replay")
+    ap.add_argument("--probe-steps", type=int, default=3, help="eager steps after the timed region that bracket "
+                    "every MSDeformAttn launch with HIP events (roofline)")
     ap.add_argument("--seed", type=int, default=111)
     args = ap.parse_args()
 
@@ -170,28 +174,79 @@ def main():
     model = model.to(memory_format=torch.channels_last)
     model.teacher_model.to(memory_format=torch.channels_last)
     model.lazy_log = True                      # log scalars stay on the device inside the timed loop
-    wrapped = model
-    if world > 1:
-        from dskd_amd.dist import wrap_ddp
-        wrapped = wrap_ddp(model, device_ids=[local_rank])
-    optimizer = build_optimizer(model, cfg.optimizer[0])
     data, synth = make_batch(args.batch, cfg.num_prev, args.seed + rank, device)
     data["img"] = data["img"].contiguous(memory_format=torch.channels_last)
+    inject = {"pred_bboxes": synth["t_b"], "pred_labels": synth["t_l"], "pred_keepid": synth["keep"]}
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        loss, lv = train_step(model, wrapped, optimizer, data, synth, amp_dtype)
+    def all_ok(flag):
+        t = torch.tensor([1 if flag else 0], device=device)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    # Default execution: hipGraph replay of the step (dskd_amd/graph_step.py), gradients
+    # exchanged as ONE flat all-reduce over RCCL.  Fallback (--no-graph, or if capture fails on
+    # any rank): eager launches with DDP's bucketed all-reduce overlapped with backward.
+    mode = "eager+ddp" if args.no_graph else "hipgraph"
+    stepper = None
+    extra_warmup = 0
+    if mode == "hipgraph":
+        optimizer = build_optimizer(model, cfg.optimizer[0], capturable=True)
+        stepper = GraphedDistillStep(model, optimizer, amp_dtype=amp_dtype, max_norm=0.1, use_graphs=True, warmup=3)
+        ok = True
+        try:
+            n_warm = max(args.warmup, stepper.warmup + 2)       # capture happens inside the untimed warm-up
+            extra_warmup = n_warm - args.warmup
+            for _ in range(n_warm):
+                loss = stepper.step(data, inject)
+            torch.cuda.synchronize()
+            ok = len(stepper._graphs) == 1 and bool(torch.isfinite(loss).item())
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] rank {rank}: hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager",
+                  file=sys.stderr, flush=True)
+            ok = False
+        if not all_ok(ok):
+            mode = "eager+ddp(fallback)"
+            stepper = None
+            model.bbox_head.avg_pos_static = None
+            for p in model.parameters():
+                p.grad = None
+    if stepper is None:
+        wrapped = model
+        if world > 1:
+            from dskd_amd.dist import wrap_ddp
+            wrapped = wrap_ddp(model, device_ids=[local_rank])
+        optimizer = build_optimizer(model, cfg.optimizer[0])
+        for _ in range(args.warmup):
+            loss, lv = train_step(model, wrapped, optimizer, data, synth, amp_dtype)
+
+    def one_step():
+        if stepper is not None:
+            return stepper.step(data, inject)
+        return train_step(model, wrapped, optimizer, data, synth, amp_dtype)[0]
+
     sync()
-    native.timing_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, lv = train_step(model, wrapped, optimizer, data, synth, amp_dtype)
+        loss = one_step()
     sync()
     dt = time.perf_counter() - t0
+
+    # Roofline probe: the same step, same inputs, launched eagerly so that every MSDeformAttn
+    # launch can be bracketed by HIP events on the launch stream (events cannot be recorded
+    # inside a replayed hipGraph on ROCm).  Not part of the timed region.
+    native.timing_enable(True)
+    for _ in range(args.probe_steps):
+        if stepper is not None:
+            stepper.eager_step(data, inject)
+        else:
+            train_step(model, wrapped, optimizer, data, synth, amp_dtype)
+    torch.cuda.synchronize()
     kt = native.timing_collect()
     native.timing_enable(False)
 
@@ -218,7 +273,9 @@ def main():
         if dom:
             a = kernels[dom]["achieved_GBs"]
             roofline = {"bound": "hbm", "kernel": dom, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(a / HBM_PEAK_GBS, 4), "traffic": None, "kernels": kernels}
+                        "frac": round(a / HBM_PEAK_GBS, 4), "traffic": None,
+                        "timing": f"HIP events around each launch, {args.probe_steps} eager steps of the same "
+                                  "workload right after the timed region", "kernels": kernels}
         ips = args.batch * world * args.steps / dt
         out = {"metric": "images/sec (teacher+student distill step), DefDETR-R50 COCO 800x1333", "value": round(ips, 3),
                "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -229,7 +286,8 @@ def main():
                "config": {"workload": "Deformable-DETR R50 70+10 incremental DSKD distillation step "
                                       "(BASELINE.json configs[1])", "global_batch": args.batch * world,
                           "per_gpu_batch": args.batch, "image": [IMG_H, IMG_W], "queries": 300, "prev_classes": cfg.num_prev,
-                          "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
+                          "parallelism": f"dp{world}", "execution": mode, "extra_untimed_warmup": extra_warmup,
+                          "final_loss": round(final_loss, 4)},
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.seed, cfg.num_prev)

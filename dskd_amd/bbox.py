@@ -17,6 +17,7 @@ reference pays one per problem, gfl_hungarian_assigner.py:143-151).
 import torch
 
 from . import native
+from .utils import device_const
 from .builder import BBOX_ASSIGNERS, BBOX_SAMPLERS, MATCH_COST, build_match_cost
 
 
@@ -61,13 +62,12 @@ def bbox_overlaps(bboxes1, bboxes2, mode="iou", is_aligned=False, eps=1e-6):
         if mode == "giou":
             enclosed_lt = torch.min(bboxes1[..., :, None, :2], bboxes2[..., None, :, :2])
             enclosed_rb = torch.max(bboxes1[..., :, None, 2:], bboxes2[..., None, :, 2:])
-    eps = union.new_tensor([eps])
-    union = torch.max(union, eps)
+    union = union.clamp(min=eps)           # == torch.max(union, eps) of the reference, without a H2D copy
     ious = overlap / union
     if mode in ["iou", "iof"]:
         return ious
     enclose_wh = (enclosed_rb - enclosed_lt).clamp(min=0)
-    enclose_area = torch.max(enclose_wh[..., 0] * enclose_wh[..., 1], eps)
+    enclose_area = (enclose_wh[..., 0] * enclose_wh[..., 1]).clamp(min=eps)
     return ious - (enclose_area - union) / enclose_area
 
 
@@ -210,9 +210,8 @@ class GFLHungarianAssigner:
         # scatter the matches: one vectorised index_put for all problems
         n_match = [min(Q, g) for g in G]
         total = sum(n_match)
-        prob_of = torch.repeat_interleave(torch.arange(P, device=dev), torch.tensor(n_match, device=dev),
-                                          output_size=total)
-        start_of = torch.tensor([gt_start[p] for p in range(P)], device=dev)[prob_of]
+        prob_of = device_const([p for p in range(P) for _ in range(n_match[p])], torch.long, dev)
+        start_of = device_const([gt_start[p] for p in range(P) for _ in range(n_match[p])], torch.long, dev)
         row, col = row[:total], col[:total]
         gt_inds[prob_of, row] = col + 1
         labels[prob_of, row] = lab_cat[start_of + col]

@@ -199,7 +199,7 @@ class DeformableDETR_il(nn.Module):
         loss = sum(v for k, v in log_vars.items() if "loss" in k)
         log_vars["loss"] = loss
         keys = list(log_vars.keys())
-        flat = allreduce_scalars([torch.as_tensor(float(len(keys)), device=loss.device)] + [log_vars[k] for k in keys])
+        flat = allreduce_scalars([torch.full((), float(len(keys)), device=loss.device)] + [log_vars[k] for k in keys])
         if self.lazy_log:
             return loss, OrderedDict(_keys=keys, _flat=flat)
         host = flat.cpu().tolist()
@@ -207,6 +207,18 @@ class DeformableDETR_il(nn.Module):
         assert abs(host[0] - len(keys)) < 1e-6, "loss log variables are different across GPUs!\n" + ",".join(keys)
         del world
         return loss, OrderedDict((k, v) for k, v in zip(keys, host[1:]))
+
+    def parse_losses_local(self, losses):
+        """(loss, keys, flat) with flat = [n_keys, values...] on the device and NO collective and
+        no host copy: the graphed step reduces ``flat`` across ranks outside the captured region."""
+        log_vars = OrderedDict()
+        for name, value in losses.items():
+            log_vars[name] = value.mean() if isinstance(value, torch.Tensor) else sum(v.mean() for v in value)
+        loss = sum(v for k, v in log_vars.items() if "loss" in k)
+        log_vars["loss"] = loss
+        keys = list(log_vars.keys())
+        flat = torch.stack([v.detach().float().reshape(()) for v in log_vars.values()])
+        return loss, keys, flat
 
     def train_step(self, data, optimizer=None):
         """:419-450."""

@@ -31,6 +31,7 @@ from .bbox import bbox_cxcywh_to_xyxy, bbox_overlaps, bbox_xyxy_to_cxcywh
 from .builder import HEADS, build_assigner, build_loss, build_positional_encoding, build_sampler, build_transformer
 from .dist import reduce_mean
 from .transformer import Linear, inverse_sigmoid
+from .utils import device_const
 
 
 def multi_apply(func, *args, **kwargs):
@@ -63,7 +64,7 @@ class Integral_average(nn.Module):
     def forward(self, x):
         x = x.reshape(-1, self.reg_max + 1)
         x = x / x.sum(1).unsqueeze(1).repeat(1, self.reg_max + 1)
-        space = torch.linspace(0, self.reg_max, self.reg_max + 1).to(x.device)
+        space = torch.linspace(0, self.reg_max, self.reg_max + 1, device=x.device)
         space = space / self.reg_max / 2
         x = x * space
         return x.sum(1).reshape(-1, 2, 2).sum(2)
@@ -237,13 +238,13 @@ class GFLDeformableDETRHead_il(nn.Module):
             norm = []
             for i, g in enumerate(gt_bboxes_list):
                 img_h, img_w, _ = img_metas[i]["img_shape"]
-                factor = g.new_tensor([img_w, img_h, img_w, img_h]).unsqueeze(0)
+                factor = device_const([float(img_w), float(img_h), float(img_w), float(img_h)], g.dtype, g.device).unsqueeze(0)
                 norm.append(bbox_xyxy_to_cxcywh(g.reshape(-1, 4) / factor))
             gt_norm = torch.cat(norm, 0)                                  # [sum G, 4]
             starts = [0]
             for g in G[:-1]:
                 starts.append(starts[-1] + g)
-            start_img = torch.tensor(starts, device=gt_norm.device).repeat(nl)[:, None]   # [P,1]
+            start_img = device_const(starts * nl, torch.long, gt_norm.device)[:, None]     # [P,1]
             idx = (start_img + gt_inds - 1).clamp(min=0)
             bbox_targets = torch.where(pos[..., None], gt_norm[idx], gt_norm.new_zeros(()))
         else:
@@ -317,12 +318,19 @@ class GFLDeformableDETRHead_il(nn.Module):
 
         # normaliser: clamp(reduce_mean(num_total_pos), 1) (:1491-1492); identical for every
         # layer, so one all-reduce per step; stays on the device when distributed.
-        avg_pos = reduce_mean(all_cls_scores.new_tensor([float(num_total_pos)])).clamp(min=1)[0] \
-            if _dist_on() else max(float(num_total_pos), 1.0)
+        self.last_num_total_pos = num_total_pos
+        if getattr(self, "avg_pos_static", None) is not None:
+            # graphed step: the cross-rank mean was computed outside the captured region
+            avg_pos = self.avg_pos_static
+        elif _dist_on():
+            avg_pos = reduce_mean(device_const([float(num_total_pos)], torch.float32,
+                                               all_cls_scores.device)).clamp(min=1)[0]
+        else:
+            avg_pos = max(float(num_total_pos), 1.0)
 
-        factors = torch.cat([all_bbox_preds.new_tensor([m["img_shape"][1], m["img_shape"][0], m["img_shape"][1],
-                                                        m["img_shape"][0]]).unsqueeze(0).repeat(Q, 1)
-                             for m in img_metas], 0)
+        factors = device_const([[float(m["img_shape"][1]), float(m["img_shape"][0]), float(m["img_shape"][1]),
+                                 float(m["img_shape"][0])] for m in img_metas], all_bbox_preds.dtype,
+                               all_bbox_preds.device).repeat_interleave(Q, dim=0)
         losses_cls, losses_bbox, losses_iou, losses_dfl = self.loss_layers_dense(
             all_cls_scores.reshape(nl, B * Q, self.cls_out_channels), bbox_cxcywh.reshape(nl, B * Q, 4),
             bbox_lrtb.reshape(nl, B * Q, -1), labels, bbox_targets, pos, factors, avg_pos)
@@ -330,9 +338,8 @@ class GFLDeformableDETRHead_il(nn.Module):
         loss_dict = dict()
         prev_mask = None
         if self.has_teacher:
-            prev_mask = torch.zeros(self.cls_out_channels, dtype=torch.bool)
-            prev_mask[list(task_labels["prev"])] = True
-            prev_mask = prev_mask.to(hs.device)
+            prev_set = set(int(v) for v in task_labels["prev"])
+            prev_mask = device_const([c in prev_set for c in range(self.cls_out_channels)], torch.bool, hs.device)
             self.last_prev_mask = prev_mask
         if self.has_teacher and self.loss_corr is not None:               # :525-555
             hs_student = hs[-1].reshape(-1, hs.shape[-1])

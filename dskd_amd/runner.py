@@ -17,7 +17,7 @@ from .datasets import to_device
 from .dist import get_dist_info
 
 
-def build_optimizer(model, cfg):
+def build_optimizer(model, cfg, capturable=False):
     """ext-mmcv DefaultOptimizerConstructor semantics for the keys used by the DSKD configs:
     a parameter whose name contains a custom key gets lr * lr_mult (longest key wins)."""
     cfg = dict(cfg)
@@ -47,6 +47,8 @@ def build_optimizer(model, cfg):
     kwargs = {k: v for k, v in cfg.items() if k not in ("lr", "weight_decay")}
     if typ in ("AdamW", "Adam") and all(p.is_cuda for g in groups for p in g["params"]):
         kwargs.setdefault("fused", True)     # one multi-tensor kernel per group on the GPU
+        if capturable:
+            kwargs.setdefault("capturable", True)   # step counter on the device: hipGraph-safe
     return opt_cls(groups, lr=base_lr, weight_decay=base_wd, **kwargs)
 
 

@@ -21,6 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import native
+from .utils import device_const
 from .builder import (ATTENTION, FEEDFORWARD_NETWORK, POSITIONAL_ENCODING, TRANSFORMER, TRANSFORMER_LAYER,
                       TRANSFORMER_LAYER_SEQUENCE, build_attention, build_feedforward_network,
                       build_transformer_layer, build_transformer_layer_sequence)
@@ -56,15 +57,24 @@ class _TallLinearFn(torch.autograd.Function):
     the partial products -- a split-K GEMM expressed through the library."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, chunk):
-        ctx.chunk = chunk
-        ctx.save_for_backward(x, weight)
+    def forward(ctx, x, weight, bias, chunk, relu):
+        ctx.chunk, ctx.relu = chunk, relu
         ctx.has_bias = bias is not None
-        return F.linear(x, weight, bias)
+        assert x.dim() == 2           # the caller flattens: the output must not be a view
+        if relu and bias is not None and x.is_cuda:
+            y = torch._addmm_activation(bias, x, weight.t())     # bias + ReLU in the GEMM epilogue
+        else:
+            y = F.linear(x, weight, bias)
+            if relu:
+                y = torch.relu_(y)
+        ctx.save_for_backward(x, weight, y if relu else None)
+        return y
 
     @staticmethod
     def backward(ctx, g):
-        x, weight = ctx.saved_tensors
+        x, weight, y = ctx.saved_tensors
+        if ctx.relu:
+            g = torch.ops.aten.threshold_backward(g, y, 0)
         g2 = g.reshape(-1, g.shape[-1])
         x2 = x.reshape(-1, x.shape[-1])
         gx = gw = gb = None
@@ -73,10 +83,10 @@ class _TallLinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             nb = x2.shape[0] // ctx.chunk
             part = torch.bmm(g2.view(nb, ctx.chunk, -1).transpose(1, 2), x2.view(nb, ctx.chunk, -1))
-            gw = part.float().sum(0).to(weight.dtype)
+            gw = part.sum(0, dtype=torch.float32).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = g2.float().sum(0).to(g.dtype)
-        return gx, gw, gb, None
+            gb = g2.sum(0, dtype=torch.float32).to(g.dtype)
+        return gx, gw, gb, None, None
 
 
 class Linear(nn.Linear):
@@ -85,8 +95,8 @@ class Linear(nn.Linear):
     teacher (and any frozen student layer) would re-cast every weight on every call; trainable
     parameters take the stock path (autocast's own per-step cache)."""
 
-    def forward(self, x):
-        dev = x.device.type
+    def frozen_lp(self, dev):
+        """(weight, bias) in the autocast dtype when both are frozen and autocast is on, else None."""
         if torch.is_autocast_enabled(dev) and not self.weight.requires_grad and \
                 (self.bias is None or not self.bias.requires_grad):
             dtype = torch.get_autocast_dtype(dev)
@@ -95,25 +105,37 @@ class Linear(nn.Linear):
             if cache is None or cache[0] != key:
                 cache = (key, self.weight.detach().to(dtype), None if self.bias is None else self.bias.detach().to(dtype))
                 self.__dict__["_lp"] = cache
-            return F.linear(x, cache[1], cache[2])
+            return cache[1], cache[2]
+        return None
+
+    def forward(self, x):
+        lp = self.frozen_lp(x.device.type)
+        if lp is not None:
+            return F.linear(x, lp[0], lp[1])
         return tall_linear(x, self.weight, self.bias)
 
 
-def tall_linear(x, weight, bias):
-    """F.linear, switching to the split-K weight gradient for very tall inputs."""
+def tall_linear(x, weight, bias, relu=False):
+    """F.linear (optionally + ReLU), switching to the split-K weight gradient -- and the fused
+    bias+ReLU GEMM epilogue -- for very tall inputs."""
     dev = x.device.type
     tokens = x.numel() // max(x.shape[-1], 1)
     if tokens >= 16384 and weight.requires_grad and torch.is_grad_enabled() and x.is_contiguous():
         chunk = _token_chunk(tokens, weight.numel())
         if chunk is not None:
+            lead = x.shape[:-1]
+            x2 = x.reshape(tokens, x.shape[-1])
             if torch.is_autocast_enabled(dev):       # what autocast would do for F.linear
                 dtype = torch.get_autocast_dtype(dev)
-                x, weight = x.to(dtype), weight.to(dtype)
+                x2, weight = x2.to(dtype), weight.to(dtype)
                 bias = None if bias is None else bias.to(dtype)
                 with torch.autocast(dev, enabled=False):
-                    return _TallLinearFn.apply(x, weight, bias, chunk)
-            return _TallLinearFn.apply(x, weight, bias, chunk)
-    return F.linear(x, weight, bias)
+                    y = _TallLinearFn.apply(x2, weight, bias, chunk, relu)
+            else:
+                y = _TallLinearFn.apply(x2, weight, bias, chunk, relu)
+            return y.view(*lead, y.shape[-1])
+    y = F.linear(x, weight, bias)
+    return torch.relu_(y) if relu else y
 
 
 def inverse_sigmoid(x, eps=1e-5):
@@ -324,7 +346,23 @@ class FFN(nn.Module):
         self.add_identity = add_identity
 
     def forward(self, x, identity=None):
-        out = self.layers(x)
+        first = self.layers[0]
+        if self.num_fcs == 2 and isinstance(first[1], nn.ReLU) and first[0].weight.requires_grad:
+            # Linear + ReLU as one GEMM with a fused epilogue, then the rest of the stack
+            out = tall_linear(x, first[0].weight, first[0].bias, relu=True)
+            out = first[2](out)
+            for m in list(self.layers)[1:]:
+                out = m(out)
+        elif self.num_fcs == 2 and isinstance(first[1], nn.ReLU) and x.is_cuda and not torch.is_grad_enabled() \
+                and first[0].bias is not None and first[0].frozen_lp(x.device.type) is not None:
+            # frozen teacher under autocast: cached low-precision weights + fused bias/ReLU epilogue
+            w, b = first[0].frozen_lp(x.device.type)
+            out = torch._addmm_activation(b, x.reshape(-1, x.shape[-1]).to(w.dtype), w.t()).view(*x.shape[:-1], -1)
+            out = first[2](out)
+            for m in list(self.layers)[1:]:
+                out = m(out)
+        else:
+            out = self.layers(x)
         if not self.add_identity:
             return self.dropout_layer(out)
         if identity is None:
@@ -599,6 +637,6 @@ class DeformableDetrTransformer(nn.Module):
             query=query, key=None, value=memory, query_pos=query_pos, key_padding_mask=mask_flatten,
             reference_points=reference_points, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
             valid_ratios=valid_ratios, reg_branches=reg_branches, value_batch_first=True, **kwargs)
-        spatial_shapes_t = torch.as_tensor(spatial_shapes, dtype=torch.long, device=device)
+        spatial_shapes_t = device_const(spatial_shapes, torch.long, device)
         info_all = (memory.permute(1, 0, 2), spatial_shapes_t)      # reference layout (sum HW, bs, C), a view
         return inter_states, init_reference_out, inter_references, info_all, None, None

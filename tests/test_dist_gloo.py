@@ -64,10 +64,36 @@ def _worker(rank, world, port, out):
     gsum = torch.stack([p.grad.double().sum() for p in model.parameters() if p.grad is not None]).sum()
     gathered = [torch.zeros_like(gsum) for _ in range(world)]
     dist.all_gather(gathered, gsum)
+    # ---- the graph-step driver's data-parallel exchange (eager on CPU): ONE flat gradient
+    # all-reduce, no DDP wrapper; parameters must stay identical across ranks
+    from dskd_amd.graph_step import GraphedDistillStep
+    from dskd_amd.runner import build_optimizer
+    torch.manual_seed(1)
+    m2 = build_detector(cfg.model)
+    m2.init_weights()
+    for mm in m2.modules():
+        if isinstance(mm, torch.nn.Dropout):
+            mm.p = 0.0
+        if isinstance(mm, torch.nn.MultiheadAttention):
+            mm.dropout = 0.0
+    m2.set_teacher(model=copy.deepcopy(m2))
+    m2.LableInPCNTask = {"prev": list(range(70)), "curr": list(range(70, 80)), "next": []}
+    m2.train()
+    opt2 = build_optimizer(m2, cfg.optimizer[0])
+    stepper = GraphedDistillStep(m2, opt2, amp_dtype=None, max_norm=0.1)
+    data = dict(img=img, img_metas=metas, gt_bboxes=gt_b, gt_labels=gt_l)
+    inject = dict(pred_bboxes=ti["pred_bboxes"], pred_labels=ti["pred_labels"], pred_keepid=ti["pred_keepid"])
+    for _ in range(2):
+        stepper.step(data, inject)
+    psum = torch.stack([p.detach().double().sum() for p in m2.parameters()]).sum()
+    pg = [torch.zeros_like(psum) for _ in range(world)]
+    dist.all_gather(pg, psum)
+    step_logs = stepper.logs()
     rm = reduce_mean(torch.tensor([float(rank + 1)]))
     sc = allreduce_scalars([torch.tensor(float(rank)), torch.tensor(2.0)])
     if rank == 0:
-        out.put(dict(gsums=[float(x) for x in gathered], reduce_mean=float(rm), scalars=sc.tolist(),
+        out.put(dict(psums=[float(x) for x in pg], step_keys=sorted(step_logs.keys()),
+                     gsums=[float(x) for x in gathered], reduce_mean=float(rm), scalars=sc.tolist(),
                      keys=sorted(log_vars.keys()), loss=float(log_vars["loss"]), local_loss=float(loss)))
     dist.barrier()
     dist.destroy_process_group()
@@ -85,6 +111,8 @@ def test_two_rank_ddp_step_gloo():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert res["gsums"][0] == pytest.approx(res["gsums"][1], rel=1e-9)        # DDP averaged the gradients
+    assert res["psums"][0] == pytest.approx(res["psums"][1], rel=1e-12)        # stepper keeps ranks in sync
+    assert "loss" in res["step_keys"] and "loss_fg_feature" in res["step_keys"]
     assert res["reduce_mean"] == pytest.approx(1.5)
     assert res["scalars"] == [pytest.approx(0.5), pytest.approx(2.0)]
     assert "loss_corr" in res["keys"] and "loss_fg_feature" in res["keys"] and "d4.loss_dfl" in res["keys"]
