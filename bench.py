@@ -149,7 +149,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--dropout", type=float, default=None, help="override dropout p (default: config, 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="eager launches + DDP instead of hipGraph replay")
+    ap.add_argument("--graph", action="store_true", help="EXPERIMENTAL: replay the step as hipGraphs "
+                    "(dskd_amd/graph_step.py) instead of eager launches + DDP")
     ap.add_argument("--probe-steps", type=int, default=3, help="eager steps after the timed region that bracket "
                     "every MSDeformAttn launch with HIP events (roofline)")
     ap.add_argument("--seed", type=int, default=111)
@@ -189,10 +190,11 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(t.item())
 
-    # Default execution: hipGraph replay of the step (dskd_amd/graph_step.py), gradients
-    # exchanged as ONE flat all-reduce over RCCL.  Fallback (--no-graph, or if capture fails on
-    # any rank): eager launches with DDP's bucketed all-reduce overlapped with backward.
-    mode = "eager+ddp" if args.no_graph else "hipgraph"
+    # Default execution: eager launches (the step has no host<->device synchronisation apart
+    # from the teacher decode, so the host runs ahead of the GPU) with DDP's bucketed all-reduce
+    # overlapped with backward.  --graph: hipGraph replay of the step, gradients exchanged as
+    # ONE flat all-reduce over RCCL; falls back to eager if capture fails on any rank.
+    mode = "hipgraph" if args.graph else "eager+ddp"
     stepper = None
     extra_warmup = 0
     if mode == "hipgraph":

@@ -162,7 +162,13 @@ __global__ __launch_bounds__(64) void lsap_kernel(const float* __restrict__ cost
     const float c = cost[e];
     bad |= (c != c) || (c == -INFINITY);
   }
+  // On an error the status word carries the scipy error class and the outputs are filled with
+  // an in-range identity pairing, so that a caller that indexes with them before looking at
+  // the status (asynchronous pipelines do) can never go out of bounds.
+  int64_t* ro = row_out + d.out_off;
+  int64_t* co = col_out + d.out_off;
   if (__any(bad)) {
+    for (int k = lane; k < nr; k += 64) { ro[k] = k; co[k] = k; }
     if (lane == 0) status[blockIdx.x] = DSKD_ERR_INVALID_COST;
     return;
   }
@@ -204,6 +210,7 @@ __global__ __launch_bounds__(64) void lsap_kernel(const float* __restrict__ cost
       best = wave_best(best);
       minVal = best.val;
       if (minVal == INFINITY) {  // wave-uniform
+        for (int k = lane; k < nr; k += 64) { ro[k] = k; co[k] = k; }
         if (lane == 0) status[blockIdx.x] = DSKD_ERR_INFEASIBLE;
         return;
       }
@@ -243,8 +250,6 @@ __global__ __launch_bounds__(64) void lsap_kernel(const float* __restrict__ cost
     wave_lds_sync();
   }
 
-  int64_t* ro = row_out + d.out_off;
-  int64_t* co = col_out + d.out_off;
   if (tr) {
     // pairs sorted by original row = col4row value (all distinct): rank by counting
     for (int k = lane; k < nr; k += 64) {

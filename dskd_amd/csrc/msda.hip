@@ -77,11 +77,20 @@ struct Traits<__bf16> {
 
 // One sampling point -> four corner byte offsets (row * ROWB, or kOOB) and the four
 // bilinear weights.  aux = (lx, ly, attn, level) for the backward.
+// Per-level geometry is looked up in a tiny LDS table indexed by the lane's level: chains of
+// selects over the kernel-argument arrays were lowered to divergent branch trees by the compiler.
+__device__ __forceinline__ void fill_level_table(i32x4* tab, const LevelGeom& g) {
+#pragma unroll
+  for (int l = 0; l < kMaxLevels; ++l)
+    if (threadIdx.x == l) tab[l] = i32x4{g.H[l], g.W[l], g.start[l], 0};
+}
+
 template <int ROWB>
 __device__ __forceinline__ void point_params(float lx_n, float ly_n, float a, int lvl,
-                                             const LevelGeom& g, i32x4& off, f32x4& w,
+                                             const i32x4* tab, i32x4& off, f32x4& w,
                                              f32x4& aux) {
-  const int H = SEL4(g.H, lvl), W = SEL4(g.W, lvl), st = SEL4(g.start, lvl);
+  const i32x4 lt = tab[lvl];
+  const int H = lt.x, W = lt.y, st = lt.z;
   const float x = lx_n * (float)W - 0.5f;
   const float y = ly_n * (float)H - 0.5f;
   off = i32x4{kOOB, kOOB, kOOB, kOOB};
@@ -145,7 +154,7 @@ __device__ __forceinline__ void load_vals(__amdgpu_buffer_rsrc_t rsrc, int voff,
 template <typename T, bool WITH_AUX>
 __device__ __forceinline__ void stage_points(const float* __restrict__ loc,
                                              const float* __restrict__ attn,
-                                             const LevelGeom& g, int b, int Nq, int q0,
+                                             const i32x4* g, int b, int Nq, int q0,
                                              int q_end, int LP, int points, int lane,
                                              i32x4* s_off, f32x4* s_wt, f32x4* s_aux) {
   using TR = Traits<T>;
@@ -186,6 +195,9 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_kernel(
   constexpr int SLOTS = TR::QPW * kHeads * kHeadStride;
   __shared__ i32x4 s_off_all[kWaves][SLOTS];
   __shared__ f32x4 s_wt_all[kWaves][SLOTS];
+  __shared__ i32x4 s_lvl[kMaxLevels];
+  fill_level_table(s_lvl, g);
+  __syncthreads();
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -211,7 +223,7 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_kernel(
   const f32x4* my_wt = s_wt + (qs * kHeads + h) * kHeadStride;
 
   for (int q0 = q_begin + wave * TR::QPW; q0 < q_end; q0 += kWaves * TR::QPW) {
-    stage_points<T, false>(loc, attn, g, b, Nq, q0, q_end, LP, points, lane, s_off, s_wt,
+    stage_points<T, false>(loc, attn, s_lvl, b, Nq, q0, q_end, LP, points, lane, s_off, s_wt,
                            nullptr);
     wave_lds_sync();
 
@@ -268,6 +280,9 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_kernel(
   __shared__ i32x4 s_off_all[kWaves][SLOTS];
   __shared__ f32x4 s_wt_all[kWaves][SLOTS];
   __shared__ f32x4 s_aux_all[kWaves][SLOTS];
+  __shared__ i32x4 s_lvl[kMaxLevels];
+  fill_level_table(s_lvl, g);
+  __syncthreads();
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -293,7 +308,7 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_kernel(
   const int myslot = (qs * kHeads + h) * kHeadStride;
 
   for (int q0 = q_begin + wave * TR::QPW; q0 < q_end; q0 += kWaves * TR::QPW) {
-    stage_points<T, true>(loc, attn, g, b, Nq, q0, q_end, LP, points, lane, s_off, s_wt,
+    stage_points<T, true>(loc, attn, s_lvl, b, Nq, q0, q_end, LP, points, lane, s_off, s_wt,
                           s_aux);
     wave_lds_sync();
 
@@ -339,7 +354,8 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_kernel(
       if (qv && part == (s & (TR::LPH - 1))) {
         const float lx = ax.x, ly = ax.y, a = ax.z;
         const int lvl = (int)ax.w;
-        const float Wf = (float)SEL4(g.W, lvl), Hf = (float)SEL4(g.H, lvl);
+        const i32x4 lt = s_lvl[lvl];
+        const float Wf = (float)lt.y, Hf = (float)lt.x;
         const float hx = 1.f - lx, hy = 1.f - ly;
         const float ga = w.x * d0 + w.y * d1 + w.z * d2 + w.w * d3;
         const float gx = Wf * a * (hy * (d1 - d0) + ly * (d3 - d2));
@@ -469,6 +485,7 @@ __global__ __launch_bounds__(kVWaves * 64) void msda_bwd_value_kernel(
   float* s_red = reinterpret_cast<float*>(s_q + kVWaves * 4);  // [2 * waves] block reductions
   float* s_g = s_red + 2 * kVWaves;                            // [waves][4][8] scaled grad_out
   int* s_fb = reinterpret_cast<int*>(s_g + kVWaves * 32);      // [waves] fallback flag
+  i32x4* s_tab = reinterpret_cast<i32x4*>(s_fb + kVWaves);     // [4][4] per-level lookup rows (16-B aligned)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -503,8 +520,19 @@ __global__ __launch_bounds__(kVWaves * 64) void msda_bwd_value_kernel(
 #pragma unroll
   for (int l = 0; l < kMaxLevels; ++l) qinv[l] = 1.0f / (float)(qdx[l] > 0 ? qdx[l] : 1);
 
+  // lookup rows per level l: [4l+0] = {cum, qxa, qya, qdx}   [4l+1] = {1/qdx, start, W, H}
+  //                           [4l+2] = {ww, wh, wx0, wy0}     [4l+3] = {base, 0, 0, 0}
+#pragma unroll
+  for (int l = 0; l < kMaxLevels; ++l)
+    if (tid == l) {
+      s_tab[4 * l + 0] = i32x4{cum[l], qxa[l], qya[l], qdx[l]};
+      s_tab[4 * l + 1] = i32x4{__builtin_bit_cast(int, qinv[l]), g.start[l], g.W[l], g.H[l]};
+      s_tab[4 * l + 2] = i32x4{g.ww[l], g.wh[l], wx0[l], wy0[l]};
+      s_tab[4 * l + 3] = i32x4{g.base[l], 0, 0, 0};
+    }
   for (int i = tid * 4; i < kSlice * g.NP; i += kVWaves * 64 * 4)
     *reinterpret_cast<i32x4*>(win + i) = i32x4{0, 0, 0, 0};
+  __syncthreads();
 
   float* gvb = grad_value + (size_t)b * Nq * (kHeads * kCh) + chbase;
   const T* gob = grad_out + (size_t)b * Nq * (kHeads * kCh) + chbase;
@@ -516,10 +544,10 @@ __global__ __launch_bounds__(kVWaves * 64) void msda_bwd_value_kernel(
     int lq = 0;
 #pragma unroll
     for (int l = 1; l < kMaxLevels; ++l) lq += qi >= cum[l];
-    const int rem = qi - SEL4(cum, lq);
-    const int dx = SEL4(qdx, lq);
-    const int yy = (int)(((float)rem + 0.5f) * SEL4F(qinv, lq));
-    const int qg = SEL4(g.start, lq) + (SEL4(qya, lq) + yy) * SEL4(g.W, lq) + SEL4(qxa, lq) + (rem - yy * dx);
+    const i32x4 qa = s_tab[4 * lq], qb = s_tab[4 * lq + 1];
+    const int rem = qi - qa.x;
+    const int yy = (int)(((float)rem + 0.5f) * as_f32((unsigned)qb.x));
+    const int qg = qb.y + (qa.z + yy) * qb.z + qa.y + (rem - yy * qa.w);
     gmax = fmaxf(gmax, fabsf((float)gob[(size_t)qg * (kHeads * kCh) + (i & 7)]));
     const float* ap = attn + (((size_t)b * Nq + qg) * kHeads + h) * (size_t)LP;
     for (int s2 = (i & 7); s2 < LP; s2 += kSlice) asum += fabsf(ap[s2]);
@@ -563,19 +591,19 @@ __global__ __launch_bounds__(kVWaves * 64) void msda_bwd_value_kernel(
         int lq = 0;
 #pragma unroll
         for (int l = 1; l < kMaxLevels; ++l) lq += qi >= cum[l];
-        const int rem = qi - SEL4(cum, lq);
-        const int xa = SEL4(qxa, lq);
-        const int dx = SEL4(qdx, lq);
-        const int ya = SEL4(qya, lq);
+        const i32x4 qa = s_tab[4 * lq], qb = s_tab[4 * lq + 1];
+        const int rem = qi - qa.x;
+        const int xa = qa.y, ya = qa.z, dx = qa.w;
         // exact: the fractional part of (rem + 0.5) / dx is at least 0.5/dx away from an integer
-        const int yy = (int)(((float)rem + 0.5f) * SEL4F(qinv, lq));
-        qg = SEL4(g.start, lq) + (ya + yy) * SEL4(g.W, lq) + xa + (rem - yy * dx);
+        const int yy = (int)(((float)rem + 0.5f) * as_f32((unsigned)qb.x));
+        qg = qb.y + (ya + yy) * qb.z + xa + (rem - yy * dx);
         if (s < LP) {
           const size_t base = (((size_t)b * Nq + qg) * kHeads + h) * (size_t)LP + s;
           const f32x2 xy = *reinterpret_cast<const f32x2*>(loc + base * 2);
           const float a = attn[base];
           const int lvl = points == 4 ? s >> 2 : s / points;
-          const int H = SEL4(g.H, lvl), W = SEL4(g.W, lvl), st = SEL4(g.start, lvl);
+          const i32x4 lb = s_tab[4 * lvl + 1], lc = s_tab[4 * lvl + 2];
+          const int H = lb.w, W = lb.z, st = lb.y;
           const float x = xy.x * (float)W - 0.5f;
           const float y = xy.y * (float)H - 0.5f;
           if (x > -1.f && y > -1.f && x < (float)W && y < (float)H) {
@@ -585,10 +613,10 @@ __global__ __launch_bounds__(kVWaves * 64) void msda_bwd_value_kernel(
             const bool vx0 = x0 >= 0, vx1 = x0 + 1 <= W - 1, vy0 = y0 >= 0, vy1 = y0 + 1 <= H - 1;
             w = f32x4{(vy0 && vx0) ? hy * hx * a : 0.f, (vy0 && vx1) ? hy * lx * a : 0.f,
                       (vy1 && vx0) ? ly * hx * a : 0.f, (vy1 && vx1) ? ly * lx * a : 0.f};
-            const int wwl = SEL4(g.ww, lvl), whl = SEL4(g.wh, lvl);
-            const int wx = x0 - SEL4(wx0, lvl), wy = y0 - SEL4(wy0, lvl);
+            const int wwl = lc.x, whl = lc.y;
+            const int wx = x0 - lc.z, wy = y0 - lc.w;
             if (fx_ok && wx >= 0 && wx + 1 < wwl && wy >= 0 && wy + 1 < whl) {
-              const int pb = (SEL4(g.base, lvl) + wy * wwl + wx) * 4;
+              const int pb = (s_tab[4 * lvl + 3].x + wy * wwl + wx) * 4;
               off = i32x4{pb, pb + 4, pb + wwl * 4, pb + wwl * 4 + 4};
             } else {  // outside the LDS window: direct global atomics, rows encoded as -(2+row)
               const int r00 = st + y0 * W + x0;
@@ -652,12 +680,13 @@ __global__ __launch_bounds__(kVWaves * 64) void msda_bwd_value_kernel(
     int l = 0;
 #pragma unroll
     for (int k = 1; k < kMaxLevels; ++k) l += (k < g.levels && p >= g.base[k]) ? 1 : 0;
-    const int rel = p - SEL4(g.base, l);
-    const int wwl = SEL4(g.ww, l);
+    const i32x4 lb = s_tab[4 * l + 1], lc = s_tab[4 * l + 2];
+    const int rel = p - s_tab[4 * l + 3].x;
+    const int wwl = lc.x;
     const int wy = (int)(((float)rel + 0.5f) / (float)wwl), wx = rel - wy * wwl;
-    const int gx = SEL4(wx0, l) + wx, gy = SEL4(wy0, l) + wy;
-    if (gx >= 0 && gx < SEL4(g.W, l) && gy >= 0 && gy < SEL4(g.H, l))
-      atomicAdd(gvb + (size_t)(SEL4(g.start, l) + gy * SEL4(g.W, l) + gx) * (kHeads * kCh) + ch, v);
+    const int gx = lc.z + wx, gy = lc.w + wy;
+    if (gx >= 0 && gx < lb.z && gy >= 0 && gy < lb.w)
+      atomicAdd(gvb + (size_t)(lb.y + gy * lb.z + gx) * (kHeads * kCh) + ch, v);
   }
 }
 
@@ -694,7 +723,7 @@ bool make_value_geom(const LevelGeom& lg, int levels, int Nq, ValueGeom* g, size
   g->NP = NP;
   *lds_bytes = sizeof(float) * (size_t)kSlice * NP + (sizeof(int) + sizeof(float)) * kVWaves * 64 * 4 +
                sizeof(int) * kVWaves * 4 + sizeof(float) * 2 * kVWaves + sizeof(float) * kVWaves * 32 +
-               sizeof(int) * kVWaves;
+               sizeof(int) * kVWaves + sizeof(int) * 4 * 4 * kMaxLevels;
   return *lds_bytes <= 156 * 1024;
 }
 

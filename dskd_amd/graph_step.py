@@ -7,13 +7,13 @@ replayed:
 
     graph T   teacher backbone + neck + transformer + heads          (no_grad, eval)
     eager     teacher box decode (score threshold / top-k: data-dependent sizes, one sync)
-    graph S   zero grads, student forward, all losses, backward
-    eager     [world > 1] ONE all-reduce of the flat gradient buffer over RCCL + log scalars
+    graph S   student forward, all losses, backward (gradients allocated in the graph's pool)
+    eager     [world > 1] ONE all-reduce of the flattened gradients over RCCL + log scalars
     graph U   global-norm gradient clip + fused AdamW update
 
-The gradients live in one flat fp32 buffer (parameters' ``.grad`` are views of it), so the
-data-parallel exchange is a single large collective -- the shape xGMI likes
--- and nothing inside a captured region talks to the host or to another rank.  Requirements
+For data parallelism the gradients are flattened into one buffer and exchanged as a single
+large collective -- the shape xGMI likes -- and nothing inside a captured
+region talks to the host or to another rank.  Requirements
 met elsewhere in the package: no host->device copies inside the step (``utils.device_const``),
 no ``.item()``/``nonzero`` in the loss path, custom kernels launched on the capturing stream
 with their arguments passed by value.
@@ -37,8 +37,6 @@ class GraphedDistillStep:
         self.dev = next(model.parameters()).device
         self._graphs = {}
         self._seen = {}
-        self._flat = None
-        self._params = None
         self.last_logs = None
         self._avg_pos = None
 
@@ -63,10 +61,7 @@ class GraphedDistillStep:
                         pred_labels=[r[1] for r in pred], pred_logits=[r[2] for r in pred], pred_keepid=keep)
 
     def _fwd_bwd(self, data, feats, outs, det):
-        if self._flat is not None:
-            self._flat.zero_()
-        else:
-            self.opt.zero_grad(set_to_none=True)
+        self.opt.zero_grad(set_to_none=True)
         with self._autocast():
             ti = {"neck_feats": feats if self.model.bbox_head.feats_distill else None, "head_outs": outs,
                   "pred_keepid": det["pred_keepid"], "pred_logits": det.get("pred_logits"),
@@ -79,8 +74,7 @@ class GraphedDistillStep:
         return loss.detach(), keys, flat
 
     def _update(self):
-        params = self._params if self._params is not None else \
-            [p for g in self.opt.param_groups for p in g["params"] if p.grad is not None]
+        params = [p for g in self.opt.param_groups for p in g["params"] if p.grad is not None]
         torch.nn.utils.clip_grad_norm_(params, max_norm=self.max_norm, norm_type=self.norm_type, foreach=True)
         self.opt.step()
 
@@ -108,31 +102,14 @@ class GraphedDistillStep:
         """Everything that crosses ranks, outside the graphs: one gradient all-reduce (mean) and
         one small all-reduce of the log scalars."""
         if self.world > 1:
-            if self._flat is not None:
-                dist.all_reduce(self._flat)
-                self._flat.div_(self.world)
-            else:
-                for p in (p for g in self.opt.param_groups for p in g["params"] if p.grad is not None):
-                    dist.all_reduce(p.grad)
-                    p.grad.div_(self.world)
+            grads = [p.grad for g in self.opt.param_groups for p in g["params"] if p.grad is not None]
+            flat = torch._utils._flatten_dense_tensors(grads)
+            dist.all_reduce(flat)
+            flat.div_(self.world)
+            torch._foreach_copy_(grads, list(torch._utils._unflatten_dense_tensors(flat, grads)))
             dist.all_reduce(flat_logs)
             flat_logs.div_(self.world)
         return flat_logs
-
-    # ------------------------------------------------------------------ flat gradient buffer
-    def _make_flat_grads(self):
-        """After one eager backward: re-home every existing .grad into one flat buffer."""
-        params = [p for g in self.opt.param_groups for p in g["params"] if p.grad is not None]
-        total = sum(p.numel() for p in params)
-        flat = torch.zeros(total, dtype=params[0].grad.dtype, device=self.dev)
-        off = 0
-        for p in params:
-            n = p.numel()
-            view = flat[off:off + n].view_as(p)
-            view.copy_(p.grad)
-            p.grad = view
-            off += n
-        self._flat, self._params = flat, params
 
     # ------------------------------------------------------------------ public
     @staticmethod
@@ -180,8 +157,6 @@ class GraphedDistillStep:
         return g["loss"]
 
     def _capture(self, data, inject):
-        if self._flat is None:
-            self._make_flat_grads()
         torch.cuda.synchronize()
         gT = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gT):
@@ -196,7 +171,9 @@ class GraphedDistillStep:
         with torch.cuda.graph(gU, pool=gT.pool()):
             self._update()
         torch.cuda.synchronize()
-        return dict(T=gT, S=gS, U=gU, outs=outs, feats=feats, loss=loss, keys=keys, flat_logs=flat_logs)
+        from .utils import const_cache_snapshot
+        return dict(T=gT, S=gS, U=gU, outs=outs, feats=feats, loss=loss, keys=keys, flat_logs=flat_logs,
+                    keepalive=(const_cache_snapshot(), det, data, inject))   # everything the graphs point at
 
     def logs(self):
         """Host copy of the last step's log vars (one device->host copy)."""

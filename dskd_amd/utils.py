@@ -24,3 +24,9 @@ def device_const(values, dtype, device):
     else:
         _CONST_CACHE.move_to_end(key)
     return t
+
+
+def const_cache_snapshot():
+    """References to every cached constant: a captured hipGraph holds raw pointers to them, so
+    the graph's owner keeps this list alive (the LRU may otherwise evict and free them)."""
+    return list(_CONST_CACHE.values())

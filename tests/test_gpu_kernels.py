@@ -226,6 +226,8 @@ def test_lsap_device_errors():
     ok = rng.random((5, 7)).astype(np.float32)
     res = _lsap_device([bad, ninf, infeasible, ok])
     assert [r[2] for r in res] == [-3, -3, -4, 0]
+    for r, c, st in res[:3]:          # failed problems still hand back in-range indices
+        assert (r >= 0).all() and (r < 5).all() and (c >= 0).all() and (c < 7).all()
     with pytest.raises(ValueError, match="invalid numeric"):
         native.raise_for_lsap_status(torch.tensor([0, -3]))
     with pytest.raises(ValueError, match="infeasible"):

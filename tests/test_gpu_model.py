@@ -89,17 +89,22 @@ def test_full_step_gpu_matches_cpu_oracle_fp32(oracle_checker):
     native.raise_for_lsap_status(m_gpu.bbox_head.last_lsap_status)
 
 
-def test_graph_replay_equals_eager():
-    """hipGraph capture/replay of the step produces the same training trajectory as eager."""
+@pytest.mark.parametrize("channels_last,amp", [(False, None), (True, torch.bfloat16)])
+def test_graph_replay_equals_eager(channels_last, amp):
+    """hipGraph capture/replay of the step produces the same training trajectory as eager
+    (also in the benchmark's configuration: channels_last model, bf16 autocast)."""
     cfg, m1 = _build(seed=3)
     m2 = copy.deepcopy(m1)
     dev = torch.device("cuda:0")
     losses = []
     for m, use_graphs in ((m1, False), (m2, True)):
         m.to(dev).train()
+        if channels_last:
+            m.to(memory_format=torch.channels_last)
+            m.teacher_model.to(memory_format=torch.channels_last)
         opt = build_optimizer(m, cfg.optimizer[0], capturable=True)
         data, inject = _batch(dev)
-        stepper = GraphedDistillStep(m, opt, amp_dtype=None, max_norm=0.1, use_graphs=use_graphs, warmup=2)
+        stepper = GraphedDistillStep(m, opt, amp_dtype=amp, max_norm=0.1, use_graphs=use_graphs, warmup=2)
         seq = []
         for _ in range(6):
             loss = stepper.step(data, inject)
@@ -110,5 +115,5 @@ def test_graph_replay_equals_eager():
             logs = stepper.logs()
             assert "loss_corr" in logs and "loss_fg_feature" in logs and logs["loss"] == pytest.approx(seq[-1], rel=1e-5)
     for a, b in zip(*losses):
-        assert b == pytest.approx(a, rel=2e-3), losses
+        assert b == pytest.approx(a, rel=2e-3 if amp is None else 3e-2), losses
     assert losses[0][-1] != losses[0][0]                      # the weights actually move
