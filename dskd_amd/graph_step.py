@@ -165,10 +165,10 @@ class GraphedDistillStep:
         det = dict(self._decode(outs, data), **inject)
         self._set_avg_pos(data, det)
         gS = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gS, pool=gT.pool()):
+        with torch.cuda.graph(gS):
             loss, keys, flat_logs = self._fwd_bwd(data, feats, outs, det)
         gU = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gU, pool=gT.pool()):
+        with torch.cuda.graph(gU):
             self._update()
         torch.cuda.synchronize()
         from .utils import const_cache_snapshot
