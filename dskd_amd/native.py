@@ -28,6 +28,8 @@ _SIGNATURES = {
     "dskd_device_count": (C.c_int, []),
     "dskd_msda_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [C.c_int] * 8 + [_vp]),
     "dskd_msda_bwd": (C.c_int, [_vp] * 9 + [C.c_int] * 8 + [_vp]),
+    "dskd_msda_prep_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "dskd_msda_prep_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_lsap_host": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "dskd_lsap_batched": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "dskd_match_cost": (C.c_int, [_vp] * 7 + [C.c_int] * 3 + [_f32] * 3 + [_vp]),
@@ -232,6 +234,50 @@ def ms_deform_attn(value: torch.Tensor, spatial_shapes: Sequence[Tuple[int, int]
         return f(value, spatial_shapes, sampling_locations, attention_weights)
     shapes = tuple((int(h), int(w)) for h, w in spatial_shapes)
     return _MSDAFunction.apply(value, sampling_locations, attention_weights, shapes)
+
+
+class _MSDAPrepFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, both, ref, shapes, heads, levels, points):
+        dt = {torch.float32: DTYPE_F32, torch.bfloat16: DTYPE_BF16}[both.dtype]
+        both = both.contiguous()
+        ref = ref.contiguous().float()
+        lead = both.shape[:-1]
+        nq = both.numel() // both.shape[-1]
+        loc = torch.empty(lead + (heads, levels, points, 2), dtype=torch.float32, device=both.device)
+        attn = torch.empty(lead + (heads, levels, points), dtype=torch.float32, device=both.device)
+        ss, _, _ = _geom(shapes)
+        rc = load().dskd_msda_prep_fwd(both.data_ptr(), ref.data_ptr(), ss, loc.data_ptr(), attn.data_ptr(), nq, heads,
+                                       levels, points, dt, _stream(both))
+        _check(rc, "dskd_msda_prep_fwd")
+        ctx.save_for_backward(attn)
+        ctx.meta = (shapes, heads, levels, points, dt, both.dtype, both.shape, nq)
+        return loc, attn
+
+    @staticmethod
+    def backward(ctx, grad_loc, grad_attn):
+        (attn,) = ctx.saved_tensors
+        shapes, heads, levels, points, dt, dtype, shape, nq = ctx.meta
+        ss, _, _ = _geom(shapes)
+        grad_both = torch.empty(shape, dtype=dtype, device=attn.device)
+        gl, ga = grad_loc.contiguous().float(), grad_attn.contiguous().float()
+        rc = load().dskd_msda_prep_bwd(gl.data_ptr(), ga.data_ptr(), attn.data_ptr(), ss, grad_both.data_ptr(), nq, heads,
+                                       levels, points, dt, _stream(attn))
+        _check(rc, "dskd_msda_prep_bwd")
+        return grad_both, None, None, None, None, None
+
+
+def msda_prepare(both: torch.Tensor, reference_points: torch.Tensor, spatial_shapes, heads: int, levels: int,
+                 points: int):
+    """softmax of the attention logits + sampling locations from the projection output
+    (``both[..., :heads*L*P*2]`` offsets, the rest logits) and NON-differentiable reference
+    points [.., levels, 2]; one launch each way instead of the module's elementwise chain
+    (ext-mmcv MultiScaleDeformableAttention.forward).  Returns (loc, attn) in f32."""
+    f = _dispatch_cpu("msda_prepare", both)
+    if f is not None:
+        return f(both, reference_points, spatial_shapes, heads, levels, points)
+    shapes = tuple((int(h), int(w)) for h, w in spatial_shapes)
+    return _MSDAPrepFunction.apply(both, reference_points, shapes, heads, levels, points)
 
 
 # --------------------------------------------------------------------------- LSAP

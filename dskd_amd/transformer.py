@@ -260,24 +260,30 @@ class MultiScaleDeformableAttention(nn.Module):
             w_cat = torch.cat([so.weight, aw.weight], 0)
             b_cat = torch.cat([so.bias, aw.bias], 0)
         both = tall_linear(query, w_cat, b_cat)
-        sampling_offsets = both[..., :n_off].float().view(
-            bs, num_query, self.num_heads, self.num_levels, self.num_points, 2)
-        attention_weights = both[..., n_off:].float().view(
-            bs, num_query, self.num_heads, self.num_levels * self.num_points)
-        attention_weights = attention_weights.softmax(-1).view(
-            bs, num_query, self.num_heads, self.num_levels, self.num_points)
-        if reference_points.shape[-1] == 2:
-            key = (tuple(map(tuple, shapes)), sampling_offsets.device)
-            if getattr(self, "_norm_key", None) != key:      # constant per geometry: build once
-                self._norm_key, self._norm = key, sampling_offsets.new_tensor([[w, h] for h, w in shapes])
-            normalizer = self._norm
-            sampling_locations = reference_points[:, :, None, :, None, :].float() \
-                + sampling_offsets / normalizer[None, None, None, :, None, :]
-        elif reference_points.shape[-1] == 4:
-            sampling_locations = reference_points[:, :, None, :, None, :2] \
-                + sampling_offsets / self.num_points * reference_points[:, :, None, :, None, 2:] * 0.5
+        if reference_points.shape[-1] == 2 and not reference_points.requires_grad and \
+                self.num_levels * self.num_points == 16 and self.num_levels <= 4:
+            # encoder: softmax + location arithmetic in one HIP pass each way
+            sampling_locations, attention_weights = native.msda_prepare(
+                both, reference_points, shapes, self.num_heads, self.num_levels, self.num_points)
         else:
-            raise ValueError(f"Last dim of reference_points must be 2 or 4, but get {reference_points.shape[-1]}")
+            sampling_offsets = both[..., :n_off].float().view(
+                bs, num_query, self.num_heads, self.num_levels, self.num_points, 2)
+            attention_weights = both[..., n_off:].float().view(
+                bs, num_query, self.num_heads, self.num_levels * self.num_points)
+            attention_weights = attention_weights.softmax(-1).view(
+                bs, num_query, self.num_heads, self.num_levels, self.num_points)
+            if reference_points.shape[-1] == 2:
+                key = (tuple(map(tuple, shapes)), sampling_offsets.device)
+                if getattr(self, "_norm_key", None) != key:      # constant per geometry: build once
+                    self._norm_key, self._norm = key, sampling_offsets.new_tensor([[w, h] for h, w in shapes])
+                normalizer = self._norm
+                sampling_locations = reference_points[:, :, None, :, None, :].float() \
+                    + sampling_offsets / normalizer[None, None, None, :, None, :]
+            elif reference_points.shape[-1] == 4:
+                sampling_locations = reference_points[:, :, None, :, None, :2] \
+                    + sampling_offsets / self.num_points * reference_points[:, :, None, :, None, 2:] * 0.5
+            else:
+                raise ValueError(f"Last dim of reference_points must be 2 or 4, but get {reference_points.shape[-1]}")
         output = native.ms_deform_attn(value, shapes, sampling_locations, attention_weights)
         output = self.output_proj(output)
         if not q_bf:

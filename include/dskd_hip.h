@@ -89,6 +89,21 @@ int dskd_msda_bwd(const void* value, const int64_t* spatial_shapes,
                   float* grad_attn, int B, int Nv, int Nq, int heads, int ch,
                   int levels, int points, int dtype, void* stream);
 
+/* Prologue / epilogue of the MultiScaleDeformableAttention module around the sampling op
+ * (what ext-mmcv's module does in PyTorch between its Linear layers and the CUDA op):
+ *   attn = softmax over levels*points of the logits;  loc = ref + offsets / (W_l, H_l).
+ * both    device, [n_query, heads*16*3] f32|bf16: offsets [heads,16,2] then logits [heads,16]
+ * ref     device, [n_query, levels, 2] f32;   loc/attn device f32 outputs (layouts as above)
+ * Requires levels*points == 16, levels <= 4.  n_query = B*Nq. */
+int dskd_msda_prep_fwd(const void* both, const float* ref, const int64_t* spatial_shapes,
+                       float* loc, float* attn, int64_t n_query, int heads, int levels,
+                       int points, int dtype, void* stream);
+/* Backward of the above: grad_both (same dtype/layout as both) from grad_loc, grad_attn and
+ * the saved attn.  reference points get no gradient from this entry point. */
+int dskd_msda_prep_bwd(const float* grad_loc, const float* grad_attn, const float* attn,
+                       const int64_t* spatial_shapes, void* grad_both, int64_t n_query,
+                       int heads, int levels, int points, int dtype, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Rectangular linear sum assignment, bit-exact with scipy 1.15.3
  * `linear_sum_assignment` (shortest augmenting path, Crouse 2016), including

@@ -12,6 +12,17 @@ class OracleChecker:
     def ms_deform_attn(self, value, spatial_shapes, loc, attn):
         return msda_ref.msda_grid_sample(value.float(), spatial_shapes, loc.float(), attn.float()).to(value.dtype)
 
+    def msda_prepare(self, both, ref, shapes, heads, levels, points):
+        """The module's own elementwise chain (ext-mmcv MultiScaleDeformableAttention.forward)."""
+        lead = both.shape[:-1]
+        n_off = heads * levels * points * 2
+        off = both[..., :n_off].float().view(*lead, heads, levels, points, 2)
+        logits = both[..., n_off:].float().view(*lead, heads, levels * points)
+        attn = logits.softmax(-1).view(*lead, heads, levels, points)
+        norm = off.new_tensor([[w, h] for h, w in shapes])
+        loc = ref.float()[..., None, :, None, :] + off / norm[None, :, None, :]
+        return loc, attn
+
     def match_cost(self, bbox_pred, cls_pred, gt_bboxes, gt_labels, gt_start, img_wh, w_cls, w_reg, w_iou):
         P, Q, _ = bbox_pred.shape
         out = []

@@ -166,6 +166,32 @@ def test_msda_bwd_windowed_matches_plain_atomics_full_size(monkeypatch):
     torch.testing.assert_close(gv2.sum(dim=(1,)), gv1.sum(dim=(1,)), atol=5e-2, rtol=1e-3)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_msda_prepare_vs_module_chain(dtype, oracle_checker):
+    """softmax + location prologue kernel (and its backward) against the module's PyTorch chain."""
+    g = torch.Generator().manual_seed(17)
+    B, Nq = 2, 437
+    shapes = [(25, 42), (13, 21), (7, 11), (4, 6)]
+    both = (torch.randn(B, Nq, 384, generator=g) * 2).to(dtype)
+    ref = torch.rand(B, Nq, 4, 2, generator=g)
+    gl = torch.randn(B, Nq, 8, 4, 4, 2, generator=g)
+    ga = torch.randn(B, Nq, 8, 4, 4, generator=g)
+    bc = both.clone().requires_grad_(True)
+    loc_r, attn_r = oracle_checker.msda_prepare(bc, ref, shapes, 8, 4, 4)
+    (loc_r * gl).sum().backward(retain_graph=True)
+    g1 = bc.grad.clone()
+    bc.grad = None
+    (attn_r * ga).sum().backward()
+    g2 = bc.grad.clone()
+    bd = both.to(DEV).requires_grad_(True)
+    loc, attn = native.msda_prepare(bd, ref.to(DEV), shapes, 8, 4, 4)
+    torch.testing.assert_close(loc.cpu(), loc_r.detach(), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(attn.cpu(), attn_r.detach(), rtol=1e-5, atol=1e-7)
+    ((loc * gl.to(DEV)).sum() + (attn * ga.to(DEV)).sum()).backward()
+    tol = dict(rtol=1e-5, atol=1e-6) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-3)
+    torch.testing.assert_close(bd.grad.float().cpu(), (g1 + g2).float(), **tol)
+
+
 # ----------------------------------------------------------------------------- LSAP
 def _lsap_device(mats):
     flat = torch.cat([torch.from_numpy(m).reshape(-1) for m in mats]).to(DEV)
