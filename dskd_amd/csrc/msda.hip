@@ -118,6 +118,8 @@ __device__ __forceinline__ void point_params(float lx_n, float ly_n, float a, in
 // NOTE: __builtin_bit_cast applied directly to a vector ELEMENT lvalue (v.y, v[1]) reads
 // element 0 with this compiler (hipcc 7.2); always go through a scalar by-value helper.
 __device__ __forceinline__ float as_f32(unsigned u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ int as_i32(float f) { return __builtin_bit_cast(int, f); }
+using i32x2 = __attribute__((ext_vector_type(2))) int;
 
 __device__ __forceinline__ void unpack_bf16x8(const u32x4& v, float* f) {
   f[0] = as_f32(v.x << 16);
@@ -327,7 +329,6 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_kernel(
         unpack_bf16x8(t, go);
       }
     }
-    const size_t gbase = (((size_t)b * Nq + (qv ? q : 0)) * kHeads + h) * (size_t)LP;
     for (int s = 0; s < LP; ++s) {
       const i32x4 o = s_off[myslot + s];
       const f32x4 w = s_wt[myslot + s];
@@ -350,8 +351,11 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_kernel(
       } else {
         d0 = group4_sum(d0); d1 = group4_sum(d1); d2 = group4_sum(d2); d3 = group4_sum(d3);
       }
-      // one lane of the group writes this sample's gradients
-      if (qv && part == (s & (TR::LPH - 1))) {
+      // One lane of the group finishes this sample's gradients and parks them in the sample's
+      // (now dead) aux slot; they leave for HBM after the loop as coalesced rows.  Per-lane
+      // 4-/8-byte stores from here measured 3.9x write amplification (WRITE_SIZE 525 MB for
+      // 136 MB of gradients at B=4).
+      if (part == (s & (TR::LPH - 1))) {
         const float lx = ax.x, ly = ax.y, a = ax.z;
         const int lvl = (int)ax.w;
         const i32x4 lt = s_lvl[lvl];
@@ -360,8 +364,23 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_kernel(
         const float ga = w.x * d0 + w.y * d1 + w.z * d2 + w.w * d3;
         const float gx = Wf * a * (hy * (d1 - d0) + ly * (d3 - d2));
         const float gy = Hf * a * (hx * (d2 - d0) + lx * (d3 - d1));
-        grad_attn[gbase + s] = ga;
-        *reinterpret_cast<f32x2*>(grad_loc + (gbase + s) * 2) = f32x2{gx, gy};
+        s_aux[myslot + s] = f32x4{gx, gy, a, ga};   // .z (attn) stays for the scatter phase
+      }
+    }
+    wave_lds_sync();
+    {
+      const int npts = TR::QPW * kHeads * LP;
+      for (int pi = lane; pi < npts; pi += 64) {
+        const int qs2 = pi / (kHeads * LP);
+        const int r = pi - qs2 * (kHeads * LP);
+        const int h2 = r / LP;
+        const int q2 = q0 + qs2;
+        if (q2 < q_end) {
+          const f32x4 res = s_aux[(qs2 * kHeads + h2) * kHeadStride + (r - h2 * LP)];
+          const size_t base = ((size_t)b * Nq + q2) * (size_t)(kHeads * LP) + r;
+          grad_attn[base] = res.w;
+          *reinterpret_cast<f32x2*>(grad_loc + base * 2) = f32x2{res.x, res.y};
+        }
       }
     }
 
@@ -413,36 +432,34 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_kernel(
 // local.  v1 above pays one global float atomic per (corner, channel): 1.46 GB of atomic bytes
 // per image and call against a chip-wide rate of ~1.3 TB/s (MI355X_MICROARCH.md "Global float
 // atomics") -> ~1.04 ms per image, 10x everything else in this op, with thousands of adders
-// per row on the coarse levels.  Here a workgroup owns a REGION of the image (32x32 level-0
-// pixels, the queries of all four levels whose centre falls inside it), one head and an
-// 8-channel slice, and accumulates into LDS windows (region footprint + margin on every
-// level, ~116 KB); only the windows' non-zero entries reach HBM as atomics (~20x fewer atomic
-// bytes).  Samples that leave the window (large learned offsets) fall back to a direct global
+// per row on the coarse levels.  Here a workgroup owns a REGION of the image (<= 32x32 level-0
+// pixels, the queries of all four levels whose centre falls inside it), one head and a
+// 16- or 32-channel group, and accumulates into LDS windows (region footprint + margin on
+// the levels it handles, ~100 KB); only the windows' non-zero entries reach HBM as atomics
+// (~20x fewer atomic bytes).  Samples that leave the window (large learned offsets) fall back to a direct global
 // atomic, so the result is correct for ANY sampling locations.
 //  * LDS float atomics are not usable for this on gfx950: measured (scratch/ubench/
 //    lds_atomics.hip) ds_add_f32 = 193 cycles per wave instruction per CU against 5.2 for
 //    ds_add_u32 -- the f32 form is serialised per lane.  The windows therefore accumulate in
 //    32-bit FIXED POINT with integer atomics: scale = 2^30 / (max|grad_out| * sum|attn|) over
 //    the workgroup's own queries (a proven bound of any cell's magnitude, so no overflow),
-//    i.e. >= 19 bits below that bound per contribution at 1360 queries; the sum itself is
+//    i.e. >= 19 bits below that bound per contribution at ~1000 queries; the sum itself is
 //    exact, hence independent of the arrival order (bitwise reproducible inside a window).
-//  * lane = (point parity, corner, channel): ONE ds_add per two sampling points, and with the
-//    window width == 2 (mod 4) and the channel-plane stride == 4 (mod 32) the 32 lanes of a
-//    half-wave (4 corners x 8 channels) hit 32 distinct banks: conflict-free.
+//  * lane = (point parity, corner, channel lane): ONE ds_add per two sampling points and
+//    channel, and with the window width == 2 (mod 4) and the channel-plane stride == 4 (mod 32)
+//    the 32 lanes of a half-wave (4 corners x 8 channel lanes) hit 32 distinct banks.
 //  * the per-point arithmetic (floor, weights, window address) is done once per point by one
 //    lane and broadcast through the wave's LDS slice.
-constexpr int kRegion = 32;     // region edge, level-0 pixels
+constexpr int kRegion = 32;     // largest region edge, level-0 pixels (edges are balanced: ceil(S0 / ceil(S0/32)))
 constexpr int kMarginLo = 5;    // window margin below / above the region footprint
 constexpr int kMarginHi = 6;
-constexpr int kSlice = 8;       // channels per workgroup
-constexpr int kVWaves = 16;
 constexpr int kMaxReg = 16;     // regions per axis
 constexpr int kSkip = 0x7FFFFFF0;
 
 struct ValueGeom {
   int H[kMaxLevels], W[kMaxLevels], start[kMaxLevels];
-  int ww[kMaxLevels], wh[kMaxLevels], base[kMaxLevels];
-  int NP, npos, RX, RY, levels;
+  int ww[kMaxLevels], wh[kMaxLevels];
+  int RX, RY, EX, EY, levels;
 };
 
 // floor(x + 0.5) in ONE VALU instruction (v_cvt_rpi_i32_f32; checked on gfx950).  Plain
@@ -459,227 +476,322 @@ __host__ __device__ inline int floor_div(int a, int b) {  // b > 0
   return (a % b != 0 && a < 0) ? q - 1 : q;
 }
 
-__device__ __forceinline__ int win_origin(int r, int Sl, int S0) {
-  // floor(r * kRegion * Sl / S0 - 0.5) - margin, in exact integer arithmetic
-  return floor_div(2 * kRegion * r * Sl - S0, 2 * S0) - kMarginLo;
+// Region r of an axis (edge E level-0 pixels, finest extent S0) on a level of extent Sl:
+//  * the query x belongs to region floor(((2x+1) * S0) / (2 * Sl)) / E, so its query range starts
+//    at ceil((2 * E * r * Sl - S0) / (2 * S0)), clamped to [0, Sl];
+//  * its window starts at floor(r * E * Sl / S0 - 0.5) - kMarginLo.
+// Both are evaluated in exact integer arithmetic in the kernel prologue.
+
+// Global query index of the qi-th query of a region (queries ordered level by level, row by row
+// inside the region's footprint on that level); rows of the lookup table as filled below.
+__device__ __forceinline__ int region_query(const i32x4* s_tab, const int* cum, int qi) {
+  int lq = 0;
+#pragma unroll
+  for (int l = 1; l < kMaxLevels; ++l) lq += qi >= cum[l];
+  const i32x4 qa = s_tab[4 * lq], qb = s_tab[4 * lq + 1];
+  const int rem = qi - qa.x;
+  // exact: the fractional part of (rem + 0.5) / dx is at least 0.5/dx away from an integer
+  const int yy = (int)(((float)rem + 0.5f) * as_f32((unsigned)qb.x));
+  return qb.y + (qa.z + yy) * qb.z + qa.y + (rem - yy * qa.w);
 }
 
-// First query coordinate of region r on a level of extent Sl (finest level S0): the query x
-// belongs to region floor(((2x+1) * S0) / (2 * Sl)) / kRegion, so the range starts at
-// ceil((2 * kRegion * r * Sl - S0) / (2 * S0)), clamped to [0, Sl].
-__host__ __device__ inline int region_begin(int r, int Sl, int S0) {
-  const int v = floor_div(2 * kRegion * r * Sl - S0 + 2 * S0 - 1, 2 * S0);
-  return v < 0 ? 0 : (v > Sl ? Sl : v);
+// One launch per LEVEL GROUP (variant).  A workgroup owns (image, region, head, channel group)
+// and only the sampling points of its levels, so the per-point arithmetic (floor, bilinear
+// weights, window address) is done 20 times per (query, head) over the three launches instead
+// of 64 with one 8-channel slice per workgroup.  At 100x167 / 50x84 / 25x42 / 13x21 (regions of
+// 25x28 level-0 pixels, all the same size so the workgroups of a launch are balanced):
+//   variant 0: level 0, 16 channels (two groups)    window 42x37        -> 100 KB, 16 waves
+//   variant 1: level 1, 32 channels                 window 30x25        ->  99 KB, 12 waves
+//   variant 2: levels 2+3, 32 channels              windows 22x19+18x16 ->  95 KB, 16 waves
+// The main loop is bound by the LDS pipeline: 2048 integer atomic lane-adds per (query, head)
+// = 32 ds_add_u32 wave instructions at ~5.2 cycles each, plus one 8-byte record read per K adds.
+struct VarGeom {
+  int lv0, nlv;              // first level, number of levels handled
+  int base[kMaxLevels];      // first window position of each handled level
+  int npos, NP;              // window positions, channel-plane stride (incl. 8 dummy slots)
+  int waves;                 // workgroup size in waves (host side only)
+};
+
+// NE (4 or 8) consecutive grad_out elements as floats, with vector loads (rows are 16-byte
+// aligned: 256 elements per (query) row, channel offsets multiples of NE)
+template <typename T, int NE>
+__device__ __forceinline__ void load_row(const T* p, float* f) {
+  if constexpr (sizeof(T) == 4) {
+#pragma unroll
+    for (int k = 0; k < NE / 4; ++k) {
+      const f32x4 v = reinterpret_cast<const f32x4*>(p)[k];
+      f[4 * k] = v.x; f[4 * k + 1] = v.y; f[4 * k + 2] = v.z; f[4 * k + 3] = v.w;
+    }
+  } else if constexpr (NE == 8) {
+    unpack_bf16x8(*reinterpret_cast<const u32x4*>(p), f);
+  } else {
+    const i32x2 v = *reinterpret_cast<const i32x2*>(p);
+    const unsigned lo = (unsigned)v.x, hi = (unsigned)v.y;
+    f[0] = as_f32(lo << 16); f[1] = as_f32(lo & 0xFFFF0000u);
+    f[2] = as_f32(hi << 16); f[3] = as_f32(hi & 0xFFFF0000u);
+  }
 }
 
-template <typename T>
-__global__ __launch_bounds__(kVWaves * 64) void msda_bwd_value_kernel(
+#ifdef DSKD_VALUE_PROFILE
+__device__ unsigned long long g_vprof[64];
+#define VPROF(slot) do { if (tid == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&g_vprof[vg.lv0 * 8 + (slot)], t_ - t_prev); t_prev = t_; } } while (0)
+#else
+#define VPROF(slot)
+#endif
+
+template <typename T, int NCH, int PPQ, int NW>
+__global__ __launch_bounds__(NW * 64) void msda_bwd_value_kernel(
     const float* __restrict__ loc, const float* __restrict__ attn,
-    const T* __restrict__ grad_out, float* __restrict__ grad_value, ValueGeom g, int Nq,
-    int LP, int points) {
+    const T* __restrict__ grad_out, float* __restrict__ grad_value, ValueGeom g, VarGeom vg,
+    int Nq, int LP, int points) {
+  constexpr int NQW = 64 / PPQ;           // queries per wave pass
+  constexpr int NG = kCh / NCH;           // channel groups per head
   extern __shared__ float smem[];
-  int* win = reinterpret_cast<int*>(smem);                     // [kSlice][NP] fixed point
-  int* s_off = win + kSlice * g.NP;                            // [waves][64][4]
-  float* s_w = reinterpret_cast<float*>(s_off + kVWaves * 64 * 4);
-  int* s_q = reinterpret_cast<int*>(s_w + kVWaves * 64 * 4);   // [waves][4]
-  float* s_red = reinterpret_cast<float*>(s_q + kVWaves * 4);  // [2 * waves] block reductions
-  float* s_g = s_red + 2 * kVWaves;                            // [waves][4][8] scaled grad_out
-  int* s_fb = reinterpret_cast<int*>(s_g + kVWaves * 32);      // [waves] fallback flag
-  i32x4* s_tab = reinterpret_cast<i32x4*>(s_fb + kVWaves);     // [4][4] per-level lookup rows (16-B aligned)
+  int* win = reinterpret_cast<int*>(smem);                              // [NCH][NP] fixed point
+  int* s_rec = win + NCH * vg.NP;                                       // [waves][64][4]{off, w}
+  float* s_g = reinterpret_cast<float*>(s_rec + NW * 64 * 8);           // [waves][NQW][NCH]
+  float* s_red = s_g + NW * NQW * NCH;                             // [2 * waves]
+  i32x4* s_tab = reinterpret_cast<i32x4*>(s_red + 2 * NW);              // [4][4] lookup rows
+  int* s_geo = reinterpret_cast<int*>(s_tab + 4 * kMaxLevels);     // [24] region geometry
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef DSKD_VALUE_PROFILE
+  unsigned long long t_prev = wall_clock64();
+#endif
 
   int vb = xcd_remap(blockIdx.x, gridDim.x);
-  const int hs = vb & 31;          // (head, slice): the 32 workgroups of a region are adjacent
-  vb >>= 5;
+  const int cg = vb % NG; vb /= NG;
+  const int h = vb & 7; vb >>= 3;
   const int rx = vb % g.RX; vb /= g.RX;
   const int ry = vb % g.RY;
   const int b = vb / g.RY;
-  const int h = hs >> 2, slice = hs & 3;
-  const int chbase = h * kCh + slice * kSlice;
+  const int chbase = h * kCh + cg * NCH;
 
-  // queries of this region, per level
-  int cum[kMaxLevels + 1], qxa[kMaxLevels], qdx[kMaxLevels], qya[kMaxLevels];
-  int wx0[kMaxLevels], wy0[kMaxLevels];
-  cum[0] = 0;
+  // Region geometry.  The 24 integer divisions behind it (4 levels x {query range begin / end
+  // in x and y, window origin in x and y}) run on 24 lanes of wave 0 at once instead of 24 times
+  // in sequence on every wave; the rows of the lookup table are built from the results.
+  //   s_tab[4l+0] = {cum, qxa, qya, qdx}   [4l+1] = {1/qdx, start, W, H}
+  //   s_tab[4l+2] = {ww, wh, wx0, wy0}     [4l+3] = {window base, nq, 0, 0}
+  if (wave == 0) {
+    if (lane < 6 * kMaxLevels) {
+      const int l = lane / 6, kind = lane - 6 * l;   // 0,1: x begin/end  2,3: y begin/end  4,5: origin x/y
+      const bool xaxis = kind == 0 || kind == 1 || kind == 4;
+      int Sl = 1;
 #pragma unroll
-  for (int l = 0; l < kMaxLevels; ++l) {
-    const bool on = l < g.levels;
-    qxa[l] = region_begin(rx, g.W[l], g.W[0]);
-    qya[l] = region_begin(ry, g.H[l], g.H[0]);
-    qdx[l] = on ? region_begin(rx + 1, g.W[l], g.W[0]) - qxa[l] : 0;
-    const int dy = on ? region_begin(ry + 1, g.H[l], g.H[0]) - qya[l] : 0;
-    cum[l + 1] = cum[l] + qdx[l] * dy;
-    wx0[l] = win_origin(rx, g.W[l], g.W[0]);
-    wy0[l] = win_origin(ry, g.H[l], g.H[0]);
-  }
-  const int nq = cum[kMaxLevels];
-  float qinv[kMaxLevels];
-#pragma unroll
-  for (int l = 0; l < kMaxLevels; ++l) qinv[l] = 1.0f / (float)(qdx[l] > 0 ? qdx[l] : 1);
-
-  // lookup rows per level l: [4l+0] = {cum, qxa, qya, qdx}   [4l+1] = {1/qdx, start, W, H}
-  //                           [4l+2] = {ww, wh, wx0, wy0}     [4l+3] = {base, 0, 0, 0}
-#pragma unroll
-  for (int l = 0; l < kMaxLevels; ++l)
-    if (tid == l) {
-      s_tab[4 * l + 0] = i32x4{cum[l], qxa[l], qya[l], qdx[l]};
-      s_tab[4 * l + 1] = i32x4{__builtin_bit_cast(int, qinv[l]), g.start[l], g.W[l], g.H[l]};
-      s_tab[4 * l + 2] = i32x4{g.ww[l], g.wh[l], wx0[l], wy0[l]};
-      s_tab[4 * l + 3] = i32x4{g.base[l], 0, 0, 0};
+      for (int k = 0; k < kMaxLevels; ++k)
+        if (l == k) Sl = xaxis ? g.W[k] : g.H[k];
+      const int S0 = xaxis ? g.W[0] : g.H[0], E = xaxis ? g.EX : g.EY;
+      const int r = (xaxis ? rx : ry) + ((kind == 1 || kind == 3) ? 1 : 0);
+      const int q = floor_div(2 * E * r * Sl - S0 + (kind < 4 ? 2 * S0 - 1 : 0), 2 * S0);
+      s_geo[lane] = kind < 4 ? (q < 0 ? 0 : (q > Sl ? Sl : q)) : q - kMarginLo;   // region_begin | win_origin
     }
-  for (int i = tid * 4; i < kSlice * g.NP; i += kVWaves * 64 * 4)
+    wave_lds_sync();
+    int tot = 0, mine = 0;
+#pragma unroll
+    for (int k = 0; k < kMaxLevels; ++k) {
+      if (k == lane) mine = tot;
+      if (k < g.levels) tot += (s_geo[6 * k + 1] - s_geo[6 * k]) * (s_geo[6 * k + 3] - s_geo[6 * k + 2]);
+    }
+#pragma unroll
+    for (int l = 0; l < kMaxLevels; ++l)
+      if (lane == l) {
+        const int qxa = s_geo[6 * l], qya = s_geo[6 * l + 2];
+        const int qdx = l < g.levels ? s_geo[6 * l + 1] - qxa : 0;
+        s_tab[4 * l + 0] = i32x4{mine, qxa, qya, qdx};
+        s_tab[4 * l + 1] = i32x4{as_i32(1.0f / (float)(qdx > 0 ? qdx : 1)), g.start[l], g.W[l], g.H[l]};
+        s_tab[4 * l + 2] = i32x4{g.ww[l], g.wh[l], s_geo[6 * l + 4], s_geo[6 * l + 5]};
+        s_tab[4 * l + 3] = i32x4{vg.base[l], tot, 0, 0};
+      }
+  }
+  for (int i = tid * 4; i < NCH * vg.NP; i += NW * 64 * 4)
     *reinterpret_cast<i32x4*>(win + i) = i32x4{0, 0, 0, 0};
   __syncthreads();
+  int cum[kMaxLevels];
+#pragma unroll
+  for (int l = 0; l < kMaxLevels; ++l) cum[l] = s_tab[4 * l].x;
+  const int nq = s_tab[3].y;
 
+  VPROF(0);
   float* gvb = grad_value + (size_t)b * Nq * (kHeads * kCh) + chbase;
   const T* gob = grad_out + (size_t)b * Nq * (kHeads * kCh) + chbase;
+  const int s_first = vg.lv0 * points;          // first of the PPQ sample indices handled here
 
-  // ---- fixed-point scale: bound of any window cell = max|grad_out| * sum|attn| over the region
+  // ---- fixed-point scale: bound of any window cell = max|grad_out| * sum|attn| over the
+  // region's queries (this channel group, these levels)
   float gmax = 0.f, asum = 0.f;
-  for (int i = tid; i < nq * kSlice; i += kVWaves * 64) {
-    const int qi = i >> 3;
-    int lq = 0;
+  for (int i0 = tid; i0 < nq * (NCH / 8); i0 += 4 * NW * 64) {   // 8 channels per lane and step,
+#pragma unroll                                                    // 4 steps of loads in flight
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * NW * 64;
+      const bool ok = i < nq * (NCH / 8);            // out of range: load element 0, ignore it
+      const int ii = ok ? i : 0;
+      const int qi = ii / (NCH / 8), c8 = ii - qi * (NCH / 8);
+      const int qg = region_query(s_tab, cum, qi);
+      float f[8];
+      load_row<T, 8>(gob + (size_t)qg * (kHeads * kCh) + c8 * 8, f);
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(
+          attn + (((size_t)b * Nq + qg) * kHeads + h) * (size_t)LP + s_first + (c8 < PPQ / 4 ? c8 : 0) * 4);
+      float m = 0.f;
 #pragma unroll
-    for (int l = 1; l < kMaxLevels; ++l) lq += qi >= cum[l];
-    const i32x4 qa = s_tab[4 * lq], qb = s_tab[4 * lq + 1];
-    const int rem = qi - qa.x;
-    const int yy = (int)(((float)rem + 0.5f) * as_f32((unsigned)qb.x));
-    const int qg = qb.y + (qa.z + yy) * qb.z + qa.y + (rem - yy * qa.w);
-    gmax = fmaxf(gmax, fabsf((float)gob[(size_t)qg * (kHeads * kCh) + (i & 7)]));
-    const float* ap = attn + (((size_t)b * Nq + qg) * kHeads + h) * (size_t)LP;
-    for (int s2 = (i & 7); s2 < LP; s2 += kSlice) asum += fabsf(ap[s2]);
+      for (int k = 0; k < 8; ++k) m = fmaxf(m, fabsf(f[k]));
+      gmax = ok ? fmaxf(gmax, m) : gmax;
+      asum += (ok && c8 < PPQ / 4) ? fabsf(a4.x) + fabsf(a4.y) + fabsf(a4.z) + fabsf(a4.w) : 0.f;
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     gmax = fmaxf(gmax, __shfl_xor(gmax, o));
     asum += __shfl_xor(asum, o);
   }
-  if (lane == 0) { s_red[wave] = gmax; s_red[kVWaves + wave] = asum; }
+  if (lane == 0) { s_red[wave] = gmax; s_red[NW + wave] = asum; }
   __syncthreads();
   gmax = 0.f; asum = 0.f;
 #pragma unroll
-  for (int w2 = 0; w2 < kVWaves; ++w2) { gmax = fmaxf(gmax, s_red[w2]); asum += s_red[kVWaves + w2]; }
+  for (int w2 = 0; w2 < NW; ++w2) { gmax = fmaxf(gmax, s_red[w2]); asum += s_red[NW + w2]; }
   const float bound = gmax * asum;
+  VPROF(1);
   if (bound == 0.f) return;   // nothing to scatter from this region (uniform across the workgroup)
   // NaN / inf gradients: accumulate nothing here and let them through the float fallback below
   const bool fx_ok = bound > 0.f && bound < 3.0e38f;
   const float fx_scale = fx_ok ? 1.0e9f / bound : 0.f;        // 1e9 < 2^30: headroom for rounding
   const float fx_inv = fx_ok ? bound * 1.0e-9f : 0.f;
-  int* my_off = s_off + wave * 64 * 4;
-  float* my_w = s_w + wave * 64 * 4;
-  int* my_q = s_q + wave * 4;
-  float* my_g = s_g + wave * 32;
-  const int half = lane >> 5, corner = (lane >> 3) & 3, ch = lane & 7;
-  char* win_ch = reinterpret_cast<char*>(win + ch * g.NP);
-  const unsigned dummy = (unsigned)(g.npos + corner + 4 * half) * 4u;   // 8 spare slots per channel plane
 
-  for (int qbase = wave * 4; qbase < nq; qbase += kVWaves * 4) {
-    // ---- phase 1: one lane per sampling point (4 queries x 16 points)
+  int* my_rec = s_rec + wave * 64 * 8;
+  float* my_g = s_g + wave * NQW * NCH;
+  // phase-2 lane roles: (point parity, corner, channel lane); a lane owns the K channels
+  // cl + 8k, so ONE 8-byte record read feeds K ds_add.  A half-wave is one point x 4 corners x
+  // 8 channel lanes: window width == 2 (mod 4) spreads the corners over the 4 bank residues,
+  // plane stride == 4 (mod 32) spreads the channel lanes -> 32 distinct banks.
+  constexpr int K = NCH / 8;
+  const int pp = lane >> 5, crn = (lane >> 3) & 3, cl = lane & 7;
+  char* win_cl = reinterpret_cast<char*>(win + cl * vg.NP);
+  const int plane8 = vg.NP * 32;                  // bytes between channel planes cl and cl + 8
+  const unsigned dummy = (unsigned)(vg.npos + crn + 4 * pp) * 4u;
+  const int* rec_lane = my_rec + pp * 8 + crn * 2;
+
+  // Software pipeline: the global loads of pass i+1 (sampling location, attention weight and
+  // the query's grad_out slice) are issued before phase 2 of pass i, so their latency overlaps
+  // the LDS work instead of heading every pass.
+  constexpr int NE = NCH / PPQ;   // grad_out channels staged per lane
+  f32x2 n_xy = f32x2{0.f, 0.f};
+  float n_a = 0.f, n_g[NE];
+  int n_qg = -1;
+  auto fetch = [&](int qbase) {
+    const int qi = qbase + lane / PPQ;
+    n_qg = -1;
+    if (qi < nq) {
+      n_qg = region_query(s_tab, cum, qi);
+      const size_t base = (((size_t)b * Nq + n_qg) * kHeads + h) * (size_t)LP + s_first + (lane & (PPQ - 1));
+      n_xy = *reinterpret_cast<const f32x2*>(loc + base * 2);
+      n_a = attn[base];
+      load_row<T, NE>(gob + (size_t)n_qg * (kHeads * kCh) + (lane & (PPQ - 1)) * NE, n_g);
+    }
+  };
+  fetch(wave * NQW);
+
+  for (int qbase = wave * NQW; qbase < nq; qbase += NW * NQW) {
+    unsigned long long fbmask;   // points of this pass that left the window
+    // ---- phase 1: one lane per sampling point (NQW queries x PPQ points)
     {
-      const int qi = qbase + (lane >> 4);
-      const int s = lane & 15;
-      // LDS byte offsets; kSkip (and the negative fallback codes) are clamped onto the
-      // consumer lane's dummy slot by an unsigned min in phase 2
+      const int s = s_first + (lane & (PPQ - 1));
+      // LDS byte offsets; kSkip (and the negative fallback codes) are clamped onto the consumer
+      // lane's dummy slot by an unsigned min in phase 2
       i32x4 off = i32x4{kSkip, kSkip, kSkip, kSkip};
       f32x4 w = f32x4{0.f, 0.f, 0.f, 0.f};
       bool is_fb = false;
-      int qg = -1;
-      if (qi < nq) {
-        int lq = 0;
-#pragma unroll
-        for (int l = 1; l < kMaxLevels; ++l) lq += qi >= cum[l];
-        const i32x4 qa = s_tab[4 * lq], qb = s_tab[4 * lq + 1];
-        const int rem = qi - qa.x;
-        const int xa = qa.y, ya = qa.z, dx = qa.w;
-        // exact: the fractional part of (rem + 0.5) / dx is at least 0.5/dx away from an integer
-        const int yy = (int)(((float)rem + 0.5f) * as_f32((unsigned)qb.x));
-        qg = qb.y + (ya + yy) * qb.z + xa + (rem - yy * dx);
-        if (s < LP) {
-          const size_t base = (((size_t)b * Nq + qg) * kHeads + h) * (size_t)LP + s;
-          const f32x2 xy = *reinterpret_cast<const f32x2*>(loc + base * 2);
-          const float a = attn[base];
-          const int lvl = points == 4 ? s >> 2 : s / points;
-          const i32x4 lb = s_tab[4 * lvl + 1], lc = s_tab[4 * lvl + 2];
-          const int H = lb.w, W = lb.z, st = lb.y;
-          const float x = xy.x * (float)W - 0.5f;
-          const float y = xy.y * (float)H - 0.5f;
-          if (x > -1.f && y > -1.f && x < (float)W && y < (float)H) {
-            const float xf = floorf(x), yf = floorf(y);
-            const int x0 = (int)xf, y0 = (int)yf;
-            const float lx = x - xf, ly = y - yf, hx = 1.f - lx, hy = 1.f - ly;
-            const bool vx0 = x0 >= 0, vx1 = x0 + 1 <= W - 1, vy0 = y0 >= 0, vy1 = y0 + 1 <= H - 1;
-            w = f32x4{(vy0 && vx0) ? hy * hx * a : 0.f, (vy0 && vx1) ? hy * lx * a : 0.f,
-                      (vy1 && vx0) ? ly * hx * a : 0.f, (vy1 && vx1) ? ly * lx * a : 0.f};
-            const int wwl = lc.x, whl = lc.y;
-            const int wx = x0 - lc.z, wy = y0 - lc.w;
-            if (fx_ok && wx >= 0 && wx + 1 < wwl && wy >= 0 && wy + 1 < whl) {
-              const int pb = (s_tab[4 * lvl + 3].x + wy * wwl + wx) * 4;
-              off = i32x4{pb, pb + 4, pb + wwl * 4, pb + wwl * 4 + 4};
-            } else {  // outside the LDS window: direct global atomics, rows encoded as -(2+row)
-              const int r00 = st + y0 * W + x0;
-              off = i32x4{(vy0 && vx0) ? -(2 + r00) : -1, (vy0 && vx1) ? -(2 + r00 + 1) : -1,
-                          (vy1 && vx0) ? -(2 + r00 + W) : -1, (vy1 && vx1) ? -(2 + r00 + W + 1) : -1};
-              is_fb = true;
-            }
+      const int qg = n_qg;
+      if (qg >= 0) {
+        const f32x2 xy = n_xy;
+        const float a = n_a;
+        const int lvl = s / points;
+        const i32x4 lb = s_tab[4 * lvl + 1], lc = s_tab[4 * lvl + 2];
+        const int H = lb.w, W = lb.z, st = lb.y;
+        const float x = xy.x * (float)W - 0.5f;
+        const float y = xy.y * (float)H - 0.5f;
+        if (x > -1.f && y > -1.f && x < (float)W && y < (float)H) {
+          const float xf = floorf(x), yf = floorf(y);
+          const int x0 = (int)xf, y0 = (int)yf;
+          const float lx = x - xf, ly = y - yf, hx = 1.f - lx, hy = 1.f - ly;
+          const bool vx0 = x0 >= 0, vx1 = x0 + 1 <= W - 1, vy0 = y0 >= 0, vy1 = y0 + 1 <= H - 1;
+          w = f32x4{(vy0 && vx0) ? hy * hx * a : 0.f, (vy0 && vx1) ? hy * lx * a : 0.f,
+                    (vy1 && vx0) ? ly * hx * a : 0.f, (vy1 && vx1) ? ly * lx * a : 0.f};
+          const int wwl = lc.x, whl = lc.y;
+          const int wx = x0 - lc.z, wy = y0 - lc.w;
+          if (fx_ok && wx >= 0 && wx + 1 < wwl && wy >= 0 && wy + 1 < whl) {
+            const int pb = (s_tab[4 * lvl + 3].x + wy * wwl + wx) * 4;
+            off = i32x4{pb, pb + 4, pb + wwl * 4, pb + wwl * 4 + 4};
+          } else {  // outside the LDS window: direct global atomics, rows encoded as -(2+row)
+            const int r00 = st + y0 * W + x0;
+            off = i32x4{(vy0 && vx0) ? -(2 + r00) : -1, (vy0 && vx1) ? -(2 + r00 + 1) : -1,
+                        (vy1 && vx0) ? -(2 + r00 + W) : -1, (vy1 && vx1) ? -(2 + r00 + W + 1) : -1};
+            is_fb = true;
           }
         }
       }
-      const bool any_fb = __any(is_fb);
-      *reinterpret_cast<i32x4*>(my_off + lane * 4) = off;
-      *reinterpret_cast<f32x4*>(my_w + lane * 4) = w;
-      if ((lane & 15) == 0) my_q[lane >> 4] = qg;
-      if ((lane & 15) < kSlice)   // stage the four queries' grad_out slice, pre-scaled
-        my_g[(lane >> 4) * kSlice + (lane & 7)] =
-            qg >= 0 ? (float)gob[(size_t)qg * (kHeads * kCh) + (lane & 7)] : 0.f;
-      if (lane == 0) s_fb[wave] = any_fb ? 1 : 0;
+      fbmask = __ballot(is_fb);
+      i32x4* rec = reinterpret_cast<i32x4*>(my_rec + lane * 8);   // {off0, w0, off1, w1} {off2, w2, off3, w3}
+      rec[0] = i32x4{off.x, as_i32(w.x), off.y, as_i32(w.y)};
+      rec[1] = i32x4{off.z, as_i32(w.z), off.w, as_i32(w.w)};
+      // the pass's grad_out rows (this channel group), NE channels per lane
+      float* gdst = my_g + (lane / PPQ) * NCH + (lane & (PPQ - 1)) * NE;
+#pragma unroll
+      for (int e = 0; e < NE; e += 4)
+        *reinterpret_cast<f32x4*>(gdst + e) = qg >= 0 ? f32x4{n_g[e], n_g[e + 1], n_g[e + 2], n_g[e + 3]}
+                                                       : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    fetch(qbase + NW * NQW);
     wave_lds_sync();
 
-    // ---- phase 2: lane = (point parity, corner, channel).  Every lane always adds (skipped
-    // and out-of-window corners are clamped onto a per-lane dummy slot by one unsigned min), so
-    // the loop is branch-free: per ds_add one LDS read, one multiply, one rounding convert, one
-    // address add.
+    // ---- phase 2: branch-free accumulation.  Per pair of points: one 8-byte LDS read
+    // {offset, weight}, one unsigned min (skipped / out-of-window corners land on the lane's
+    // dummy slot), and per channel one multiply, one rounding convert, one ds_add.
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      int offs[8];
-      float ws[8];
-      const float gs = my_g[k * kSlice + ch] * fx_scale;
+    for (int qk = 0; qk < NQW; ++qk) {
+      float gs[K];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int pt = 2 * (k * 8 + j) + half;
-        offs[j] = my_off[pt * 4 + corner];
-        ws[j] = my_w[pt * 4 + corner];
-      }
+      for (int k = 0; k < K; ++k) gs[k] = my_g[qk * NCH + cl + 8 * k] * fx_scale;
+      i32x2 r[PPQ / 2];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const unsigned o = min((unsigned)offs[j], dummy);
-        atomicAdd(reinterpret_cast<int*>(win_ch + o), cvt_round(ws[j] * gs));
+      for (int j = 0; j < PPQ / 2; ++j)
+        r[j] = *reinterpret_cast<const i32x2*>(rec_lane + (qk * PPQ + 2 * j) * 8);
+#pragma unroll
+      for (int j = 0; j < PPQ / 2; ++j) {
+        const unsigned o = min((unsigned)r[j].x, dummy);
+        const float wj = as_f32((unsigned)r[j].y);
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+          atomicAdd(reinterpret_cast<int*>(win_cl + k * plane8 + o), cvt_round(wj * gs[k]));
       }
     }
-    if (s_fb[wave]) {   // rare: samples that left the window -> direct global atomics
-      for (int it = 0; it < 32; ++it) {
-        const int pt = 2 * it + half;
-        const int o = my_off[pt * 4 + corner];
-        if (o <= -2)
-          atomicAdd(gvb + (size_t)(-(o + 2)) * (kHeads * kCh) + ch,
-                    my_w[pt * 4 + corner] * my_g[(it >> 3) * kSlice + ch]);
+    while (fbmask) {   // samples that left the window -> direct global atomics, point by point
+      const int pt = __builtin_ctzll(fbmask);
+      fbmask &= fbmask - 1;
+      const int o = my_rec[pt * 8 + crn * 2];
+      if (o <= -2) {
+        const float wj = as_f32((unsigned)my_rec[pt * 8 + crn * 2 + 1]);
+        for (int k = pp; k < K; k += 2)
+          atomicAdd(gvb + (size_t)(-(o + 2)) * (kHeads * kCh) + cl + 8 * k,
+                    wj * my_g[(pt / PPQ) * NCH + cl + 8 * k]);
       }
     }
     wave_lds_sync();
   }
+  VPROF(2);
   __syncthreads();
+  VPROF(3);
 
-  // ---- flush the non-zero window entries
-  for (int p = tid >> 3; p < g.npos; p += kVWaves * 8) {
-    const int iv = win[ch * g.NP + p];
+  // ---- flush the non-zero window entries: consecutive lanes = consecutive channels, so every
+  // global atomic instruction adds NCH*4-byte contiguous segments
+  const int ch = tid & (NCH - 1);
+  for (int p = tid / NCH; p < vg.npos; p += (NW * 64) / NCH) {
+    const int iv = win[ch * vg.NP + p];
     if (iv == 0) continue;
     const float v = (float)iv * fx_inv;
-    int l = 0;
+    int l = vg.lv0;
 #pragma unroll
-    for (int k = 1; k < kMaxLevels; ++k) l += (k < g.levels && p >= g.base[k]) ? 1 : 0;
+    for (int k = 1; k < kMaxLevels; ++k) l += (k > vg.lv0 && k < vg.lv0 + vg.nlv && p >= vg.base[k]) ? 1 : 0;
     const i32x4 lb = s_tab[4 * l + 1], lc = s_tab[4 * l + 2];
     const int rel = p - s_tab[4 * l + 3].x;
     const int wwl = lc.x;
@@ -688,11 +800,27 @@ __global__ __launch_bounds__(kVWaves * 64) void msda_bwd_value_kernel(
     if (gx >= 0 && gx < lb.z && gy >= 0 && gy < lb.w)
       atomicAdd(gvb + (size_t)(lb.y + gy * lb.z + gx) * (kHeads * kCh) + ch, v);
   }
+  VPROF(4);
 }
 
-// Host side of the windowed kernel: per-level window extents and per-region query ranges.
-// Returns false when the geometry does not fit (then the v1 kernel is used).
-bool make_value_geom(const LevelGeom& lg, int levels, int Nq, ValueGeom* g, size_t* lds_bytes) {
+// Host side of the windowed kernels: per-level window extents, the three level-group variants
+// and their LDS budgets.  Returns false when the geometry does not fit (then the plain-atomics
+// kernel is used).
+constexpr int kNumVar = 3;
+constexpr int kVarNch[kNumVar] = {16, 32, 32};
+constexpr int kVarPpq[kNumVar] = {4, 4, 8};
+constexpr size_t kMaxLds = 160 * 1024;
+
+inline size_t value_lds_bytes(int nch, int ppq, int nw, int NP) {
+  const int nqw = 64 / ppq;
+  return sizeof(int) * (size_t)nch * NP + sizeof(int) * nw * 64 * 8 +
+         sizeof(float) * nw * nqw * nch + sizeof(float) * 2 * nw +
+         sizeof(int) * 4 * 4 * kMaxLevels + sizeof(int) * 6 * kMaxLevels;
+}
+
+bool make_value_geom(const LevelGeom& lg, int levels, int points, int Nq, ValueGeom* g,
+                     VarGeom* var, size_t* lds_bytes) {
+  if (levels != 4 || points != 4) return false;
   int tot = 0;
   for (int l = 0; l < levels; ++l) tot += lg.H[l] * lg.W[l];
   if (tot != Nq) return false;
@@ -702,29 +830,75 @@ bool make_value_geom(const LevelGeom& lg, int levels, int Nq, ValueGeom* g, size
   g->levels = levels;
   g->RX = (W0 + kRegion - 1) / kRegion;
   g->RY = (H0 + kRegion - 1) / kRegion;
+  // equal-sized regions: every workgroup of a launch gets the same number of queries
+  g->EX = (W0 + g->RX - 1) / g->RX;
+  g->EY = (H0 + g->RY - 1) / g->RY;
   if (g->RX > kMaxReg || g->RY > kMaxReg) return false;
-  int npos = 0;
-  for (int l = 0; l < kMaxLevels; ++l) {
-    if (l < levels) {
-      if (lg.W[l] > W0 || lg.H[l] > H0) return false;   // level 0 must be the finest
-      g->H[l] = lg.H[l]; g->W[l] = lg.W[l]; g->start[l] = lg.start[l];
-      int ww = (kRegion * lg.W[l] + W0 - 1) / W0 + 1 + kMarginLo + kMarginHi;
-      while ((ww & 3) != 2) ++ww;                        // bank spread of the 4 corners
-      const int wh = (kRegion * lg.H[l] + H0 - 1) / H0 + 1 + kMarginLo + kMarginHi;
-      g->ww[l] = ww; g->wh[l] = wh; g->base[l] = npos;
-      npos += ww * wh;
-    } else {
-      g->H[l] = 1; g->W[l] = 1; g->start[l] = 0; g->ww[l] = 2; g->wh[l] = 1; g->base[l] = npos;
-    }
+  for (int l = 0; l < levels; ++l) {
+    if (lg.W[l] > W0 || lg.H[l] > H0) return false;   // level 0 must be the finest
+    g->H[l] = lg.H[l]; g->W[l] = lg.W[l]; g->start[l] = lg.start[l];
+    g->ww[l] = (g->EX * lg.W[l] + W0 - 1) / W0 + 1 + kMarginLo + kMarginHi;
+    while ((g->ww[l] & 3) != 2) ++g->ww[l];             // bank spread of the 4 corners
+    g->wh[l] = (g->EY * lg.H[l] + H0 - 1) / H0 + 1 + kMarginLo + kMarginHi;
   }
-  g->npos = npos;
-  int NP = npos + 8;                                      // + dummy slots of the branch-free loop
-  while ((NP & 31) != 4) ++NP;                            // channel-plane stride: +4 banks per channel
-  g->NP = NP;
-  *lds_bytes = sizeof(float) * (size_t)kSlice * NP + (sizeof(int) + sizeof(float)) * kVWaves * 64 * 4 +
-               sizeof(int) * kVWaves * 4 + sizeof(float) * 2 * kVWaves + sizeof(float) * kVWaves * 32 +
-               sizeof(int) * kVWaves + sizeof(int) * 4 * 4 * kMaxLevels;
-  return *lds_bytes <= 156 * 1024;
+  const int lv0[kNumVar] = {0, 1, 2}, nlv[kNumVar] = {1, 1, 2};
+  for (int v = 0; v < kNumVar; ++v) {
+    VarGeom& vg = var[v];
+    vg.lv0 = lv0[v]; vg.nlv = nlv[v];
+    int npos = 0;
+    for (int l = 0; l < kMaxLevels; ++l) {
+      const bool mine = l >= lv0[v] && l < lv0[v] + nlv[v];
+      vg.base[l] = mine ? npos : 0x3FFFFFFF;
+      if (mine) npos += g->ww[l] * g->wh[l];
+    }
+    vg.npos = npos;
+    // channel-plane stride (incl. 8 dummy slots): == 4 (mod 32), see the kernel's lane roles
+    int NP = npos + 8;
+    while ((NP & 31) != 4) ++NP;
+    vg.NP = NP;
+    // as many waves as the LDS left beside the window allows (each wave owns a parameter slice)
+    vg.waves = 0;
+    for (int nw : {16, 12, 8}) {
+      lds_bytes[v] = (value_lds_bytes(kVarNch[v], kVarPpq[v], nw, NP) + 15) & ~(size_t)15;
+      if (lds_bytes[v] <= kMaxLds) { vg.waves = nw; break; }
+    }
+    if (vg.waves == 0) return false;
+  }
+  return true;
+}
+
+template <typename T, int V, int NW>
+int launch_value_nw(const float* loc, const float* attn, const T* grad_out, float* grad_value,
+                    const ValueGeom& g, const VarGeom& vg, size_t lds, int B, int Nq, int LP,
+                    int points, hipStream_t st) {
+  constexpr int NCH = kVarNch[V], PPQ = kVarPpq[V];
+  auto kern = msda_bwd_value_kernel<T, NCH, PPQ, NW>;
+  static const hipError_t attr = hipFuncSetAttribute(
+      (const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+  if (attr != hipSuccess) return fail(DSKD_ERR_LAUNCH, "dskd_msda_bwd: cannot reserve LDS");
+  const dim3 grid((unsigned)(B * g.RY * g.RX * kHeads * (kCh / NCH))), block(NW * 64);
+  hipLaunchKernelGGL(kern, grid, block, lds, st, loc, attn, grad_out, grad_value, g, vg, Nq, LP, points);
+  return DSKD_OK;
+}
+
+template <typename T, int V>
+int launch_value_variant(const float* loc, const float* attn, const T* grad_out, float* grad_value,
+                         const ValueGeom& g, const VarGeom& vg, size_t lds, int B, int Nq, int LP,
+                         int points, hipStream_t st) {
+  switch (vg.waves) {
+    case 16: return launch_value_nw<T, V, 16>(loc, attn, grad_out, grad_value, g, vg, lds, B, Nq, LP, points, st);
+    case 12: return launch_value_nw<T, V, 12>(loc, attn, grad_out, grad_value, g, vg, lds, B, Nq, LP, points, st);
+    default: return launch_value_nw<T, V, 8>(loc, attn, grad_out, grad_value, g, vg, lds, B, Nq, LP, points, st);
+  }
+}
+
+template <typename T>
+int launch_value(const float* loc, const float* attn, const T* grad_out, float* grad_value,
+                 const ValueGeom& g, const VarGeom* var, const size_t* lds, int B, int Nq, int LP,
+                 int points, hipStream_t st) {
+  if (int rc = launch_value_variant<T, 0>(loc, attn, grad_out, grad_value, g, var[0], lds[0], B, Nq, LP, points, st)) return rc;
+  if (int rc = launch_value_variant<T, 1>(loc, attn, grad_out, grad_value, g, var[1], lds[1], B, Nq, LP, points, st)) return rc;
+  return launch_value_variant<T, 2>(loc, attn, grad_out, grad_value, g, var[2], lds[2], B, Nq, LP, points, st);
 }
 
 int fill_geom(const int64_t* spatial_shapes, const int64_t* level_start, int levels, int Nv,
@@ -823,32 +997,24 @@ extern "C" int dskd_msda_bwd(const void* value, const int64_t* spatial_shapes,
 
   // Encoder self-attention shape (queries == pixels): windowed LDS accumulation of grad_value.
   ValueGeom vg;
-  size_t lds = 0;
+  VarGeom var[kNumVar];
+  size_t lds[kNumVar];
   const char* env = getenv("DSKD_MSDA_BWD");   // "v1" forces the plain-atomics kernel (A/B tests)
   const bool force_v1 = env && env[0] == 'v' && env[1] == '1';
-  const bool windowed = !force_v1 && Nq == Nv && make_value_geom(g, levels, Nq, &vg, &lds);
+  const bool windowed = !force_v1 && Nq == Nv && make_value_geom(g, levels, points, Nq, &vg, var, lds);
   if (windowed) {
-    const dim3 vgrid((unsigned)(B * vg.RY * vg.RX * 32)), vblock(kVWaves * 64);
     if (dtype == DSKD_DTYPE_F32) {
-      static const hipError_t attr =
-          hipFuncSetAttribute((const void*)msda_bwd_value_kernel<float>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-      if (attr != hipSuccess) return fail(DSKD_ERR_LAUNCH, "dskd_msda_bwd: cannot reserve LDS");
       hipLaunchKernelGGL((msda_bwd_kernel<float, false>), grid, block, 0, st, (const float*)value, loc, attn,
                          (const float*)grad_out, grad_value, grad_loc, grad_attn, g, Nv, Nq, LP, points, qpb,
                          bpi);
-      hipLaunchKernelGGL(msda_bwd_value_kernel<float>, vgrid, vblock, lds, st, loc, attn,
-                         (const float*)grad_out, grad_value, vg, Nq, LP, points);
+      if (int rc = launch_value<float>(loc, attn, (const float*)grad_out, grad_value, vg, var, lds, B, Nq, LP,
+                                       points, st)) return rc;
     } else {
-      static const hipError_t attr =
-          hipFuncSetAttribute((const void*)msda_bwd_value_kernel<__bf16>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-      if (attr != hipSuccess) return fail(DSKD_ERR_LAUNCH, "dskd_msda_bwd: cannot reserve LDS");
       hipLaunchKernelGGL((msda_bwd_kernel<__bf16, false>), grid, block, 0, st, (const __bf16*)value, loc, attn,
                          (const __bf16*)grad_out, grad_value, grad_loc, grad_attn, g, Nv, Nq, LP, points, qpb,
                          bpi);
-      hipLaunchKernelGGL(msda_bwd_value_kernel<__bf16>, vgrid, vblock, lds, st, loc, attn,
-                         (const __bf16*)grad_out, grad_value, vg, Nq, LP, points);
+      if (int rc = launch_value<__bf16>(loc, attn, (const __bf16*)grad_out, grad_value, vg, var, lds, B, Nq, LP,
+                                        points, st)) return rc;
     }
     return check_launch("dskd_msda_bwd");
   }
@@ -862,3 +1028,12 @@ extern "C" int dskd_msda_bwd(const void* value, const int64_t* spatial_shapes,
                        Nq, LP, points, qpb, bpi);
   return check_launch("dskd_msda_bwd");
 }
+
+#ifdef DSKD_VALUE_PROFILE
+extern "C" int dskd_debug_value_prof(unsigned long long* out, int reset) {
+  hipDeviceSynchronize();
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(dskd::g_vprof), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[64] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(dskd::g_vprof), z, sizeof(z)); }
+  return 0;
+}
+#endif

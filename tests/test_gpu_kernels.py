@@ -136,6 +136,7 @@ def _encoder_like_inputs(shapes, B, seed, sigma_px, dtype=torch.float32):
 
 @pytest.mark.parametrize("shapes,sigma", [([(25, 42), (13, 21), (7, 11), (4, 6)], 2.0),
                                           ([(40, 70), (20, 35), (10, 18), (5, 9)], 12.0),   # many window misses
+                                          ([(64, 96), (32, 48), (16, 24), (8, 12)], 3.0),   # 32-px regions: 8-wave variant
                                           ([(33, 47), (17, 24)], 3.0), ([(9, 5)], 1.0)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_msda_bwd_windowed_encoder_shape(shapes, sigma, dtype):
