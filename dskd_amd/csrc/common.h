@@ -73,4 +73,20 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Zero fill as a KERNEL.  hipMemsetAsync must not be used on the launch path: captured into a
+// hipGraph (ROCm 7.0 runtime of this image) the memset node replays with a garbage fill value
+// from the second replay on (scratch/graph_memset_repro.py), which silently corrupts results.
+template <int kUnused = 0>   // template: one definition shared by every translation unit
+__global__ void zero_fill_kernel(u32x4* __restrict__ p, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+    p[i] = u32x4{0u, 0u, 0u, 0u};
+}
+// bytes must be a multiple of 16 and p 16-byte aligned.
+inline void zero_fill(void* p, size_t bytes, hipStream_t st) {
+  const size_t n16 = bytes / 16;
+  if (n16 == 0) return;
+  const unsigned blocks = (unsigned)((n16 + 255) / 256 < 2048 ? (n16 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(zero_fill_kernel<0>, dim3(blocks), dim3(256), 0, st, reinterpret_cast<u32x4*>(p), n16);
+}
+
 }  // namespace dskd

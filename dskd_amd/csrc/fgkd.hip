@@ -430,10 +430,10 @@ extern "C" int dskd_fgkd_fwd(const float* const* feat_s, const float* const* fea
   for (int i = 0; i <= kMaxImages; ++i) im.box_start[i] = box_start[i <= B ? i : B];
   for (int i = 0; i < 2 * kMaxImages; ++i) im.img_hw[i] = i < 2 * B ? img_hw[i] : 1.f;
 
-  if (hipMemsetAsync(ws.gm, 0, sizeof(float) * (size_t)M * D + 16, st) != hipSuccess)
-    return fail(DSKD_ERR_LAUNCH, "dskd_fgkd_fwd: memset failed");
-  if (hipMemsetAsync(grad_hs_s, 0, sizeof(float) * (size_t)N * D, st) != hipSuccess)
-    return fail(DSKD_ERR_LAUNCH, "dskd_fgkd_fwd: memset failed");
+  if ((reinterpret_cast<uintptr_t>(grad_hs_s) & 15) || (D & 3))
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_fgkd_fwd: grad_hs_s must be 16-byte aligned and D a multiple of 4");
+  zero_fill(ws.gm, sizeof(float) * (size_t)M * D, st);          // kernels, not hipMemsetAsync (see common.h)
+  zero_fill(grad_hs_s, sizeof(float) * (size_t)N * D, st);
 
   hipLaunchKernelGGL(fgkd_pairs_kernel, dim3(1), dim3(256), 0, st, hs_t, keepid_t, hs_s, labels_s,
                      prev_mask, N, D, NC, M, ws, status);

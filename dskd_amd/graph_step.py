@@ -1,15 +1,33 @@
 """The distillation training step as replayable hipGraphs.
 
-An eager step issues ~4 000 kernel launches and is host-bound on MI355X (80 ms wall for 70 ms
+An eager step issues ~3 700 kernel launches and is host-bound on MI355X (68 ms wall for 60 ms
 of GPU work at B=4).  When the shapes of a step repeat (same image size, same number of GT
 and teacher boxes per image) the launch sequence is identical, so it is captured once and
 replayed:
 
     graph T   teacher backbone + neck + transformer + heads          (no_grad, eval)
     eager     teacher box decode (score threshold / top-k: data-dependent sizes, one sync)
-    graph S   student forward, all losses, backward (gradients allocated in the graph's pool)
+    graph F   student backbone + neck forward (autograd graph kept: its buffers are static)
+    graph S   transformer + heads + all losses + backward down to the neck outputs
+    eager     backward of neck + backbone through the autograd graph recorded under F
     eager     [world > 1] ONE all-reduce of the flattened gradients over RCCL + log scalars
     graph U   global-norm gradient clip + fused AdamW update
+
+STATUS: experimental, opt-in (``bench.py --graph``), NOT trusted at full scale on this image.
+Root cause, pinned on the GPU (scratch/graph_memset_repro.py, scratch/graph_debug.py): a
+``hipMemsetAsync`` captured into a hipGraph replays with a garbage fill value from the second
+replay on (ROCm runtime bundled with torch 2.10+rocm7.0).  Three users of memset nodes sit
+inside a training step:
+  * MIOpen's split-K weight-gradient kernels zero their output with it -> whole tiles of conv
+    weight gradients came back NaN.  That is why the neck/backbone backward runs EAGERLY here
+    (its ~500 launches queue behind graph S on the stream, so the GPU never waits for them);
+  * our own kernels used it for two workspaces -> they now zero with a fill kernel
+    (csrc/common.h ``zero_fill``);
+  * ATen's multi-block reductions (``Reduce.cuh``: bias-gradient column sums, loss sums) reset
+    their semaphores with it -> single elements of bias gradients come back NaN, other
+    reductions silently return the previous replay's value.  There is no clean way around
+    this one from outside ATen, so the eager step stays the default execution mode.
+Small shapes (single-block reductions, no split-K) replay correctly: tests/test_gpu_model.py.
 
 For data parallelism the gradients are flattened into one buffer and exchanged as a single
 large collective -- the shape xGMI likes -- and nothing inside a captured
@@ -72,6 +90,32 @@ class GraphedDistillStep:
             loss, keys, flat = self.model.parse_losses_local(losses)
         loss.backward()
         return loss.detach(), keys, flat
+
+    def _student_feats(self, data):
+        with self._autocast():
+            return self.model.extract_feat(data["img"])
+
+    def _head_fwd_bwd(self, data, xs, feats, outs, det):
+        """Student head on the (detached) neck outputs ``xs``: losses and backward; the
+        gradients of ``xs`` are what the eager neck/backbone backward continues from."""
+        m = self.model
+        for meta in data["img_metas"]:
+            meta.setdefault("batch_input_shape", tuple(data["img"].shape[-2:]))
+        with self._autocast():
+            ti = {"neck_feats": feats if m.bbox_head.feats_distill else None, "head_outs": outs,
+                  "pred_keepid": det["pred_keepid"], "pred_logits": det.get("pred_logits"),
+                  "pred_scores": det.get("pred_scores"), "pred_labels": det["pred_labels"],
+                  "pred_bboxes": det["pred_bboxes"]}
+            losses = m.bbox_head.forward_train(xs, data["img_metas"], data["gt_bboxes"], data["gt_labels"], None,
+                                               proposal_cfg=None, teacher_info=ti, task_labels=m.LableInPCNTask)
+            loss, keys, flat = m.parse_losses_local(losses)
+        loss.backward()
+        return loss.detach(), keys, flat
+
+    def _feat_params(self):
+        m = self.model
+        mods = [m.backbone] + ([m.neck] if m.with_neck else [])
+        return [p for mod in mods for p in mod.parameters() if p.requires_grad]
 
     def _update(self):
         params = [p for g in self.opt.param_groups for p in g["params"] if p.grad is not None]
@@ -150,7 +194,10 @@ class GraphedDistillStep:
         g["T"].replay()
         self._decode(g["outs"], data)           # executed (and synchronising) as in the eager step
         self._set_avg_pos(data, inject)
+        g["F"].replay()
         g["S"].replay()
+        # neck + backbone backward, eager, accumulating in place into the static gradients F zeroed
+        torch.autograd.backward(g["xs_raw"], [x.grad for x in g["xs"]], retain_graph=True)
         flat = self._exchange(g["flat_logs"])
         g["U"].replay()
         self.last_logs = (g["keys"], flat)
@@ -164,16 +211,35 @@ class GraphedDistillStep:
         gT.replay()                             # capture does not execute: produce real outputs
         det = dict(self._decode(outs, data), **inject)
         self._set_avg_pos(data, det)
+        # static gradients of the feature extractor (eager backward accumulates into them)
+        fparams = self._feat_params()
+        fgrads = [torch.zeros_like(p) for p in fparams]
+        for p, gr in zip(fparams, fgrads):
+            p.grad = gr
+        fset = {id(p) for p in fparams}
+        for grp in self.opt.param_groups:
+            for p in grp["params"]:
+                if id(p) not in fset:
+                    p.grad = None               # head gradients are allocated inside graph S
+        gF = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gF):
+            torch._foreach_zero_(fgrads)
+            xs_raw = self._student_feats(data)
+        xs = [f.detach().requires_grad_(True) for f in xs_raw]
         gS = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gS):
-            loss, keys, flat_logs = self._fwd_bwd(data, feats, outs, det)
+            loss, keys, flat_logs = self._head_fwd_bwd(data, xs, feats, outs, det)
+        gF.replay()
+        gS.replay()
+        torch.autograd.backward(xs_raw, [x.grad for x in xs], retain_graph=True)
         gU = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gU):
-            self._update()
+            self._update()                      # the first real update happens on the next replay
         torch.cuda.synchronize()
         from .utils import const_cache_snapshot
-        return dict(T=gT, S=gS, U=gU, outs=outs, feats=feats, loss=loss, keys=keys, flat_logs=flat_logs,
-                    keepalive=(const_cache_snapshot(), det, data, inject))   # everything the graphs point at
+        return dict(T=gT, F=gF, S=gS, U=gU, outs=outs, feats=feats, xs_raw=xs_raw, xs=xs, loss=loss, keys=keys,
+                    flat_logs=flat_logs,
+                    keepalive=(const_cache_snapshot(), det, data, inject, fgrads))   # everything the graphs point at
 
     def logs(self):
         """Host copy of the last step's log vars (one device->host copy)."""
