@@ -30,6 +30,9 @@ _SIGNATURES = {
     "dskd_msda_bwd": (C.c_int, [_vp] * 9 + [C.c_int] * 8 + [_vp]),
     "dskd_msda_prep_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_msda_prep_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "dskd_add_ln_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, _f32, _f32,
+                                   C.c_uint64, C.c_uint64, C.c_int, _vp]),
+    "dskd_add_ln_bwd": (C.c_int, [_vp] * 9 + [_i64, C.c_int, _f32, C.c_uint64, C.c_uint64, C.c_int, _vp]),
     "dskd_lsap_host": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "dskd_lsap_batched": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "dskd_match_cost": (C.c_int, [_vp] * 7 + [C.c_int] * 3 + [_f32] * 3 + [_vp]),
@@ -278,6 +281,85 @@ def msda_prepare(both: torch.Tensor, reference_points: torch.Tensor, spatial_sha
         return f(both, reference_points, spatial_shapes, heads, levels, points)
     shapes = tuple((int(h), int(w)) for h, w in spatial_shapes)
     return _MSDAPrepFunction.apply(both, reference_points, shapes, heads, levels, points)
+
+
+# --------------------------------------------------------------------------- add + dropout + LayerNorm
+_drop_calls = 0
+
+
+def _next_drop_key():
+    """(seed, offset) of the next dropout mask: torch's seed (so ``torch.manual_seed`` governs
+    it) and a per-process call counter; no device work, no synchronisation."""
+    global _drop_calls
+    _drop_calls += 1
+    return torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, _drop_calls
+
+
+class _AddLNFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, res, gamma, beta, pos, eps, p, want_q):
+        dt = {torch.float32: DTYPE_F32, torch.bfloat16: DTYPE_BF16}[h.dtype]
+        h, res = h.contiguous(), res.contiguous()
+        rows, D = h.numel() // h.shape[-1], h.shape[-1]
+        train = any(ctx.needs_input_grad[:5])
+        y = torch.empty_like(h)
+        q = torch.empty_like(h) if want_q else None
+        z = torch.empty_like(h) if train else None
+        stats = torch.empty((rows, 2), dtype=torch.float32, device=h.device) if train else None
+        gamma_f, beta_f = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        pos_f = pos.detach().float().contiguous() if pos is not None else None
+        seed, offset = _next_drop_key() if p > 0 else (0, 0)
+        rc = load().dskd_add_ln_fwd(
+            h.data_ptr(), res.data_ptr(), None if pos_f is None else pos_f.data_ptr(),
+            0 if pos_f is None else pos_f.numel() // D, gamma_f.data_ptr(), beta_f.data_ptr(), y.data_ptr(),
+            None if q is None else q.data_ptr(), None if z is None else z.data_ptr(),
+            None if stats is None else stats.data_ptr(), rows, D, eps, p, seed, offset, dt, _stream(h))
+        _check(rc, "dskd_add_ln_fwd")
+        if train:
+            ctx.save_for_backward(z, stats, gamma_f)
+        ctx.meta = (dt, rows, D, p, seed, offset, None if pos is None else tuple(pos.shape), gamma.dtype, want_q)
+        return y, q
+
+    @staticmethod
+    def backward(ctx, dy, dq):
+        z, stats, gamma_f = ctx.saved_tensors
+        dt, rows, D, p, seed, offset, pos_shape, gdtype, want_q = ctx.meta
+        if dy is None:
+            dy = torch.zeros_like(z)
+        dy = dy.contiguous().to(z.dtype)
+        dq = dq.contiguous().to(z.dtype) if (want_q and dq is not None) else None
+        dres = torch.empty_like(z)
+        dh = torch.empty_like(z) if p > 0 else None
+        dgb = torch.zeros((2, D), dtype=torch.float32, device=z.device)
+        rc = load().dskd_add_ln_bwd(dy.data_ptr(), None if dq is None else dq.data_ptr(), z.data_ptr(), stats.data_ptr(),
+                                    gamma_f.data_ptr(), dres.data_ptr(), None if dh is None else dh.data_ptr(),
+                                    dgb[0].data_ptr(), dgb[1].data_ptr(), rows, D, p, seed, offset, dt, _stream(z))
+        _check(rc, "dskd_add_ln_bwd")
+        dpos = None
+        if pos_shape is not None and ctx.needs_input_grad[4] and dq is not None:
+            # q = y + pos[r % pos_rows]: d(pos) = sum of dq over the repeats (the images of a batch)
+            pos_rows = 1
+            for d_ in pos_shape[:-1]:
+                pos_rows *= d_
+            dpos = dq.view(rows // pos_rows, pos_rows, D).sum(0, dtype=torch.float32).view(pos_shape)
+        return (dres if dh is None else dh), dres, dgb[0].to(gdtype), dgb[1].to(gdtype), dpos, None, None, None
+
+
+def add_layer_norm(h: torch.Tensor, res: torch.Tensor, norm: torch.nn.LayerNorm, p: float = 0.0,
+                   pos: Optional[torch.Tensor] = None, want_q: bool = False):
+    """``y = norm(res + dropout_p(h))`` and, with ``want_q``, ``q = y + pos`` -- the tail of a
+    transformer sub-layer (ext-mmcv BaseTransformerLayer: ``identity + dropout(out)`` then
+    'norm', then the next layer's ``query + query_pos``) as ONE launch each way.
+    h, res: [..., 256] f32 | bf16 (same dtype); pos: [..., Nv, 256] broadcast over the leading
+    (batch) dimension of a batch-first token tensor.  Returns (y, q or None)."""
+    f = _dispatch_cpu("add_layer_norm", h)
+    if f is not None:
+        return f(h, res, norm, p, pos, want_q)
+    _need_gpu(h, res)
+    if res.dtype != h.dtype:
+        res = res.to(h.dtype)
+    y, q = _AddLNFunction.apply(h, res, norm.weight, norm.bias, pos, float(norm.eps), float(p), bool(want_q))
+    return y, q
 
 
 # --------------------------------------------------------------------------- LSAP

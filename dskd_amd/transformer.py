@@ -233,6 +233,15 @@ class MultiScaleDeformableAttention(nn.Module):
             query = query.permute(1, 0, 2)
         if not v_bf:
             value = value.permute(1, 0, 2)
+        output = self.core(query, value, reference_points, spatial_shapes, key_padding_mask)
+        if not q_bf:
+            output = output.permute(1, 0, 2)
+        return self.dropout(output) + identity
+
+    def core(self, query, value, reference_points, spatial_shapes, key_padding_mask=None):
+        """Batch-first body of ``forward``: ``query`` already carries its positional encoding;
+        returns ``output_proj(sampling(...))`` WITHOUT the module's dropout + identity (the
+        fused encoder path folds those into the following LayerNorm launch)."""
         bs, num_query, _ = query.shape
         bs, num_value, _ = value.shape
         shapes = spatial_shapes.tolist() if isinstance(spatial_shapes, torch.Tensor) else list(spatial_shapes)
@@ -285,10 +294,7 @@ class MultiScaleDeformableAttention(nn.Module):
             else:
                 raise ValueError(f"Last dim of reference_points must be 2 or 4, but get {reference_points.shape[-1]}")
         output = native.ms_deform_attn(value, shapes, sampling_locations, attention_weights)
-        output = self.output_proj(output)
-        if not q_bf:
-            output = output.permute(1, 0, 2)
-        return self.dropout(output) + identity
+        return self.output_proj(output)
 
 
 @ATTENTION.register_module()
@@ -352,12 +358,23 @@ class FFN(nn.Module):
         self.add_identity = add_identity
 
     def forward(self, x, identity=None):
+        out = self.core(x, final_dropout=True)
+        if not self.add_identity:
+            return self.dropout_layer(out)
+        if identity is None:
+            identity = x
+        return identity + self.dropout_layer(out)
+
+    def core(self, x, final_dropout):
+        """The Linear/act/Dropout stack; ``final_dropout=False`` leaves out the trailing
+        ``Dropout(ffn_drop)`` (the fused encoder path applies it inside the LayerNorm launch)."""
         first = self.layers[0]
+        rest = list(self.layers)[1:] if final_dropout else list(self.layers)[1:-1]
         if self.num_fcs == 2 and isinstance(first[1], nn.ReLU) and first[0].weight.requires_grad:
             # Linear + ReLU as one GEMM with a fused epilogue, then the rest of the stack
             out = tall_linear(x, first[0].weight, first[0].bias, relu=True)
             out = first[2](out)
-            for m in list(self.layers)[1:]:
+            for m in rest:
                 out = m(out)
         elif self.num_fcs == 2 and isinstance(first[1], nn.ReLU) and x.is_cuda and not torch.is_grad_enabled() \
                 and first[0].bias is not None and first[0].frozen_lp(x.device.type) is not None:
@@ -365,15 +382,13 @@ class FFN(nn.Module):
             w, b = first[0].frozen_lp(x.device.type)
             out = torch._addmm_activation(b, x.reshape(-1, x.shape[-1]).to(w.dtype), w.t()).view(*x.shape[:-1], -1)
             out = first[2](out)
-            for m in list(self.layers)[1:]:
+            for m in rest:
                 out = m(out)
         else:
-            out = self.layers(x)
-        if not self.add_identity:
-            return self.dropout_layer(out)
-        if identity is None:
-            identity = x
-        return identity + self.dropout_layer(out)
+            out = first(x)
+            for m in rest:
+                out = m(out)
+        return out
 
 
 @TRANSFORMER_LAYER.register_module()
@@ -495,9 +510,55 @@ class DetrTransformerEncoder(TransformerLayerSequence):
         self.post_norm = nn.LayerNorm(self.embed_dims) if (post_norm_cfg is not None and self.pre_norm) else None
 
     def forward(self, *args, **kwargs):
+        x = self._forward_fused(*args, **kwargs)
+        if x is not None:
+            return x
         x = super().forward(*args, **kwargs)
         if self.post_norm is not None:
             x = self.post_norm(x)
+        return x
+
+    def _fusable(self):
+        ok = getattr(self, "_fusable_cache", None)
+        if ok is None:
+            ok = self.post_norm is None and self.embed_dims == 256
+            for layer in self.layers:
+                ok = ok and tuple(layer.operation_order) == ("self_attn", "norm", "ffn", "norm")
+                if not ok:
+                    break
+                att, ffn = layer.attentions[0], layer.ffns[0]
+                ok = ok and isinstance(att, MultiScaleDeformableAttention) and isinstance(ffn, FFN) \
+                    and ffn.add_identity and isinstance(ffn.dropout_layer, nn.Identity) \
+                    and isinstance(ffn.layers[-1], nn.Dropout) and all(n.elementwise_affine for n in layer.norms)
+            self._fusable_cache = ok
+        return ok
+
+    def _forward_fused(self, query, key=None, value=None, query_pos=None, query_key_padding_mask=None,
+                       reference_points=None, spatial_shapes=None, tokens_batch_first=None, **kwargs):
+        """MI355X path of the deformable encoder (post-norm layers, batch-first tokens on the
+        GPU): the residual stream stays in the compute dtype and each sub-layer's
+        ``identity + dropout(out)`` -> LayerNorm -> (next layer's) ``+ query_pos`` is ONE HIP
+        launch each way (native.add_layer_norm) instead of dropout / mixed-dtype add / fp32
+        LayerNorm / cast / positional add.  Returns None when the configuration does not
+        match, and the generic operation_order interpreter runs instead."""
+        if not (tokens_batch_first and query.is_cuda and query_pos is not None and reference_points is not None
+                and reference_points.shape[-1] == 2 and self._fusable()):
+            return None
+        dev = query.device.type
+        dtype = torch.get_autocast_dtype(dev) if torch.is_autocast_enabled(dev) else query.dtype
+        if dtype not in (torch.float32, torch.bfloat16):
+            return None
+        x = query.to(dtype)
+        pos = query_pos.float()
+        q = (x + pos).to(dtype)
+        last = len(self.layers) - 1
+        for i, layer in enumerate(self.layers):
+            att, ffn = layer.attentions[0], layer.ffns[0]
+            h = att.core(q, x, reference_points, spatial_shapes, query_key_padding_mask)
+            x1, _ = native.add_layer_norm(h, x, layer.norms[0], p=att.dropout.p if att.training else 0.0)
+            f = ffn.core(x1, final_dropout=False)
+            x, q = native.add_layer_norm(f, x1, layer.norms[1], p=ffn.layers[-1].p if ffn.training else 0.0,
+                                         pos=None if i == last else pos, want_q=i != last)
         return x
 
 

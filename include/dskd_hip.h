@@ -31,6 +31,12 @@
  *   dskd_fgkd_fwd
  *       the `decode_v1` feature distillation loop + KL loss
  *       (gfl_deformable_detr_head_il.py:664-718, mmdet/models/losses/kd_loss.py:10-43).
+ *   dskd_add_ln_fwd / dskd_add_ln_bwd
+ *       the tail of every transformer sub-layer of ext-mmcv `BaseTransformerLayer.forward`
+ *       (mmcv/cnn/bricks/transformer.py, imported at mmdet/models/utils/transformer.py:13-15
+ *       and run by DetrTransformerEncoder :454-483 / DeformableDetrTransformerDecoder
+ *       :625-710): `identity + dropout(out)` of MultiScaleDeformableAttention / FFN, the
+ *       following 'norm' (nn.LayerNorm) and the next layer's `query + query_pos`.
  */
 #ifndef DSKD_HIP_H
 #define DSKD_HIP_H
@@ -194,6 +200,37 @@ int dskd_fgkd_fwd(const float* const* feat_s, const float* const* feat_t,
                   const int64_t* labels_s, const uint8_t* prev_mask, int N, int D,
                   int NC, int M, float T, float loss_weight, float* loss,
                   float* grad_hs_s, void* workspace, int32_t* status, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Fused sub-layer tail:   z = res + dropout(h);  y = LayerNorm(z) * gamma + beta;  q = y + pos
+ *
+ * h, res      device, [rows, D] f32|bf16 (dtype): sub-layer output and residual (identity)
+ * pos         device, [pos_rows, D] f32 or NULL; row r uses pos[r % pos_rows] (positional
+ *             encoding shared by the images of a batch-first batch)
+ * gamma, beta device, [D] f32
+ * y           device, [rows, D] dtype (overwritten)
+ * q           device, [rows, D] dtype or NULL (requires pos)
+ * z, stats    device, [rows, D] dtype and [rows, 2] f32 (mean, rstd), saved for backward; both
+ *             NULL in inference.  With bf16 the statistics are those of the ROUNDED z.
+ * drop_p      dropout probability in [0, 1); the mask is Philox4x32-10(seed, offset) counted by
+ *             (row, lane) and is regenerated by the backward call from the same (seed, offset).
+ * All pointers 16-byte aligned.  Supported: D == 256.
+ * ------------------------------------------------------------------------- */
+int dskd_add_ln_fwd(const void* h, const void* res, const float* pos, int64_t pos_rows,
+                    const float* gamma, const float* beta, void* y, void* q, void* z,
+                    float* stats, int64_t rows, int D, float eps, float drop_p, uint64_t seed,
+                    uint64_t offset, int dtype, void* stream);
+/* Backward of the above.
+ * dy, dq      device, [rows, D] dtype: gradients of y and (or NULL) of q
+ * dres        device, [rows, D] dtype: d loss / d res (overwritten)
+ * dh          device, [rows, D] dtype: d loss / d h; pass NULL exactly when drop_p == 0
+ *             (then d loss / d h == dres)
+ * dgamma, dbeta device, [D] f32, MUST be zeroed by the caller (accumulated with atomics)
+ */
+int dskd_add_ln_bwd(const void* dy, const void* dq, const void* z, const float* stats,
+                    const float* gamma, void* dres, void* dh, float* dgamma, float* dbeta,
+                    int64_t rows, int D, float drop_p, uint64_t seed, uint64_t offset, int dtype,
+                    void* stream);
 
 #ifdef __cplusplus
 }

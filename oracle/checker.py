@@ -23,6 +23,13 @@ class OracleChecker:
         loc = ref.float()[..., None, :, None, :] + off / norm[None, :, None, :]
         return loc, attn
 
+    def add_layer_norm(self, h, res, norm, p, pos, want_q):
+        """The module chain itself (ext-mmcv BaseTransformerLayer): identity + dropout(out), the
+        'norm' op, and the next layer's query + query_pos."""
+        import torch.nn.functional as F
+        y = norm(res + F.dropout(h, p, training=p > 0))
+        return y, (y + pos if want_q else None)
+
     def match_cost(self, bbox_pred, cls_pred, gt_bboxes, gt_labels, gt_start, img_wh, w_cls, w_reg, w_iou):
         P, Q, _ = bbox_pred.shape
         out = []

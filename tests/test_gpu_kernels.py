@@ -193,6 +193,117 @@ def test_msda_prepare_vs_module_chain(dtype, oracle_checker):
     torch.testing.assert_close(bd.grad.float().cpu(), (g1 + g2).float(), **tol)
 
 
+# ----------------------------------------------------------------------------- add + dropout + LayerNorm
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("want_q", [False, True])
+def test_add_layer_norm_vs_module_chain(dtype, want_q, oracle_checker):
+    """identity + out -> LayerNorm -> + query_pos (ext-mmcv BaseTransformerLayer) in one launch
+    each way, against the PyTorch chain in fp32 on the same (rounded) inputs.  p = 0."""
+    g = torch.Generator().manual_seed(5)
+    B, Nv, D = 3, 413, 256                       # 1239 rows: not a multiple of the 4-row workgroup
+    h = (torch.randn(B, Nv, D, generator=g) * 1.5).to(dtype)
+    res = (torch.randn(B, Nv, D, generator=g) + 0.3).to(dtype)
+    pos = torch.randn(1, Nv, D, generator=g)
+    norm = torch.nn.LayerNorm(D)
+    with torch.no_grad():
+        norm.weight.copy_(1 + 0.2 * torch.randn(D, generator=g)); norm.bias.copy_(0.1 * torch.randn(D, generator=g))
+    gy = torch.randn(B, Nv, D, generator=g)
+    gq = torch.randn(B, Nv, D, generator=g)
+    # reference in fp32
+    hr, rr = h.float().clone().requires_grad_(True), res.float().clone().requires_grad_(True)
+    pr = pos.clone().requires_grad_(True)
+    yr, qr = oracle_checker.add_layer_norm(hr, rr, norm, 0.0, pr, want_q)
+    ((yr * gy).sum() + ((qr * gq).sum() if want_q else 0)).backward()
+    ref_g = (hr.grad, rr.grad, norm.weight.grad.clone(), norm.bias.grad.clone(), pr.grad)
+    norm.zero_grad()
+    # device
+    nd = torch.nn.LayerNorm(D).to(DEV); nd.load_state_dict(norm.state_dict())
+    hd, rd = h.to(DEV).requires_grad_(True), res.to(DEV).requires_grad_(True)
+    pd = pos.to(DEV).requires_grad_(True)
+    y, q = native.add_layer_norm(hd, rd, nd, 0.0, pd if want_q else None, want_q)
+    assert y.dtype == dtype and (q is None) == (not want_q)
+    ((y.float() * gy.to(DEV)).sum() + ((q.float() * gq.to(DEV)).sum() if want_q else 0)).backward()
+    tol = dict(rtol=1e-5, atol=2e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=3e-2)
+    torch.testing.assert_close(y.float().cpu(), yr.detach(), **tol)
+    if want_q:
+        torch.testing.assert_close(q.float().cpu(), qr.detach(), **tol)
+    gtol = dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=3e-2, atol=5e-2)
+    torch.testing.assert_close(hd.grad.float().cpu(), ref_g[0], **gtol)
+    torch.testing.assert_close(rd.grad.float().cpu(), ref_g[1], **gtol)
+    # column sums over 1239 rows: relative to their magnitude
+    wtol = dict(rtol=1e-4, atol=1e-3) if dtype == torch.float32 else dict(rtol=3e-2, atol=0.5)
+    torch.testing.assert_close(nd.weight.grad.cpu(), ref_g[2], **wtol)
+    torch.testing.assert_close(nd.bias.grad.cpu(), ref_g[3], **wtol)
+    if want_q:
+        torch.testing.assert_close(pd.grad.cpu(), ref_g[4], **(dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32
+                                                               else dict(rtol=2e-2, atol=3e-2)))
+
+
+def test_add_layer_norm_dropout_mask_through_abi():
+    """Dropout inside the fused launch, checked through the raw C-ABI: drop rate, 1/(1-p)
+    scaling, determinism in (seed, offset), and backward regenerating the SAME mask."""
+    lib = native.load()
+    rows, D, p = 2048, 256, 0.3
+    g = torch.Generator().manual_seed(9)
+    h = (torch.rand(rows, D, generator=g) + 1.0).to(DEV)          # strictly positive: dropped <=> z == res
+    res = torch.zeros(rows, D, device=DEV)
+    gamma, beta = torch.ones(D, device=DEV), torch.zeros(D, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def fwd(seed, offset):
+        y, z = torch.empty_like(h), torch.empty_like(h)
+        stats = torch.empty(rows, 2, device=DEV)
+        rc = lib.dskd_add_ln_fwd(h.data_ptr(), res.data_ptr(), None, 0, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                 None, z.data_ptr(), stats.data_ptr(), rows, D, 1e-5, p, seed, offset, native.DTYPE_F32, st)
+        assert rc == 0, lib.dskd_last_error()
+        return y, z, stats
+    y, z, stats = fwd(1234, 7)
+    keep = z != 0
+    frac = keep.float().mean().item()
+    assert abs(frac - (1 - p)) < 4 * (p * (1 - p) / (rows * D)) ** 0.5 + 1e-3, frac
+    torch.testing.assert_close(z[keep], (h / (1 - p))[keep], rtol=1e-6, atol=0)
+    # per-row and per-column drop rates are uniform (no stuck lanes / rows)
+    assert (keep.float().mean(0) - (1 - p)).abs().max() < 0.06 and (keep.float().mean(1) - (1 - p)).abs().max() < 0.15
+    _, z2, _ = fwd(1234, 7)
+    assert torch.equal(z, z2)
+    _, z3, _ = fwd(1234, 8)
+    assert not torch.equal(z3 != 0, keep)
+    # statistics of z
+    torch.testing.assert_close(stats[:, 0], z.mean(1), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(stats[:, 1], (z.var(1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-4, atol=1e-5)
+    # backward with the same key: d(h) == d(res) * mask / (1 - p)
+    dy = torch.randn(rows, D, generator=g).to(DEV)
+    dres, dh = torch.empty_like(h), torch.empty_like(h)
+    dg, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    rc = lib.dskd_add_ln_bwd(dy.data_ptr(), None, z.data_ptr(), stats.data_ptr(), gamma.data_ptr(), dres.data_ptr(),
+                             dh.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, D, p, 1234, 7, native.DTYPE_F32, st)
+    assert rc == 0, lib.dskd_last_error()
+    assert torch.equal(dh != 0, keep & (dres != 0))
+    torch.testing.assert_close(dh[keep], (dres / (1 - p))[keep], rtol=1e-6, atol=0)
+    torch.testing.assert_close(db, dy.sum(0), rtol=1e-4, atol=1e-3)
+    # argument checks of the ABI
+    assert lib.dskd_add_ln_fwd(h.data_ptr(), res.data_ptr(), None, 0, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                               None, None, None, rows, 128, 1e-5, 0.0, 0, 0, native.DTYPE_F32, st) == -1
+    assert lib.dskd_add_ln_bwd(dy.data_ptr(), None, z.data_ptr(), stats.data_ptr(), gamma.data_ptr(), dres.data_ptr(),
+                               None, dg.data_ptr(), db.data_ptr(), rows, D, p, 1, 1, native.DTYPE_F32, st) == -1
+
+
+def test_add_layer_norm_full_size_properties():
+    """BASELINE size (4 x 22 223 rows, bf16): LayerNorm invariants that need no oracle -- every
+    output row has mean beta-weighted 0 / variance 1 for gamma = 1, beta = 0, and scaling the
+    inputs by 2 leaves y unchanged."""
+    g = torch.Generator().manual_seed(3)
+    rows, D = 4 * 22223, 256
+    h = torch.randn(rows, D, generator=g).to(torch.bfloat16).to(DEV)
+    res = torch.randn(rows, D, generator=g).to(torch.bfloat16).to(DEV)
+    norm = torch.nn.LayerNorm(D).to(DEV)
+    y, _ = native.add_layer_norm(h, res, norm, 0.0)
+    yf = y.float()
+    assert yf.mean(1).abs().max() < 2e-2 and (yf.var(1, unbiased=False) - 1).abs().max() < 3e-2
+    y2, _ = native.add_layer_norm(h * 2, res * 2, norm, 0.0)
+    torch.testing.assert_close(y2.float(), yf, rtol=2e-2, atol=2e-2)
+
+
 # ----------------------------------------------------------------------------- LSAP
 def _lsap_device(mats):
     flat = torch.cat([torch.from_numpy(m).reshape(-1) for m in mats]).to(DEV)
