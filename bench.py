@@ -95,17 +95,27 @@ def make_batch(B, num_prev, seed, device, n_gt=7, n_t=10):
     return dict(img=img.to(device), img_metas=metas, gt_bboxes=gt_b, gt_labels=gt_l), dict(t_b=t_b, t_l=t_l, keep=keep)
 
 
-def train_step(model, wrapped, optimizer, data, synth, amp_dtype, max_norm=0.1):
+def train_step(model, wrapped, optimizer, data, synth, amp_dtype, max_norm=0.1, ahead=None):
+    """One distillation step.  ``ahead`` (a ``TeacherAhead``): the teacher of the next batch runs
+    on a second stream behind the student's backward and its decode no longer drains the main
+    stream; every step still contains one teacher forward + decode, one student
+    forward/backward and one optimizer update."""
     module = model
     dev = data["img"].device
     optimizer.zero_grad(set_to_none=True)
     with torch.autocast(device_type=dev.type, dtype=amp_dtype, enabled=amp_dtype is not None):
-        feats, outs, keepid, logits, labels, scores, bboxes = module.out_teacher(data["img"], data["img_metas"])
+        if ahead is not None:
+            ti = ahead.finish(data["img"], data["img_metas"])
+            feats, outs = ti["neck_feats"], ti["head_outs"]
+        else:
+            feats, outs, keepid, logits, labels, scores, bboxes = module.out_teacher(data["img"], data["img_metas"])
         teacher_info = {"neck_feats": feats, "head_outs": outs, "pred_keepid": synth["keep"], "pred_logits": None,
                         "pred_scores": None, "pred_labels": synth["t_l"], "pred_bboxes": synth["t_b"]}
         losses = wrapped(img=data["img"], img_metas=data["img_metas"], gt_bboxes=data["gt_bboxes"],
                          gt_labels=data["gt_labels"], teacher_info=teacher_info)
         loss, log_vars = module._parse_losses(losses)
+        if ahead is not None:
+            ahead.launch(data["img"], data["img_metas"])      # the next batch (synthetic: the same tensors)
     loss.backward()
     params = [p for gr in optimizer.param_groups for p in gr["params"] if p.grad is not None]
     torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm, norm_type=2)
@@ -151,6 +161,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="EXPERIMENTAL: replay the step as hipGraphs "
                     "(dskd_amd/graph_step.py) instead of eager launches + DDP")
+    ap.add_argument("--no-teacher-ahead", action="store_true", help="run the teacher inline on the main stream "
+                    "(its decode then drains the stream mid-step) instead of one batch ahead on a second stream")
     ap.add_argument("--probe-steps", type=int, default=3, help="eager steps after the timed region that bracket "
                     "every MSDeformAttn launch with HIP events (roofline)")
     ap.add_argument("--seed", type=int, default=111)
@@ -196,6 +208,7 @@ def main():
     # ONE flat all-reduce over RCCL; falls back to eager if capture fails on any rank.
     mode = "hipgraph" if args.graph else "eager+ddp"
     stepper = None
+    ahead = None
     extra_warmup = 0
     if mode == "hipgraph":
         optimizer = build_optimizer(model, cfg.optimizer[0], capturable=True)
@@ -224,13 +237,16 @@ def main():
             from dskd_amd.dist import wrap_ddp
             wrapped = wrap_ddp(model, device_ids=[local_rank])
         optimizer = build_optimizer(model, cfg.optimizer[0])
-        for _ in range(args.warmup):
-            loss, lv = train_step(model, wrapped, optimizer, data, synth, amp_dtype)
+        ahead = None if args.no_teacher_ahead else model.teacher_ahead()
+        if ahead is not None:
+            mode += "+teacher_ahead"
+        for _ in range(args.warmup):     # the first step runs its teacher inline, then the pipeline is primed
+            loss, lv = train_step(model, wrapped, optimizer, data, synth, amp_dtype, ahead=ahead)
 
     def one_step():
         if stepper is not None:
             return stepper.step(data, inject)
-        return train_step(model, wrapped, optimizer, data, synth, amp_dtype)[0]
+        return train_step(model, wrapped, optimizer, data, synth, amp_dtype, ahead=ahead)[0]
 
     sync()
     t0 = time.perf_counter()
@@ -247,7 +263,7 @@ def main():
         if stepper is not None:
             stepper.eager_step(data, inject)
         else:
-            train_step(model, wrapped, optimizer, data, synth, amp_dtype)
+            train_step(model, wrapped, optimizer, data, synth, amp_dtype, ahead=ahead)
     torch.cuda.synchronize()
     kt = native.timing_collect()
     native.timing_enable(False)

@@ -22,6 +22,7 @@ Only the branches the DSKD configs enable are built ('hard' + 'teacher-first',
 """
 import copy
 
+import os
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -30,7 +31,7 @@ from . import native
 from .bbox import bbox_cxcywh_to_xyxy, bbox_overlaps, bbox_xyxy_to_cxcywh
 from .builder import HEADS, build_assigner, build_loss, build_positional_encoding, build_sampler, build_transformer
 from .dist import reduce_mean
-from .transformer import Linear, inverse_sigmoid
+from .transformer import Linear, inverse_sigmoid, lowp_params
 from .utils import device_const
 
 
@@ -174,6 +175,14 @@ class GFLDeformableDETRHead_il(nn.Module):
     def forward(self, mlvl_feats, img_metas):
         """:196-281.  Returns (cls [nb_dec,B,Q,C], box [nb_dec,B,Q,2+4*(reg_max+1)] sigmoid,
         (memory, spatial_shapes), hs [nb_dec,B,Q,D])."""
+        dev = mlvl_feats[0].device.type
+        if mlvl_feats[0].is_cuda and torch.is_grad_enabled() and torch.is_autocast_enabled(dev):
+            # training under autocast: all Linear parameters cast to the compute dtype in one launch
+            with lowp_params(self, torch.get_autocast_dtype(dev)):
+                return self._forward(mlvl_feats, img_metas)
+        return self._forward(mlvl_feats, img_metas)
+
+    def _forward(self, mlvl_feats, img_metas):
         batch_size = mlvl_feats[0].size(0)
         input_img_h, input_img_w = img_metas[0]["batch_input_shape"]
         full = all(tuple(m["img_shape"][:2]) == (input_img_h, input_img_w) for m in img_metas)

@@ -89,11 +89,75 @@ class _TallLinearFn(torch.autograd.Function):
         return gx, gw, gb, None, None
 
 
+class _CastParams(torch.autograd.Function):
+    """fp32 master parameters -> compute dtype in ONE multi-tensor launch, and their gradients
+    back in one.  torch.autocast does the same per parameter: ~200 cast launches forward and as
+    many ``ToCopyBackward`` launches backward for the student head, each a few microseconds of
+    GPU time and ~10 us of host time."""
+
+    @staticmethod
+    def forward(ctx, dtype, *params):
+        ctx.set_materialize_grads(False)
+        ctx.pdtypes = [p.dtype for p in params]
+        outs = [torch.empty_like(p, dtype=dtype) for p in params]
+        torch._foreach_copy_(outs, [p.detach() for p in params])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        idx = [i for i, g in enumerate(grads) if g is not None]
+        ups = [torch.empty_like(grads[i], dtype=ctx.pdtypes[i]) for i in idx]
+        if idx:
+            torch._foreach_copy_(ups, [grads[i] for i in idx])
+        out = [None] * len(grads)
+        for j, i in enumerate(idx):
+            out[i] = ups[j]
+        return (None, *out)
+
+
+class lowp_params:
+    """``with lowp_params(root, dtype):`` -- every trainable :class:`Linear` below ``root`` uses
+    a ``dtype`` copy of its parameters made by ONE :class:`_CastParams` call (autograd routes
+    the gradients back to the fp32 masters).  Frozen modules keep their cached copies."""
+
+    def __init__(self, root, dtype):
+        self.root, self.dtype = root, dtype
+
+    def __enter__(self):
+        mods = self.root.__dict__.get("_lowp_mods")
+        if mods is None:
+            mods = [m for m in self.root.modules() if isinstance(m, Linear)]
+            self.root.__dict__["_lowp_mods"] = mods
+        self.live = [m for m in mods if m.weight.requires_grad and (m.bias is None or m.bias.requires_grad)]
+        params = []
+        for m in self.live:
+            params.append(m.weight)
+            if m.bias is not None:
+                params.append(m.bias)
+        if params:
+            outs = iter(_CastParams.apply(self.dtype, *params))
+            for m in self.live:
+                m.__dict__["_live_lp"] = (next(outs), next(outs) if m.bias is not None else None)
+        return self
+
+    def __exit__(self, *exc):
+        for m in self.live:
+            m.__dict__.pop("_live_lp", None)
+        return False
+
+
 class Linear(nn.Linear):
     """nn.Linear that keeps a low-precision copy of FROZEN parameters under autocast.
     torch.autocast caches weight casts only for leaf tensors that require grad, so the frozen
     teacher (and any frozen student layer) would re-cast every weight on every call; trainable
-    parameters take the stock path (autocast's own per-step cache)."""
+    parameters use the step's :class:`lowp_params` copies when a caller provides them, else
+    the stock path (autocast's own per-step cache)."""
+
+    def lp(self):
+        """(weight, bias) to compute with: the live low-precision copies inside ``lowp_params``,
+        else the parameters themselves."""
+        live = self.__dict__.get("_live_lp")
+        return live if live is not None else (self.weight, self.bias)
 
     def frozen_lp(self, dev):
         """(weight, bias) in the autocast dtype when both are frozen and autocast is on, else None."""
@@ -112,7 +176,8 @@ class Linear(nn.Linear):
         lp = self.frozen_lp(x.device.type)
         if lp is not None:
             return F.linear(x, lp[0], lp[1])
-        return tall_linear(x, self.weight, self.bias)
+        w, b = self.lp()
+        return tall_linear(x, w, b)
 
 
 def tall_linear(x, weight, bias, relu=False):
@@ -266,8 +331,9 @@ class MultiScaleDeformableAttention(nn.Module):
                              torch.cat([so.bias, aw.bias], 0).detach().to(dtype))
             w_cat, b_cat = self._cat
         else:
-            w_cat = torch.cat([so.weight, aw.weight], 0)
-            b_cat = torch.cat([so.bias, aw.bias], 0)
+            (sw, sb), (ww, wb) = so.lp(), aw.lp()
+            w_cat = torch.cat([sw, ww], 0)
+            b_cat = torch.cat([sb, wb], 0)
         both = tall_linear(query, w_cat, b_cat)
         if reference_points.shape[-1] == 2 and not reference_points.requires_grad and \
                 self.num_levels * self.num_points == 16 and self.num_levels <= 4:
@@ -372,7 +438,8 @@ class FFN(nn.Module):
         rest = list(self.layers)[1:] if final_dropout else list(self.layers)[1:-1]
         if self.num_fcs == 2 and isinstance(first[1], nn.ReLU) and first[0].weight.requires_grad:
             # Linear + ReLU as one GEMM with a fused epilogue, then the rest of the stack
-            out = tall_linear(x, first[0].weight, first[0].bias, relu=True)
+            w1, b1 = first[0].lp()
+            out = tall_linear(x, w1, b1, relu=True)
             out = first[2](out)
             for m in rest:
                 out = m(out)

@@ -1,4 +1,4 @@
-import sys, os; sys.path.insert(0,'.')
+import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 from torch.profiler import profile, ProfilerActivity
 from dskd_amd import native
@@ -21,3 +21,5 @@ with open('gpurun_out/torch_prof_shapes.txt','w') as f:
 with open('gpurun_out/torch_prof_ops.txt','w') as f:
     f.write(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=60, max_name_column_width=50))
 print("done")
+with open('gpurun_out/torch_prof_cpu.txt','w') as f:
+    f.write(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=70, max_name_column_width=60))
