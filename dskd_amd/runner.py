@@ -92,19 +92,28 @@ class TaskEpochBasedRunner:
     def module(self):
         return self.model.module if hasattr(self.model, "module") else self.model
 
-    def train_iter(self, data):
-        """One optimisation step = what ext-mmcv's runner + OptimizerHook do per batch."""
+    def train_iter(self, data, next_data=None):
+        """One optimisation step = what ext-mmcv's runner + OptimizerHook do per batch.
+        ``next_data`` (already on the device): its frozen-teacher forward is enqueued on a second
+        stream behind this batch's student backward (``TeacherAhead``), so the teacher's decode
+        never drains the main stream."""
         dev = next(self.module.parameters()).device
         data = to_device(data, dev)
         self.lr.set(self.epoch, self.iter)
         self.optimizer.zero_grad(set_to_none=True)
+        ahead = self.module.teacher_ahead() if (dev.type == "cuda" and getattr(self.module, "has_teacher", False)
+                                                and hasattr(self.module, "teacher_ahead")) else None
         with torch.autocast(device_type=dev.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
+            if ahead is not None:
+                data = dict(data, teacher_info=ahead.finish(data["img"], data["img_metas"]))
             if hasattr(self.model, "module"):       # DDP: go through forward so gradient hooks fire
                 losses = self.model(**data)
                 loss, log_vars = self.module._parse_losses(losses)
                 out = dict(loss=loss, log_vars=log_vars, num_samples=len(data["img_metas"]))
             else:
                 out = self.model.train_step(data, self.optimizer)
+            if ahead is not None and next_data is not None:
+                ahead.launch(next_data["img"], next_data["img_metas"])
         out["loss"].backward()
         if self.grad_clip:
             params = [p for g in self.optimizer.param_groups for p in g["params"] if p.grad is not None]
@@ -122,10 +131,18 @@ class TaskEpochBasedRunner:
             if hasattr(loader.sampler, "set_epoch"):
                 loader.sampler.set_epoch(epoch)
             tic = time.time()
-            for i, data in enumerate(loader):
+            dev = next(self.module.parameters()).device
+            batches = iter(loader)
+            nxt = next(batches, None)
+            i = -1
+            while nxt is not None:
+                i += 1
                 if self.max_iters_per_epoch is not None and i >= self.max_iters_per_epoch:
                     break
-                out = self.train_iter(data)
+                data, nxt = to_device(nxt, dev), next(batches, None)
+                if nxt is not None:
+                    nxt = to_device(nxt, dev)
+                out = self.train_iter(data, nxt)
                 if (i + 1) % self.log_interval == 0 or i == 0:
                     lv = out["log_vars"]
                     if not math.isfinite(lv["loss"]):                   # CheckInvalidLossHook
