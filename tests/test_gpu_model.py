@@ -117,3 +117,43 @@ def test_graph_replay_equals_eager(channels_last, amp):
     for a, b in zip(*losses):
         assert b == pytest.approx(a, rel=2e-3 if amp is None else 3e-2), losses
     assert losses[0][-1] != losses[0][0]                      # the weights actually move
+
+
+def test_teacher_ahead_matches_inline_teacher():
+    """The teacher run one batch ahead on a second stream hands over exactly what the inline
+    ``out_teacher`` computes (frozen teacher: same kernels, same inputs), and a student step fed
+    from it gives the same losses."""
+    cfg, m = _build()
+    m.to("cuda:0").train()
+    data, inj = _batch(torch.device("cuda:0"))
+    feats, outs, keepid, logits, labels, scores, bboxes = m.out_teacher(data["img"], data["img_metas"])
+    ahead = m.teacher_ahead()
+    ahead.launch(data["img"], data["img_metas"])
+    # main-stream work queued between launch and finish, as in a training step
+    junk = torch.randn(2048, 2048, device="cuda:0")
+    for _ in range(8):
+        junk = junk @ junk.t() * 1e-3
+    ti = ahead.finish()
+    assert ahead.pending is None
+    for a, b in zip(ti["neck_feats"], feats):
+        assert torch.equal(a, b)
+    for a, b in zip(ti["head_outs"][:2], outs[:2]):
+        assert torch.equal(a, b)
+    assert torch.equal(ti["pred_keepid"], keepid)
+    for a, b in zip(ti["pred_bboxes"], bboxes):
+        assert torch.equal(a, b)
+    for a, b in zip(ti["pred_labels"], labels):
+        assert torch.equal(a, b)
+    # nothing pending: finish() falls back to the inline teacher
+    ti2 = ahead.finish(data["img"], data["img_metas"])
+    assert torch.equal(ti2["pred_keepid"], keepid)
+
+    def losses(teacher_info):
+        info = dict(teacher_info, pred_keepid=inj["pred_keepid"], pred_labels=inj["pred_labels"],
+                    pred_bboxes=inj["pred_bboxes"], pred_logits=None, pred_scores=None)
+        return m.train_step(dict(data, teacher_info=info))["log_vars"]
+    inline = dict(neck_feats=feats, head_outs=outs)
+    la, lb = losses(ti), losses(inline)
+    assert set(la) == set(lb)
+    for k in la:
+        assert la[k] == pytest.approx(lb[k], rel=1e-5, abs=1e-6), k
