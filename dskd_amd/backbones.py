@@ -7,6 +7,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import native
 from .builder import BACKBONES
 
 
@@ -22,17 +23,39 @@ class FrozenAffineBN(nn.BatchNorm2d):
         return x * scale.to(x.dtype).view(1, -1, 1, 1) + shift.to(x.dtype).view(1, -1, 1, 1)
 
 
-def conv_bn(conv, bn, x):
-    """conv followed by an eval-mode (frozen-statistics) BatchNorm, folded into ONE convolution:
-    bn(conv(x, w)) = conv(x, w * scale) + shift with scale = gamma / sqrt(var + eps).  Saves two
-    full passes over the activation per conv (the largest maps here are 137 MB in bf16).  When
+def _conv_epilogue(conv, x, w, b, relu, identity):
+    """Folded convolution WITHOUT bias, then ONE in-place pass for bias (+ identity) (+ ReLU)
+    (native.bias_act).  PyTorch's MIOpen path would run the bias add, the residual add and the
+    ReLU as separate launches that each stream the whole activation."""
+    y = F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+    if b is None and identity is None:
+        return F.relu(y, inplace=True) if relu else y
+    if not y.is_cuda:                       # host tensors: the same arithmetic with PyTorch ops
+        if b is not None:
+            y = y + b.view(1, -1, 1, 1)
+        if identity is not None:
+            y = y + identity
+        return F.relu(y, inplace=True) if relu else y
+    if b is None:
+        b = y.new_zeros(y.shape[1])
+    return native.bias_act(y, b, identity, relu)
+
+
+def conv_bn(conv, bn, x, relu=False, identity=None):
+    """``act(bn(conv(x)) (+ identity))`` with an eval-mode (frozen-statistics) BatchNorm folded
+    into the convolution: bn(conv(x, w)) = conv(x, w * scale) + shift with scale = gamma /
+    sqrt(var + eps).  Saves two full passes over the activation per conv (the largest maps here
+    are 137 MB in bf16), and the shift / residual / ReLU that remain are one fused pass.  When
     neither the conv weight nor the BN affine require grad (the frozen stem/stage 1 and the whole
     teacher) the folded weight is cached in the compute dtype."""
     if bn.training:
-        return bn(conv(x))
+        y = bn(conv(x))
+        if identity is not None:
+            y = y + identity
+        return F.relu(y, inplace=True) if relu else y
     live = conv.__dict__.get("_folded_live")
     if live is not None:            # produced for all trainable convs at once by ResNet._fold_trainable
-        return F.conv2d(x, live[0], live[1], conv.stride, conv.padding, conv.dilation, conv.groups)
+        return _conv_epilogue(conv, x, live[0], live[1], relu, identity)
     dtype = torch.get_autocast_dtype(x.device.type) if torch.is_autocast_enabled(x.device.type) else x.dtype
     frozen = not (conv.weight.requires_grad or bn.weight.requires_grad or bn.bias.requires_grad)
     key = (conv.weight._version, bn.weight._version, bn.running_var._version, bn.running_mean._version, dtype,
@@ -51,7 +74,7 @@ def conv_bn(conv, bn, x):
             if x.is_cuda and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last):
                 w = w.contiguous(memory_format=torch.channels_last)
             conv.__dict__["_folded"] = (key, w, b)
-    return F.conv2d(x, w, b, conv.stride, conv.padding, conv.dilation, conv.groups)
+    return _conv_epilogue(conv, x, w, b, relu, identity)
 
 
 class _FoldTrainable(torch.autograd.Function):
@@ -103,12 +126,11 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         identity = x
-        out = F.relu(conv_bn(self.conv1, self.bn1, x), inplace=True)
-        out = F.relu(conv_bn(self.conv2, self.bn2, out), inplace=True)
-        out = conv_bn(self.conv3, self.bn3, out)
+        out = conv_bn(self.conv1, self.bn1, x, relu=True)
+        out = conv_bn(self.conv2, self.bn2, out, relu=True)
         if self.downsample is not None:
             identity = conv_bn(self.downsample[0], self.downsample[1], x)
-        return F.relu(out + identity, inplace=True)
+        return conv_bn(self.conv3, self.bn3, out, relu=True, identity=identity)
 
 
 class BasicBlock(nn.Module):
@@ -256,7 +278,7 @@ class ResNet(nn.Module):
     def forward(self, x):
         live = self._fold_trainable(x)
         try:
-            x = F.relu(conv_bn(self.conv1, self.bn1, x), inplace=True)
+            x = conv_bn(self.conv1, self.bn1, x, relu=True)
             x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
             outs = []
             for i, name in enumerate(self.res_layers):

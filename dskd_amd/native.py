@@ -33,6 +33,7 @@ _SIGNATURES = {
     "dskd_add_ln_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, _f32, _f32,
                                    C.c_uint64, C.c_uint64, C.c_int, _vp]),
     "dskd_add_ln_bwd": (C.c_int, [_vp] * 9 + [_i64, C.c_int, _f32, C.c_uint64, C.c_uint64, C.c_int, _vp]),
+    "dskd_bias_act": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_lsap_host": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "dskd_lsap_batched": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "dskd_match_cost": (C.c_int, [_vp] * 7 + [C.c_int] * 3 + [_f32] * 3 + [_vp]),
@@ -360,6 +361,49 @@ def add_layer_norm(h: torch.Tensor, res: torch.Tensor, norm: torch.nn.LayerNorm,
         res = res.to(h.dtype)
     y, q = _AddLNFunction.apply(h, res, norm.weight, norm.bias, pos, float(norm.eps), float(p), bool(want_q))
     return y, q
+
+
+# --------------------------------------------------------------------------- conv epilogue
+class _BiasActFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias, identity, relu):
+        dt = {torch.float32: DTYPE_F32, torch.bfloat16: DTYPE_BF16}[x.dtype]
+        Cc = x.shape[1]
+        rc = load().dskd_bias_act(x.data_ptr(), bias.data_ptr(), None if identity is None else identity.data_ptr(),
+                                  x.numel(), Cc, 1 if relu else 0, dt, _stream(x))
+        _check(rc, "dskd_bias_act")
+        ctx.mark_dirty(x)
+        ctx.relu = relu
+        if relu:
+            ctx.save_for_backward(x)
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.relu:
+            (y,) = ctx.saved_tensors
+            g = torch.ops.aten.threshold_backward(g, y, 0)
+        gb = g.sum((0, 2, 3)) if ctx.needs_input_grad[1] else None
+        return g, gb, (g if ctx.needs_input_grad[2] else None), None
+
+
+def bias_act(x: torch.Tensor, bias: torch.Tensor, identity: Optional[torch.Tensor] = None, relu: bool = False):
+    """``act(x + bias[None, :, None, None] (+ identity))`` IN PLACE on ``x`` (a convolution
+    output in channels_last memory): the tail of ResNet's conv -> folded BN -> (+ identity) ->
+    ReLU (reference mmdet/models/backbones/resnet.py:271-303) as one pass instead of up to four."""
+    f = _dispatch_cpu("bias_act", x)
+    if f is not None:
+        return f(x, bias, identity, relu)
+    vec = 8 if x.dtype == torch.bfloat16 else 4
+    if x.dim() != 4 or x.dtype not in (torch.float32, torch.bfloat16) or x.shape[1] % vec != 0 \
+            or not x.is_contiguous(memory_format=torch.channels_last) or bias.dtype != x.dtype \
+            or (identity is not None and (identity.dtype != x.dtype or identity.shape != x.shape or
+                                          not identity.is_contiguous(memory_format=torch.channels_last))):
+        y = x + bias.to(x.dtype).view(1, -1, 1, 1)          # layouts the kernel does not take
+        if identity is not None:
+            y = y + identity
+        return torch.relu_(y) if relu else y
+    return _BiasActFunction.apply(x, bias.contiguous(), identity, relu)
 
 
 # --------------------------------------------------------------------------- LSAP

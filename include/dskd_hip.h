@@ -37,6 +37,10 @@
  *       and run by DetrTransformerEncoder :454-483 / DeformableDetrTransformerDecoder
  *       :625-710): `identity + dropout(out)` of MultiScaleDeformableAttention / FFN, the
  *       following 'norm' (nn.LayerNorm) and the next layer's `query + query_pos`.
+ *   dskd_bias_act
+ *       the elementwise tail of a ResNet conv->BN->ReLU group with the frozen BN folded into
+ *       the convolution: `self.relu(norm(conv(x)))` and `out += identity; out = self.relu(out)`
+ *       (mmdet/models/backbones/resnet.py:271-303).
  */
 #ifndef DSKD_HIP_H
 #define DSKD_HIP_H
@@ -231,6 +235,16 @@ int dskd_add_ln_bwd(const void* dy, const void* dq, const void* z, const float* 
                     const float* gamma, void* dres, void* dh, float* dgamma, float* dbeta,
                     int64_t rows, int D, float drop_p, uint64_t seed, uint64_t offset, int dtype,
                     void* stream);
+
+/* ---------------------------------------------------------------------------
+ * In-place epilogue of a folded convolution:  x = act(x + bias[c] (+ identity))
+ * x, identity  device, channels_last activation [N, H, W, C] (C innermost), n = N*H*W*C elements,
+ *              f32 | bf16 (dtype); identity may be NULL
+ * bias         device, [C] same dtype;  relu != 0 applies max(., 0)
+ * Requires C % 8 == 0 (bf16) / C % 4 == 0 (f32), 16-byte aligned pointers.
+ * ------------------------------------------------------------------------- */
+int dskd_bias_act(void* x, const void* bias, const void* identity, int64_t n, int C, int relu,
+                  int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -23,6 +23,13 @@ class OracleChecker:
         loc = ref.float()[..., None, :, None, :] + off / norm[None, :, None, :]
         return loc, attn
 
+    def bias_act(self, x, bias, identity, relu):
+        """resnet.py:271-303: norm(conv) is conv + per-channel bias once the frozen BN is folded."""
+        y = x + bias.view(1, -1, 1, 1)
+        if identity is not None:
+            y = y + identity
+        return torch.relu(y) if relu else y
+
     def add_layer_norm(self, h, res, norm, p, pos, want_q):
         """The module chain itself (ext-mmcv BaseTransformerLayer): identity + dropout(out), the
         'norm' op, and the next layer's query + query_pos."""

@@ -27,3 +27,16 @@ for r in step:
 N=int(sys.argv[2]) if len(sys.argv)>2 else 40
 for k,(t,c) in sorted(agg.items(), key=lambda kv:-kv[1][0])[:N]:
     print(f"{t/1e6:8.2f} ms {c:5d}  {k}")
+# per-queue busy time / union coverage of the last step
+qs = collections.defaultdict(list)
+for r in step:
+    qs[r.get('Queue_Id', r.get('Stream_Id', '?'))].append((int(r['Start_Timestamp']), int(r['End_Timestamp'])))
+allint = sorted((s_, e_) for v in qs.values() for s_, e_ in v)
+cov = 0; cur_s, cur_e = allint[0]
+for s_, e_ in allint[1:]:
+    if s_ > cur_e: cov += cur_e - cur_s; cur_s, cur_e = s_, e_
+    else: cur_e = max(cur_e, e_)
+cov += cur_e - cur_s
+print(f"union of kernel intervals {cov/1e6:.1f} ms of wall {(en-st)/1e6:.1f} ms -> GPU idle {(en-st-cov)/1e6:.1f} ms")
+for q, v in qs.items():
+    print(f"  queue {q}: {len(v)} kernels, busy {sum(e_-s_ for s_,e_ in v)/1e6:.1f} ms, span {(max(e_ for _,e_ in v)-min(s_ for s_,_ in v))/1e6:.1f} ms")

@@ -10,10 +10,11 @@ model.lazy_log=True
 opt = build_optimizer(model, cfg.optimizer[0])
 data, synth = bench.make_batch(4, cfg.num_prev, 111, dev)
 data["img"]=data["img"].contiguous(memory_format=torch.channels_last)
-for _ in range(3): bench.train_step(model, model, opt, data, synth, torch.bfloat16)
+ahead = model.teacher_ahead()
+for _ in range(3): bench.train_step(model, model, opt, data, synth, torch.bfloat16, ahead=ahead)
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
-    bench.train_step(model, model, opt, data, synth, torch.bfloat16)
+    bench.train_step(model, model, opt, data, synth, torch.bfloat16, ahead=ahead)
     torch.cuda.synchronize()
 os.makedirs('gpurun_out', exist_ok=True)
 with open('gpurun_out/torch_prof_shapes.txt','w') as f:
@@ -23,3 +24,8 @@ with open('gpurun_out/torch_prof_ops.txt','w') as f:
 print("done")
 with open('gpurun_out/torch_prof_cpu.txt','w') as f:
     f.write(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=70, max_name_column_width=60))
+evs = prof.key_averages(group_by_input_shape=True)
+rows = sorted(evs, key=lambda e: -getattr(e, "self_device_time_total", 0))
+with open('gpurun_out/torch_prof_tsv.txt', 'w') as f:
+    for e in rows[:140]:
+        f.write(f"{e.key[:60]}\t{e.self_device_time_total/1e3:.3f}ms\t{e.count}\t{str(e.input_shapes)[:160]}\n")

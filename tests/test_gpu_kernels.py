@@ -304,6 +304,38 @@ def test_add_layer_norm_full_size_properties():
     torch.testing.assert_close(y2.float(), yf, rtol=2e-2, atol=2e-2)
 
 
+# ----------------------------------------------------------------------------- conv epilogue
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("with_id,relu", [(False, True), (True, True), (True, False), (False, False)])
+def test_bias_act_vs_torch(dtype, with_id, relu, oracle_checker):
+    """In-place bias (+ identity) (+ ReLU) pass after a folded convolution, forward and backward,
+    against the PyTorch ops of ResNet's Bottleneck on the same (rounded) inputs."""
+    g = torch.Generator().manual_seed(4)
+    N, C, H, W = 3, 72, 13, 29                                  # odd sizes; C % 8 == 0
+    x = torch.randn(N, C, H, W, generator=g).to(dtype).contiguous(memory_format=torch.channels_last)
+    idt = torch.randn(N, C, H, W, generator=g).to(dtype).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(C, generator=g).to(dtype)
+    gy = torch.randn(N, C, H, W, generator=g)
+    xr, ir = x.float().clone().requires_grad_(True), idt.float().clone().requires_grad_(True)
+    yr = oracle_checker.bias_act(xr, b.float(), ir if with_id else None, relu)
+    (yr * gy).sum().backward()
+    xd = x.to(DEV).requires_grad_(True)
+    idd = idt.to(DEV).requires_grad_(True)
+    xin = xd * 1.0                                              # a non-leaf, like a convolution output
+    y = native.bias_act(xin, b.to(DEV), idd if with_id else None, relu)
+    assert y.data_ptr() == xin.data_ptr()                       # in place
+    (y.float() * gy.to(DEV)).sum().backward()
+    tol = dict(rtol=1e-6, atol=1e-6) if dtype == torch.float32 else dict(rtol=1e-2, atol=2e-2)
+    torch.testing.assert_close(y.float().cpu(), yr.detach(), **tol)
+    torch.testing.assert_close(xd.grad.float().cpu(), xr.grad, **tol)
+    if with_id:
+        torch.testing.assert_close(idd.grad.float().cpu(), ir.grad, **tol)
+    # layouts the kernel does not take fall back to the same arithmetic on the GPU
+    xc = x.to(DEV).contiguous()                                 # NCHW-contiguous
+    y2 = native.bias_act(xc.clone(), b.to(DEV), None, relu)
+    torch.testing.assert_close(y2.float().cpu(), oracle_checker.bias_act(x.float(), b.float(), None, relu), **tol)
+
+
 # ----------------------------------------------------------------------------- LSAP
 def _lsap_device(mats):
     flat = torch.cat([torch.from_numpy(m).reshape(-1) for m in mats]).to(DEV)
