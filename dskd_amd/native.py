@@ -34,6 +34,8 @@ _SIGNATURES = {
                                    C.c_uint64, C.c_uint64, C.c_int, _vp]),
     "dskd_add_ln_bwd": (C.c_int, [_vp] * 9 + [_i64, C.c_int, _f32, C.c_uint64, C.c_uint64, C.c_int, _vp]),
     "dskd_bias_act": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, _vp]),
+    "dskd_dropout_fwd": (C.c_int, [_vp, _i64, _f32, C.c_uint64, C.c_uint64, C.c_int, _vp]),
+    "dskd_relu_dropout_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int, _f32, C.c_int, _vp]),
     "dskd_lsap_host": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "dskd_lsap_batched": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "dskd_match_cost": (C.c_int, [_vp] * 7 + [C.c_int] * 3 + [_f32] * 3 + [_vp]),
@@ -361,6 +363,33 @@ def add_layer_norm(h: torch.Tensor, res: torch.Tensor, norm: torch.nn.LayerNorm,
         res = res.to(h.dtype)
     y, q = _AddLNFunction.apply(h, res, norm.weight, norm.bias, pos, float(norm.eps), float(p), bool(want_q))
     return y, q
+
+
+# --------------------------------------------------------------------------- FFN hidden activation
+def dropout_(y: torch.Tensor, p: float) -> torch.Tensor:
+    """In-place dropout of a contiguous bf16 tensor, Philox mask not stored (the backward of the
+    FFN recovers it from ``y != 0``, see :func:`relu_dropout_bwd`).  Raw op, no autograd."""
+    _need_gpu(y)
+    if p > 0:
+        seed, offset = _next_drop_key()
+        rc = load().dskd_dropout_fwd(y.data_ptr(), y.numel(), p, seed, offset, DTYPE_BF16, _stream(y))
+        _check(rc, "dskd_dropout_fwd")
+    return y
+
+
+def relu_dropout_bwd(g: torch.Tensor, y_dropped: torch.Tensor, p: float, want_colsum: bool = True):
+    """Backward of ``dropout_p(relu(.))`` given its OUTPUT: ``g * (y_dropped != 0) / (1 - p)`` and
+    the column sums of that (the bias gradient of the Linear in front).  [rows, C] bf16."""
+    _need_gpu(g, y_dropped)
+    g = g.contiguous()
+    Cc = g.shape[-1]
+    rows = g.numel() // Cc
+    out = torch.empty_like(g)
+    colsum = torch.zeros(Cc, dtype=torch.float32, device=g.device) if want_colsum else None
+    rc = load().dskd_relu_dropout_bwd(g.data_ptr(), y_dropped.data_ptr(), out.data_ptr(),
+                                      None if colsum is None else colsum.data_ptr(), rows, Cc, p, DTYPE_BF16, _stream(g))
+    _check(rc, "dskd_relu_dropout_bwd")
+    return out, colsum
 
 
 # --------------------------------------------------------------------------- conv epilogue

@@ -89,6 +89,54 @@ class _TallLinearFn(torch.autograd.Function):
         return gx, gw, gb, None, None
 
 
+class _FFNInnerFn(torch.autograd.Function):
+    """``dropout_p(relu(x W^T + b))`` of the FFN for a very tall bf16 ``x`` on the GPU: bias + ReLU
+    in the GEMM epilogue, dropout in place without a stored mask, and ONE backward pass that
+    applies dropout + ReLU backward and yields the bias gradient (native.relu_dropout_bwd);
+    dX is a GEMM, dW the split-K bmm of :class:`_TallLinearFn`."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, chunk, p):
+        ctx.chunk, ctx.p = chunk, p
+        y = torch._addmm_activation(bias, x, weight.t())
+        native.dropout_(y, p)
+        ctx.save_for_backward(x, weight, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, y = ctx.saved_tensors
+        g1, colsum = native.relu_dropout_bwd(g, y, ctx.p, want_colsum=ctx.needs_input_grad[2])
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = g1 @ weight
+        if ctx.needs_input_grad[1]:
+            nb = x.shape[0] // ctx.chunk
+            part = torch.bmm(g1.view(nb, ctx.chunk, -1).transpose(1, 2), x.view(nb, ctx.chunk, -1))
+            gw = part.sum(0, dtype=torch.float32).to(weight.dtype)
+        if colsum is not None:
+            gb = colsum.to(g.dtype)
+        return gx, gw, gb, None, None
+
+
+def ffn_inner(x, weight, bias, p):
+    """Linear + ReLU + Dropout(p) of the FFN.  Tall bf16 GPU inputs that need gradients take
+    :class:`_FFNInnerFn`; everything else is ``tall_linear(relu=True)`` + ``F.dropout``."""
+    dev = x.device.type
+    tokens = x.numel() // max(x.shape[-1], 1)
+    dtype = torch.get_autocast_dtype(dev) if torch.is_autocast_enabled(dev) else x.dtype
+    if x.is_cuda and dtype == torch.bfloat16 and tokens >= 16384 and weight.requires_grad and bias is not None \
+            and torch.is_grad_enabled() and x.is_contiguous() and weight.shape[0] in (256, 512, 1024, 2048):
+        chunk = _token_chunk(tokens, weight.numel())
+        if chunk is not None:
+            x2 = x.reshape(tokens, x.shape[-1]).to(dtype)
+            with torch.autocast(dev, enabled=False):
+                y = _FFNInnerFn.apply(x2, weight.to(dtype), bias.to(dtype), chunk, float(p))
+            return y.view(*x.shape[:-1], y.shape[-1])
+    y = tall_linear(x, weight, bias, relu=True)
+    return F.dropout(y, p, training=True) if p > 0 else y
+
+
 class _CastParams(torch.autograd.Function):
     """fp32 master parameters -> compute dtype in ONE multi-tensor launch, and their gradients
     back in one.  torch.autocast does the same per parameter: ~200 cast launches forward and as
@@ -439,8 +487,7 @@ class FFN(nn.Module):
         if self.num_fcs == 2 and isinstance(first[1], nn.ReLU) and first[0].weight.requires_grad:
             # Linear + ReLU as one GEMM with a fused epilogue, then the rest of the stack
             w1, b1 = first[0].lp()
-            out = tall_linear(x, w1, b1, relu=True)
-            out = first[2](out)
+            out = ffn_inner(x, w1, b1, first[2].p if first[2].training else 0.0)
             for m in rest:
                 out = m(out)
         elif self.num_fcs == 2 and isinstance(first[1], nn.ReLU) and x.is_cuda and not torch.is_grad_enabled() \

@@ -37,6 +37,10 @@
  *       and run by DetrTransformerEncoder :454-483 / DeformableDetrTransformerDecoder
  *       :625-710): `identity + dropout(out)` of MultiScaleDeformableAttention / FFN, the
  *       following 'norm' (nn.LayerNorm) and the next layer's `query + query_pos`.
+ *   dskd_dropout_fwd / dskd_relu_dropout_bwd
+ *       `Sequential(Linear, ReLU, Dropout)` of ext-mmcv FFN (mmcv/cnn/bricks/transformer.py),
+ *       the feed-forward of every transformer layer (mmdet/models/utils/transformer.py:454-483):
+ *       the Dropout forward, and Dropout + ReLU backward + the Linear's bias gradient.
  *   dskd_bias_act
  *       the elementwise tail of a ResNet conv->BN->ReLU group with the frozen BN folded into
  *       the convolution: `self.relu(norm(conv(x)))` and `out += identity; out = self.relu(out)`
@@ -245,6 +249,21 @@ int dskd_add_ln_bwd(const void* dy, const void* dq, const void* z, const float* 
  * ------------------------------------------------------------------------- */
 int dskd_bias_act(void* x, const void* bias, const void* identity, int64_t n, int C, int relu,
                   int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * FFN hidden activation (bf16 only).
+ * dskd_dropout_fwd: y (device, n elements, n % 8 == 0) is overwritten with dropout_p(y); the mask
+ *   is Philox4x32-10(seed, offset) and is NOT stored.
+ * dskd_relu_dropout_bwd: for y_dropped = dropout_p(relu(.)),
+ *       out = g * (y_dropped != 0) / (1 - p)        (ReLU active AND kept <=> y_dropped != 0)
+ *       colsum[c] += sum over rows of out[:, c]     (the bias gradient of the Linear before the
+ *                                                    ReLU; NULL to skip, else zeroed by the caller)
+ *   g, y_dropped, out device [rows, C]; C in {256, 512, 1024, 2048}.
+ * ------------------------------------------------------------------------- */
+int dskd_dropout_fwd(void* y, int64_t n, float p, uint64_t seed, uint64_t offset, int dtype,
+                     void* stream);
+int dskd_relu_dropout_bwd(const void* g, const void* y_dropped, void* out, float* colsum,
+                          int64_t rows, int C, float p, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

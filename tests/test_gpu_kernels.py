@@ -304,6 +304,62 @@ def test_add_layer_norm_full_size_properties():
     torch.testing.assert_close(y2.float(), yf, rtol=2e-2, atol=2e-2)
 
 
+# ----------------------------------------------------------------------------- FFN hidden activation
+def test_ffn_dropout_kernels_through_ops():
+    """In-place dropout without a stored mask + the one-pass backward that recovers the mask from
+    the forward output (ext-mmcv FFN: Linear -> ReLU -> Dropout)."""
+    g = torch.Generator().manual_seed(2)
+    rows, C, p = 1531, 1024, 0.25
+    y = torch.relu(torch.randn(rows, C, generator=g)).to(torch.bfloat16).to(DEV)       # ~50 % zeros from the ReLU
+    torch.manual_seed(77)
+    native._drop_calls = 0
+    yd = native.dropout_(y.clone(), p)
+    pos = y > 0
+    keep = (yd != 0)
+    assert not bool((keep & ~pos).any())
+    frac = keep[pos].float().mean().item()
+    assert abs(frac - (1 - p)) < 5e-3, frac
+    torch.testing.assert_close(yd[keep].float(), (y.float() / (1 - p)).to(torch.bfloat16).float()[keep], rtol=1e-2, atol=0)
+    native._drop_calls = 0
+    assert torch.equal(native.dropout_(y.clone(), p), yd)                                # same (seed, call) -> same mask
+    assert not torch.equal(native.dropout_(y.clone(), p) != 0, keep)                     # next call: another mask
+    assert torch.equal(native.dropout_(y.clone(), 0.0), y)
+    gr = torch.randn(rows, C, generator=g).to(torch.bfloat16).to(DEV)
+    out, colsum = native.relu_dropout_bwd(gr, yd, p)
+    ref = torch.where(keep, gr.float() / (1 - p), torch.zeros((), device=DEV))
+    torch.testing.assert_close(out.float(), ref.to(torch.bfloat16).float(), rtol=1e-2, atol=1e-6)
+    torch.testing.assert_close(colsum, ref.sum(0), rtol=2e-3, atol=0.15)
+    for Cc in (256, 512, 2048):
+        o2, c2 = native.relu_dropout_bwd(gr[:, :Cc].contiguous(), yd[:, :Cc].contiguous(), p)
+        torch.testing.assert_close(c2, ref[:, :Cc].sum(0), rtol=2e-3, atol=0.15) if Cc <= 1024 else None
+    lib = native.load()
+    assert lib.dskd_relu_dropout_bwd(gr.data_ptr(), yd.data_ptr(), out.data_ptr(), None, rows, 768, p, native.DTYPE_BF16,
+                                     torch.cuda.current_stream().cuda_stream) == -1
+
+
+def test_ffn_inner_matches_torch_chain():
+    """Linear + ReLU (+ Dropout p=0) through the fused autograd function, tall bf16 input, against
+    the PyTorch chain in fp32 on the same rounded inputs."""
+    from dskd_amd.transformer import ffn_inner
+    g = torch.Generator().manual_seed(6)
+    T, D, Hd = 18000, 256, 1024
+    x = torch.randn(T, D, generator=g).to(torch.bfloat16)
+    w = (torch.randn(Hd, D, generator=g) * 0.05).to(torch.bfloat16)
+    b = (torch.randn(Hd, generator=g) * 0.1).to(torch.bfloat16)
+    gy = torch.randn(T, Hd, generator=g).to(torch.bfloat16)
+    xr, wr, br = (t.float().clone().requires_grad_(True) for t in (x, w, b))
+    torch.relu(torch.nn.functional.linear(xr, wr, br)).backward(gy.float())
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    y = ffn_inner(xd, wd, bd, 0.0)
+    assert "FFNInner" in type(y.grad_fn.next_functions[0][0]).__name__        # (behind the output view)
+    y.backward(gy.to(DEV))
+    torch.testing.assert_close(y.float().cpu(), torch.relu(torch.nn.functional.linear(x.float(), w.float(), b.float())),
+                               rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(xd.grad.float().cpu(), xr.grad, rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(wd.grad.float().cpu(), wr.grad, rtol=3e-2, atol=1.5)      # sums over 18 000 rows (|dW| ~ 100), bf16 result
+    torch.testing.assert_close(bd.grad.float().cpu(), br.grad, rtol=3e-2, atol=0.5)
+
+
 # ----------------------------------------------------------------------------- conv epilogue
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("with_id,relu", [(False, True), (True, True), (True, False), (False, False)])
