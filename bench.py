@@ -25,6 +25,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# MIOpen's default find mode (dynamic hybrid) answers a find-db miss with heuristics and only the
+# NEXT process gets the measured choice: on a fresh box the first run was 55 ms/step and erratic,
+# every later one 43 ms.  NORMAL makes torch.backends.cudnn.benchmark really measure, inside the
+# untimed warm-up (about +50 s of start-up).  Must be set before MIOpen initialises.
+os.environ.setdefault("MIOPEN_FIND_MODE", "1")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -248,12 +253,31 @@ def main():
             return stepper.step(data, inject)
         return train_step(model, wrapped, optimizer, data, synth, amp_dtype, ahead=ahead)[0]
 
+    step_events = [] if os.environ.get("DSKD_BENCH_STEPTIMES") else None    # diagnostic: per-step GPU/host times
+    host_marks = []
+    ms0 = torch.cuda.memory_stats(device) if step_events is not None else None
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = one_step()
+        if step_events is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            step_events.append(ev)
+            host_marks.append(time.perf_counter() - t0)
     sync()
     dt = time.perf_counter() - t0
+    if step_events:
+        ms1 = torch.cuda.memory_stats(device)
+        print("[bench] allocator over the timed region: " + ", ".join(
+            f"{k}={ms1.get(k, 0) - ms0.get(k, 0)}" for k in ("num_device_alloc", "num_device_free", "num_alloc_retries",
+                                                             "num_ooms")) +
+              f", reserved={ms1['reserved_bytes.all.current'] / 2**30:.1f} GiB, "
+              f"active={ms1['active_bytes.all.current'] / 2**30:.1f} GiB", file=sys.stderr)
+        gpu = [step_events[i - 1].elapsed_time(step_events[i]) for i in range(1, len(step_events))]
+        host = [1e3 * (host_marks[i] - host_marks[i - 1]) for i in range(1, len(host_marks))]
+        print("[bench] per-step ms, main stream: " + " ".join(f"{g:.1f}" for g in gpu), file=sys.stderr)
+        print("[bench] per-step ms, host enqueue: " + " ".join(f"{h:.1f}" for h in host), file=sys.stderr, flush=True)
 
     # Roofline probe: the same step, same inputs, launched eagerly so that every MSDeformAttn
     # launch can be bracketed by HIP events on the launch stream (events cannot be recorded

@@ -329,10 +329,12 @@ class MultiScaleDeformableAttention(nn.Module):
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,
                 reference_points=None, spatial_shapes=None, level_start_index=None, tokens_batch_first=None,
-                value_batch_first=None, **kwargs):
+                value_batch_first=None, fuse_tail=False, **kwargs):
         """``tokens_batch_first`` / ``value_batch_first`` (set by DeformableDetrTransformer)
         override the module's ``batch_first`` for query/output and for ``value``: the encoder
-        runs batch-first end to end so that no [B, 22k, 256] tensor is ever permuted+copied."""
+        runs batch-first end to end so that no [B, 22k, 256] tensor is ever permuted+copied.
+        ``fuse_tail``: return the projected output WITHOUT ``dropout(.) + identity`` (the caller
+        folds them into the following LayerNorm launch)."""
         q_bf = self.batch_first if tokens_batch_first is None else tokens_batch_first
         v_bf = q_bf if value_batch_first is None else value_batch_first
         if value is None:
@@ -349,7 +351,12 @@ class MultiScaleDeformableAttention(nn.Module):
         output = self.core(query, value, reference_points, spatial_shapes, key_padding_mask)
         if not q_bf:
             output = output.permute(1, 0, 2)
+        if fuse_tail:
+            return output
         return self.dropout(output) + identity
+
+    def tail_dropout_p(self):
+        return self.dropout.p if self.training else 0.0
 
     def core(self, query, value, reference_points, spatial_shapes, key_padding_mask=None):
         """Batch-first body of ``forward``: ``query`` already carries its positional encoding;
@@ -429,8 +436,16 @@ class MultiheadAttention(nn.Module):
         self.proj_drop = nn.Dropout(proj_drop)
         self.dropout_layer = nn.Dropout(dropout_layer["drop_prob"]) if dropout_layer else nn.Identity()
 
+    def tail_dropout_p(self):
+        """p of ``dropout_layer`` when the tail can be fused (no extra ``proj_drop``), else None."""
+        if self.proj_drop.p != 0 and self.training:
+            return None
+        if isinstance(self.dropout_layer, nn.Identity):
+            return 0.0
+        return self.dropout_layer.p if self.training else 0.0
+
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_pos=None, attn_mask=None,
-                key_padding_mask=None, **kwargs):
+                key_padding_mask=None, fuse_tail=False, **kwargs):
         if key is None:
             key = query
         if value is None:
@@ -449,6 +464,8 @@ class MultiheadAttention(nn.Module):
                         need_weights=False)[0]
         if self.batch_first:
             out = out.transpose(0, 1)
+        if fuse_tail:
+            return out
         return identity + self.dropout_layer(self.proj_drop(out))
 
 
@@ -478,6 +495,13 @@ class FFN(nn.Module):
         if identity is None:
             identity = x
         return identity + self.dropout_layer(out)
+
+    def tail_dropout_p(self):
+        """p of the trailing ``Dropout(ffn_drop)`` when the tail can be fused, else None."""
+        if not self.add_identity or not isinstance(self.dropout_layer, nn.Identity) or \
+                not isinstance(self.layers[-1], nn.Dropout):
+            return None
+        return self.layers[-1].p if self.training else 0.0
 
     def core(self, x, final_dropout):
         """The Linear/act/Dropout stack; ``final_dropout=False`` leaves out the trailing
@@ -551,14 +575,71 @@ class BaseTransformerLayer(nn.Module):
             self.ffns.append(build_feedforward_network(c))
         self.norms = nn.ModuleList(nn.LayerNorm(self.embed_dims) for _ in range(operation_order.count("norm")))
 
+    def _fused_plan(self):
+        """[(op, module, norm)] when the layer is post-norm with every sub-layer followed by its
+        LayerNorm and 256 wide, else None.  Cached."""
+        plan = self.__dict__.get("_fused_plan_cache", False)
+        if plan is False:
+            order = tuple(self.operation_order)
+            plan = None
+            if not self.pre_norm and len(order) % 2 == 0 and self.embed_dims == 256 and \
+                    all(o != "norm" for o in order[0::2]) and all(o == "norm" for o in order[1::2]):
+                plan, ai, fi = [], 0, 0
+                for k, op in enumerate(order[0::2]):
+                    if op == "ffn":
+                        mod, fi = self.ffns[fi], fi + 1
+                    else:
+                        mod, ai = self.attentions[ai], ai + 1
+                    if not hasattr(mod, "tail_dropout_p") or not self.norms[k].elementwise_affine:
+                        plan = None
+                        break
+                    plan.append((op, mod, self.norms[k]))
+            self.__dict__["_fused_plan_cache"] = plan
+        return plan
+
+    def _forward_fused(self, plan, query, key, value, query_pos, key_pos, attn_masks, query_key_padding_mask,
+                       key_padding_mask, kwargs):
+        """MI355X path of a post-norm layer on the GPU: every ``identity + dropout(out)`` -> LayerNorm
+        is one HIP launch each way (native.add_layer_norm) and the residual stream stays in the
+        compute dtype -- PyTorch's mixed-dtype adds alone cost 60 us each on the 300-query decoder."""
+        dev = query.device.type
+        dtype = torch.get_autocast_dtype(dev) if torch.is_autocast_enabled(dev) else query.dtype
+        x = query.to(dtype)
+        if query_pos is not None and query_pos.dtype != dtype:
+            query_pos = query_pos.to(dtype)
+        if key_pos is not None and key_pos.dtype != dtype:
+            key_pos = key_pos.to(dtype)
+        ai = 0
+        for op, mod, norm in plan:
+            p = mod.tail_dropout_p()
+            if op == "ffn":
+                h = mod.core(x, final_dropout=False)
+            elif op == "self_attn":
+                h = mod(x, x, x, None, query_pos=query_pos, key_pos=query_pos, attn_mask=attn_masks[ai],
+                        key_padding_mask=query_key_padding_mask, fuse_tail=True, **kwargs)
+                ai += 1
+            else:
+                h = mod(x, key, value, None, query_pos=query_pos, key_pos=key_pos, attn_mask=attn_masks[ai],
+                        key_padding_mask=key_padding_mask, fuse_tail=True, **kwargs)
+                ai += 1
+            x, _ = native.add_layer_norm(h.to(dtype), x, norm, p=p)
+        return x
+
     def forward(self, query, key=None, value=None, query_pos=None, key_pos=None, attn_masks=None,
                 query_key_padding_mask=None, key_padding_mask=None, **kwargs):
-        norm_index = attn_index = ffn_index = 0
-        identity = query
         if attn_masks is None:
             attn_masks = [None] * self.num_attn
         elif isinstance(attn_masks, torch.Tensor):
             attn_masks = [copy.deepcopy(attn_masks) for _ in range(self.num_attn)]
+        dev = query.device.type
+        if query.is_cuda and (torch.get_autocast_dtype(dev) if torch.is_autocast_enabled(dev) else query.dtype) in (
+                torch.float32, torch.bfloat16):
+            plan = self._fused_plan()
+            if plan is not None and all(m.tail_dropout_p() is not None for _, m, _ in plan):
+                return self._forward_fused(plan, query, key, value, query_pos, key_pos, attn_masks,
+                                           query_key_padding_mask, key_padding_mask, kwargs)
+        norm_index = attn_index = ffn_index = 0
+        identity = query
         for layer in self.operation_order:
             if layer == "self_attn":
                 temp_key = temp_value = query

@@ -20,6 +20,7 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
+os.environ.setdefault("MIOPEN_FIND_MODE", "1")   # measured conv algorithm choice in the first process too (see bench.py)
 import torch  # noqa: E402
 
 import dskd_amd  # noqa: E402,F401
