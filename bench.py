@@ -119,8 +119,8 @@ def train_step(model, wrapped, optimizer, data, synth, amp_dtype, max_norm=0.1, 
         losses = wrapped(img=data["img"], img_metas=data["img_metas"], gt_bboxes=data["gt_bboxes"],
                          gt_labels=data["gt_labels"], teacher_info=teacher_info)
         loss, log_vars = module._parse_losses(losses)
-        if ahead is not None:
-            ahead.launch(data["img"], data["img_metas"])      # the next batch (synthetic: the same tensors)
+    if ahead is not None:       # the next batch (synthetic: the same tensors), enqueued behind the backward
+        ahead.launch(data["img"], data["img_metas"], amp_dtype=amp_dtype, background=bool(os.environ.get("DSKD_AHEAD_THREAD")))
     loss.backward()
     params = [p for gr in optimizer.param_groups for p in gr["params"] if p.grad is not None]
     torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm, norm_type=2)

@@ -98,10 +98,66 @@ __global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const __bf16* __r
   }
 }
 
+// Column sums of a tall [rows, C] bf16 matrix (the bias gradient of a Linear: sum over tokens of
+// the output gradient).  ATen's generic reduction takes ~40 us for 88 892 x 256 (45 MB); this is
+// the same streaming structure as above: a thread keeps 8 columns, partial sums per workgroup in
+// LDS, one atomic per column and workgroup.
+template <int TPR>
+__global__ __launch_bounds__(256) void colsum_kernel(const __bf16* __restrict__ x, float* __restrict__ colsum,
+                                                     long long rows) {
+  constexpr int RPB = 256 / TPR;
+  constexpr int C = TPR * 8;
+  __shared__ float s_part[RPB][C];
+  const int t = threadIdx.x % TPR, rsub = threadIdx.x / TPR;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (rsub < RPB) {
+    for (long long row = (long long)blockIdx.x * RPB + rsub; row < rows; row += (long long)gridDim.x * RPB) {
+      float v[8];
+      unpack8(*reinterpret_cast<const u32x4*>(x + row * C + t * 8), v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += v[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s_part[rsub][t * 8 + k] = acc[k];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < RPB; ++r) s += s_part[r][c];
+    atomicAdd(colsum + c, s);
+  }
+}
+
 }  // namespace
 }  // namespace dskd
 
 using namespace dskd;
+
+extern "C" int dskd_colsum(const void* x, float* colsum, int64_t rows, int C, int dtype, void* stream) {
+  if (dtype != DSKD_DTYPE_BF16) return fail(DSKD_ERR_INVALID_ARG, "dskd_colsum: bf16 only");
+  if (rows == 0) return DSKD_OK;
+  if (!x || !colsum || rows < 0 || (reinterpret_cast<uintptr_t>(x) & 15))
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_colsum: null / unaligned pointer or negative row count");
+  hipStream_t st = (hipStream_t)stream;
+  const __bf16* xp = (const __bf16*)x;
+#define DSKD_LAUNCH_COLSUM(TPR)                                                                          \
+  {                                                                                                      \
+    const long long want = (rows + (256 / TPR) - 1) / (256 / TPR);                                       \
+    hipLaunchKernelGGL(colsum_kernel<TPR>, dim3((unsigned)(want < 1024 ? want : 1024)), dim3(256), 0,   \
+                       st, xp, colsum, (long long)rows);                                                 \
+  }
+  switch (C) {
+    case 256: DSKD_LAUNCH_COLSUM(32) break;
+    case 384: DSKD_LAUNCH_COLSUM(48) break;
+    case 512: DSKD_LAUNCH_COLSUM(64) break;
+    case 1024: DSKD_LAUNCH_COLSUM(128) break;
+    case 2048: DSKD_LAUNCH_COLSUM(256) break;
+    default: return fail(DSKD_ERR_INVALID_ARG, "dskd_colsum: C must be 256, 384, 512, 1024 or 2048 (got %d)", C);
+  }
+#undef DSKD_LAUNCH_COLSUM
+  return check_launch("dskd_colsum");
+}
 
 extern "C" int dskd_dropout_fwd(void* y, int64_t n, float p, uint64_t seed, uint64_t offset, int dtype,
                                 void* stream) {

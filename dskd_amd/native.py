@@ -36,6 +36,7 @@ _SIGNATURES = {
     "dskd_bias_act": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_dropout_fwd": (C.c_int, [_vp, _i64, _f32, C.c_uint64, C.c_uint64, C.c_int, _vp]),
     "dskd_relu_dropout_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int, _f32, C.c_int, _vp]),
+    "dskd_colsum": (C.c_int, [_vp, _vp, _i64, C.c_int, C.c_int, _vp]),
     "dskd_lsap_host": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "dskd_lsap_batched": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "dskd_match_cost": (C.c_int, [_vp] * 7 + [C.c_int] * 3 + [_f32] * 3 + [_vp]),
@@ -390,6 +391,19 @@ def relu_dropout_bwd(g: torch.Tensor, y_dropped: torch.Tensor, p: float, want_co
                                       None if colsum is None else colsum.data_ptr(), rows, Cc, p, DTYPE_BF16, _stream(g))
     _check(rc, "dskd_relu_dropout_bwd")
     return out, colsum
+
+
+COLSUM_WIDTHS = (256, 384, 512, 1024, 2048)
+
+
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    """fp32 column sums of a contiguous [rows, C] bf16 GPU matrix (bias gradient of a Linear)."""
+    _need_gpu(x)
+    Cc = x.shape[-1]
+    out = torch.zeros(Cc, dtype=torch.float32, device=x.device)
+    rc = load().dskd_colsum(x.data_ptr(), out.data_ptr(), x.numel() // Cc, Cc, DTYPE_BF16, _stream(x))
+    _check(rc, "dskd_colsum")
+    return out
 
 
 # --------------------------------------------------------------------------- conv epilogue

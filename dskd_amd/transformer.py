@@ -85,7 +85,10 @@ class _TallLinearFn(torch.autograd.Function):
             part = torch.bmm(g2.view(nb, ctx.chunk, -1).transpose(1, 2), x2.view(nb, ctx.chunk, -1))
             gw = part.sum(0, dtype=torch.float32).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = g2.sum(0, dtype=torch.float32).to(g.dtype)
+            if g2.is_cuda and g2.dtype == torch.bfloat16 and g2.shape[-1] in native.COLSUM_WIDTHS and g2.is_contiguous():
+                gb = native.colsum(g2).to(g.dtype)
+            else:
+                gb = g2.sum(0, dtype=torch.float32).to(g.dtype)
         return gx, gw, gb, None, None
 
 

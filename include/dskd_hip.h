@@ -264,6 +264,10 @@ int dskd_dropout_fwd(void* y, int64_t n, float p, uint64_t seed, uint64_t offset
                      void* stream);
 int dskd_relu_dropout_bwd(const void* g, const void* y_dropped, void* out, float* colsum,
                           int64_t rows, int C, float p, int dtype, void* stream);
+/* colsum[c] += sum over rows of x[:, c]  -- the bias gradient of a Linear (`grad.sum(0)` in
+ * AddmmBackward of every nn.Linear of the transformer).  x device [rows, C] bf16, C in
+ * {256, 384, 512, 1024, 2048}; colsum device [C] f32, zeroed by the caller. */
+int dskd_colsum(const void* x, float* colsum, int64_t rows, int C, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -337,6 +337,16 @@ def test_ffn_dropout_kernels_through_ops():
                                      torch.cuda.current_stream().cuda_stream) == -1
 
 
+@pytest.mark.parametrize("C", native.COLSUM_WIDTHS)
+def test_colsum_bias_gradient(C):
+    """Column sums of a tall bf16 matrix (the bias gradient of a Linear) against fp64 torch."""
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(7013, C, generator=g).to(torch.bfloat16)
+    out = native.colsum(x.to(DEV)).cpu()
+    torch.testing.assert_close(out.double(), x.double().sum(0), rtol=1e-4, atol=1e-2)
+    assert native.colsum(x[:0].to(DEV)).abs().max() == 0
+
+
 def test_ffn_inner_matches_torch_chain():
     """Linear + ReLU (+ Dropout p=0) through the fused autograd function, tall bf16 input, against
     the PyTorch chain in fp32 on the same rounded inputs."""
