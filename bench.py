@@ -120,7 +120,7 @@ def train_step(model, wrapped, optimizer, data, synth, amp_dtype, max_norm=0.1, 
                          gt_labels=data["gt_labels"], teacher_info=teacher_info)
         loss, log_vars = module._parse_losses(losses)
     if ahead is not None:       # the next batch (synthetic: the same tensors), enqueued behind the backward
-        ahead.launch(data["img"], data["img_metas"], amp_dtype=amp_dtype, background=bool(os.environ.get("DSKD_AHEAD_THREAD")))
+        ahead.launch(data["img"], data["img_metas"], amp_dtype=amp_dtype)
     loss.backward()
     params = [p for gr in optimizer.param_groups for p in gr["params"] if p.grad is not None]
     torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm, norm_type=2)
@@ -168,6 +168,8 @@ def main():
                     "(dskd_amd/graph_step.py) instead of eager launches + DDP")
     ap.add_argument("--no-teacher-ahead", action="store_true", help="run the teacher inline on the main stream "
                     "(its decode then drains the stream mid-step) instead of one batch ahead on a second stream")
+    ap.add_argument("--no-teacher-graph", action="store_true", help="enqueue the ahead-of-time teacher forward "
+                    "eagerly instead of replaying it as a hipGraph")
     ap.add_argument("--probe-steps", type=int, default=3, help="eager steps after the timed region that bracket "
                     "every MSDeformAttn launch with HIP events (roofline)")
     ap.add_argument("--seed", type=int, default=111)
@@ -244,9 +246,12 @@ def main():
         optimizer = build_optimizer(model, cfg.optimizer[0])
         ahead = None if args.no_teacher_ahead else model.teacher_ahead()
         if ahead is not None:
-            mode += "+teacher_ahead"
+            ahead.use_graphs = not args.no_teacher_graph
+            mode += "+teacher_ahead" + ("(hipgraph)" if ahead.use_graphs else "")
         for _ in range(args.warmup):     # the first step runs its teacher inline, then the pipeline is primed
             loss, lv = train_step(model, wrapped, optimizer, data, synth, amp_dtype, ahead=ahead)
+        if ahead is not None and ahead.use_graphs and not any(ahead._graphs.values()):
+            mode = mode.replace("(hipgraph)", "(hipgraph pending)" if not ahead._graphs else "(hipgraph rejected)")
 
     def one_step():
         if stepper is not None:

@@ -37,6 +37,7 @@ class TeacherAhead:
     for it the main stream still holds the queued backward + optimizer of the previous batch:
 
         launch(img, metas)   enqueue teacher backbone/neck/transformer/heads on the side stream
+                             (a hipGraph replay once the batch signature repeats)
         finish()             decode on the side stream (host waits for THAT stream only), make
                              the main stream wait for it, hand the tensors over
 
@@ -44,57 +45,92 @@ class TeacherAhead:
     ``finish()`` at the top of a step (falls back to an inline teacher when nothing is
     pending), ``launch(next batch)`` right after the student forward has been enqueued."""
 
-    def __init__(self, detector):
+    def __init__(self, detector, use_graphs=True, graph_warmup=2):
         self.det = detector
         self.stream = None
         self.pending = None
-        self._thread = None
+        self.use_graphs = use_graphs
+        self.graph_warmup = graph_warmup
+        self._graphs, self._seen, self._flip = {}, {}, 0
 
-    def launch(self, img, img_metas, amp_dtype=None, background=False):
-        """Enqueue the teacher forward of ``img`` on the side stream.  ``background=True`` does the
-        enqueueing (8-10 ms of host time: ~550 launches) on a helper thread, so that it overlaps
-        the host side of ``loss.backward()`` (the autograd engine runs in C++ threads and the
-        calling thread only waits): call it right before ``backward`` and ``finish`` joins.
-        ``amp_dtype``: autocast dtype to run under (thread-local state, hence explicit)."""
+    # The teacher FORWARD is also replayed as a hipGraph once a batch signature has been seen
+    # ``graph_warmup`` times: ~550 launches (8 ms of host time) become one.  This is safe where the
+    # training step as a whole is not (graph_step.py): the no-grad forward contains no memset
+    # node (checked with the profiler) and replays with changing inputs track eager results
+    # (scratch/teacher_graph_check.py); the capture is verified against the eager result right
+    # away and dropped if it disagrees.  Two graphs with separate output buffers alternate, so
+    # batch i's teacher tensors stay intact while batch i+1's forward runs beside the student's
+    # backward of batch i.
+    def _forward(self, img, img_metas, amp_dtype):
         det = self.det
+        with torch.no_grad(), torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
+            feats = det.teacher_model.extract_feat(img)
+            outs = det.teacher_model.bbox_head.forward(feats, img_metas)
+        return feats, outs
+
+    @staticmethod
+    def _signature(img, img_metas, amp_dtype):
+        return (tuple(img.shape), img.dtype, img.is_contiguous(memory_format=torch.channels_last), amp_dtype,
+                tuple(tuple(m["img_shape"]) for m in img_metas),
+                tuple(tuple(m.get("batch_input_shape", ())) for m in img_metas))
+
+    def _capture(self, img, img_metas, amp_dtype):
+        """Two graphs (double buffer) on the side stream; None when the replay does not reproduce
+        the eager forward."""
+        entries = []
+        with torch.cuda.stream(self.stream):
+            ref_feats, ref_outs = self._forward(img, img_metas, amp_dtype)
+        for _ in range(2):
+            static = img.detach().clone(memory_format=torch.preserve_format)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=self.stream):
+                feats, outs = self._forward(static, img_metas, amp_dtype)
+            g.replay()
+            entries.append(dict(graph=g, img=static, feats=feats, outs=outs))
+        torch.cuda.synchronize(img.device)
+        for e in entries:
+            for a, r in zip(_tensors((e["feats"], e["outs"])), _tensors((ref_feats, ref_outs))):
+                if a.dtype.is_floating_point:
+                    scale = float(r.float().abs().max()) + 1e-6
+                    if not bool(torch.isfinite(a.float()).all()) or float((a.float() - r.float()).abs().max()) > 0.05 * scale:
+                        return None
+        return entries
+
+    def launch(self, img, img_metas, amp_dtype=None):
+        """Enqueue the teacher forward of ``img`` on the side stream (eagerly, or as a graph replay).
+        ``amp_dtype``: autocast dtype to run under."""
         if not img.is_cuda:
             self.pending = ("inline", img, img_metas)
             return
         if self.stream is None:
             self.stream = torch.cuda.Stream(device=img.device)
         main = torch.cuda.current_stream(img.device)
+        entries = None
+        if self.use_graphs:
+            sig = self._signature(img, img_metas, amp_dtype)
+            entries = self._graphs.get(sig)
+            if entries is None and sig not in self._graphs:
+                n = self._seen.get(sig, 0)
+                self._seen[sig] = n + 1
+                if n >= self.graph_warmup:
+                    self.stream.wait_stream(main)
+                    entries = self._graphs[sig] = self._capture(img, img_metas, amp_dtype)   # None = keep eager
         self.stream.wait_stream(main)                      # the batch (and anything it depends on) is ready
-
-        def run():
-            try:
-                torch.cuda.set_device(img.device)
-                with torch.cuda.stream(self.stream), torch.no_grad(), \
-                        torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
-                    feats = det.teacher_model.extract_feat(img)
-                    outs = det.teacher_model.bbox_head.forward(feats, img_metas)
-                self.pending = ("ahead", feats, outs, img_metas)
-            except BaseException as e:  # noqa: BLE001  (re-raised by finish)
-                self.pending = ("error", e)
-
-        if background:
-            import threading
-            self.pending = ("thread",)
-            self._thread = threading.Thread(target=run, name="teacher-ahead")
-            self._thread.start()
-        else:
-            run()
-            if self.pending[0] == "error":
-                raise self.pending[1]
+        with torch.cuda.stream(self.stream):
+            if entries:
+                e = entries[self._flip]
+                self._flip ^= 1
+                e["img"].copy_(img, non_blocking=True)
+                e["graph"].replay()
+                feats, outs = e["feats"], e["outs"]
+            else:
+                feats, outs = self._forward(img, img_metas, amp_dtype)
+        self.pending = ("ahead", feats, outs, img_metas)
 
     def finish(self, img=None, img_metas=None):
         """teacher_info of the launched batch (same dict as ``forward_train`` builds)."""
         det = self.det
-        if self._thread is not None:
-            self._thread.join()                            # it has replaced self.pending with its result
-            self._thread = None
         pend, self.pending = self.pending, None
-        if pend is not None and pend[0] == "error":
-            raise pend[1]
         if pend is None or pend[0] == "inline":
             if pend is not None:
                 img, img_metas = pend[1], pend[2]

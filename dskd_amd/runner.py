@@ -113,7 +113,7 @@ class TaskEpochBasedRunner:
             else:
                 out = self.model.train_step(data, self.optimizer)
             if ahead is not None and next_data is not None:
-                ahead.launch(next_data["img"], next_data["img_metas"])
+                ahead.launch(next_data["img"], next_data["img_metas"], amp_dtype=self.amp_dtype)
         out["loss"].backward()
         if self.grad_clip:
             params = [p for g in self.optimizer.param_groups for p in g["params"] if p.grad is not None]

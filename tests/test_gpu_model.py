@@ -217,3 +217,29 @@ def test_bf16_tall_step_tracks_fp32_step():
     assert cosines[0][0] > 0.5, cosines[:5]                       # nothing points the wrong way
     assert cosines[len(cosines) // 10][0] > 0.9, cosines[:30]     # 90 % of the tensors agree to > 0.9
     assert cosines[len(cosines) // 2][0] > 0.97
+
+
+def test_teacher_ahead_graph_replay_tracks_eager_teacher():
+    """After the batch signature has repeated, the ahead-of-time teacher forward is a hipGraph
+    replay (two alternating graphs): with a NEW image every step its outputs must keep tracking
+    the inline teacher, and the previous batch's tensors must stay intact (double buffer)."""
+    cfg, m = _build(seed=5)
+    m.to("cuda:0").train()
+    data, _ = _batch(torch.device("cuda:0"))
+    ahead = m.teacher_ahead()
+    ahead.use_graphs, ahead.graph_warmup = True, 2
+    g = torch.Generator().manual_seed(21)
+    prev = None
+    for step in range(7):
+        img = torch.randn(data["img"].shape, generator=g).to("cuda:0")
+        ahead.launch(img, data["img_metas"])
+        ti = ahead.finish()
+        feats, outs, *_ = m.out_teacher(img, data["img_metas"])
+        for a, b in zip(ti["neck_feats"], feats):
+            torch.testing.assert_close(a, b, rtol=1e-3, atol=1e-3)
+        torch.testing.assert_close(ti["head_outs"][0], outs[0], rtol=1e-3, atol=1e-3)
+        if prev is not None:                                  # batch i-1's tensors were not overwritten
+            torch.testing.assert_close(prev[0], prev[1], rtol=0, atol=0)
+        prev = (ti["neck_feats"][0], ti["neck_feats"][0].clone())
+    entries = [v for v in ahead._graphs.values() if v]
+    assert len(entries) == 1 and len(entries[0]) == 2        # captured, verified, double-buffered
