@@ -183,3 +183,47 @@ def test_incremental_training_plumbing_cpu(cpu_ops, tmp_path):
     model = runners[1].module
     r2 = TaskEpochBasedRunner(model, runners[1].optimizer, max_epochs=1)
     assert r2.resume(os.path.join(str(tmp_path), "task_2_epoch_1.pth")) == dict(task=2, epoch=1, iter=2)
+
+
+def test_checkpoint_hand_over_in_reference_layout(tmp_path):
+    """checkpoints in the reference's (mmcv) layout -- ``{'meta', 'state_dict'}``
+    with keys ``backbone.* / neck.* / bbox_head.*`` -- load into the student (``set_student``) and,
+    with a config path, build the frozen teacher (``set_teacher(config=, ckptfile=)``,
+    deformable_detr_il.py:79-114)."""
+    cfg, src = _tiny_model()
+    sd = src.state_dict()
+    # the names a reference checkpoint carries for this architecture
+    for k in ("backbone.conv1.weight", "backbone.bn1.running_var", "backbone.layer3.5.conv3.weight",
+              "backbone.layer2.0.downsample.0.weight", "neck.convs.0.conv.weight", "neck.convs.2.gn.bias",
+              "neck.extra_convs.0.conv.weight", "bbox_head.query_embedding.weight", "bbox_head.prototype.weight",
+              "bbox_head.cls_branches.0.weight", "bbox_head.reg_branches.0.4.bias",
+              "bbox_head.transformer.level_embeds", "bbox_head.transformer.reference_points.weight",
+              "bbox_head.transformer.encoder.layers.5.attentions.0.sampling_offsets.weight",
+              "bbox_head.transformer.encoder.layers.0.attentions.0.attention_weights.bias",
+              "bbox_head.transformer.encoder.layers.0.ffns.0.layers.0.0.weight",
+              "bbox_head.transformer.encoder.layers.0.ffns.0.layers.1.bias",
+              "bbox_head.transformer.encoder.layers.0.norms.1.weight",
+              "bbox_head.transformer.decoder.layers.0.attentions.0.attn.in_proj_weight",
+              "bbox_head.transformer.decoder.layers.0.attentions.0.attn.out_proj.bias",
+              "bbox_head.transformer.decoder.layers.0.attentions.1.value_proj.weight",
+              "bbox_head.transformer.decoder.layers.5.norms.2.bias"):
+        assert k in sd, k
+    ckpt = tmp_path / "task_1_epoch_12.pth"
+    # a reference checkpoint repeats the shared heads under every decoder-layer index
+    extra = {f"bbox_head.cls_branches.{i}.weight": sd["bbox_head.cls_branches.0.weight"] for i in range(1, 6)}
+    torch.save({"meta": {"epoch": 12}, "state_dict": {**sd, **extra}}, ckpt)
+
+    torch.manual_seed(123)
+    dst = builder.build_detector(copy.deepcopy(cfg.model))
+    dst.init_weights()
+    assert not torch.equal(dst.bbox_head.cls_branches[0].weight, src.bbox_head.cls_branches[0].weight)
+    dst.set_student(ckptfile=str(ckpt))
+    for (n, a), (_, b) in zip(dst.state_dict().items(), src.state_dict().items()):
+        assert torch.equal(a, b), n
+    dst.set_teacher(config=cfg, ckptfile=str(ckpt))            # a Config object or a config file path
+    t = dst.teacher_model
+    assert dst.has_teacher and not t.training and all(not p.requires_grad for p in t.parameters())
+    assert torch.equal(t.backbone.layer4[2].conv3.weight, src.backbone.layer4[2].conv3.weight)
+    assert "teacher_model.backbone.conv1.weight" not in dst.state_dict()
+    dst.load_student(str(ckpt))                                   # drops the teacher (:116-121 of the reference flow)
+    assert not dst.has_teacher
