@@ -41,7 +41,9 @@ from dskd_amd.config import Config  # noqa: E402
 from dskd_amd.graph_step import GraphedDistillStep  # noqa: E402
 from dskd_amd.runner import build_optimizer  # noqa: E402
 
-CONFIG = os.path.join(ROOT, "configs", "dskd_gfl_deformable_detr_r50_70_10.py")
+CONFIGS = {"r50": os.path.join(ROOT, "configs", "dskd_gfl_deformable_detr_r50_70_10.py"),           # BASELINE configs[1]
+           "swin_t": os.path.join(ROOT, "configs", "dskd_gfl_deformable_detr_swin_t_70_10.py")}      # BASELINE configs[3]
+CONFIG = CONFIGS["r50"]
 IMG_H, IMG_W = 800, 1333
 LEVELS = [(100, 167), (50, 84), (25, 42), (13, 21)]
 NV = sum(h * w for h, w in LEVELS)
@@ -58,8 +60,8 @@ def msda_algorithmic_bytes(kind, B, Nq, esz):
     return fwd + B * (NV * 256 * 4 + Nq * 1024 + Nq * 512)
 
 
-def build_models(device, seed, dropout):
-    cfg = Config.fromfile(CONFIG)
+def build_models(device, seed, dropout, config=None):
+    cfg = Config.fromfile(config or CONFIG)
     torch.manual_seed(seed)
     model = build_detector(cfg.model)
     model.init_weights()
@@ -172,6 +174,8 @@ def main():
                     "eagerly instead of replaying it as a hipGraph")
     ap.add_argument("--probe-steps", type=int, default=3, help="eager steps after the timed region that bracket "
                     "every MSDeformAttn launch with HIP events (roofline)")
+    ap.add_argument("--backbone", default="r50", choices=sorted(CONFIGS), help="r50 = BASELINE configs[1] (the headline "
+                    "workload); swin_t = configs[3] (SURVEY.md 8f row 2), reported in DESIGN.md only")
     ap.add_argument("--seed", type=int, default=111)
     args = ap.parse_args()
 
@@ -190,7 +194,7 @@ def main():
 
     torch.backends.cudnn.benchmark = True
     amp_dtype = torch.bfloat16 if args.dtype == "bf16" else None
-    cfg, model = build_models(device, args.seed, args.dropout)
+    cfg, model = build_models(device, args.seed, args.dropout, CONFIGS[args.backbone])
     model = model.to(memory_format=torch.channels_last)
     model.teacher_model.to(memory_format=torch.channels_last)
     model.lazy_log = True                      # log scalars stay on the device inside the timed loop
@@ -336,14 +340,17 @@ def main():
                         "timing": f"HIP events around each launch, {args.probe_steps} eager steps of the same "
                                   "workload right after the timed region", "kernels": kernels}
         ips = args.batch * world * args.steps / dt
-        out = {"metric": "images/sec (teacher+student distill step), DefDETR-R50 COCO 800x1333", "value": round(ips, 3),
+        out = {"metric": "images/sec (teacher+student distill step), DefDETR-%s COCO 800x1333" %
+                         ("R50" if args.backbone == "r50" else "SwinT"), "value": round(ips, 3),
                "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype,
                "data": "synthetic (N(0,1) images 800x1333, 7 GT + 10 injected teacher detections per image, "
                        "random-init weights, teacher = perturbed copy)",
-               "config": {"workload": "Deformable-DETR R50 70+10 incremental DSKD distillation step "
-                                      "(BASELINE.json configs[1])", "global_batch": args.batch * world,
+               "config": {"workload": ("Deformable-DETR R50 70+10 incremental DSKD distillation step "
+                                       "(BASELINE.json configs[1])" if args.backbone == "r50" else
+                                       "Deformable-DETR Swin-T 70+10 incremental DSKD distillation step "
+                                       "(BASELINE.json configs[3])"), "global_batch": args.batch * world,
                           "per_gpu_batch": args.batch, "image": [IMG_H, IMG_W], "queries": 300, "prev_classes": cfg.num_prev,
                           "parallelism": f"dp{world}", "execution": mode, "extra_untimed_warmup": extra_warmup,
                           "final_loss": round(final_loss, 4)},
