@@ -152,19 +152,41 @@ class WindowMSA(nn.Module):
     def forward(self, x, mask=None):
         """x [nW*B, N, C]; mask [nW, N, N] additive (0 / -100) or None."""
         Bw, N, C = x.shape
-        qkv = self.qkv(x).view(Bw, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
+        nH, d = self.num_heads, C // self.num_heads
+        qkv = self.qkv(x).view(Bw, N, 3, nH, d).permute(2, 0, 3, 1, 4)
         q, k, v = qkv[0], qkv[1], qkv[2]
-        bias = self.bias().unsqueeze(0)                                    # [1, nH, N, N]
+        bias = self.bias()                                                  # [nH, N, N]
         if mask is not None:
+            # per-window mask, repeated over the images.  (A broadcast 5-D formulation keeps the mask
+            # small but drops PyTorch-ROCm to the unfused bmm/softmax path: measured slower.)
             nW = mask.shape[0]
-            bias = (bias + mask[:, None]).to(q.dtype)                      # [nW, nH, N, N]
-            bias = bias.unsqueeze(0).expand(Bw // nW, -1, -1, -1, -1).reshape(Bw, self.num_heads, N, N)
+            bias = (bias[None] + mask[:, None]).to(q.dtype)
+            bias = bias.unsqueeze(0).expand(Bw // nW, -1, -1, -1, -1).reshape(Bw, nH, N, N)
         else:
-            bias = bias.to(q.dtype).expand(Bw, -1, -1, -1)
+            bias = bias.to(q.dtype).unsqueeze(0).expand(Bw, -1, -1, -1)
         x = F.scaled_dot_product_attention(q, k, v, attn_mask=bias, dropout_p=self.attn_drop.p if self.training else 0.0,
                                            scale=self.scale)
-        x = x.transpose(1, 2).reshape(Bw, N, C)
-        return self.proj_drop(self.proj(x))
+        x = x.transpose(1, 2)                                               # [Bw, N, nH, d]
+        return self.proj_drop(self.proj(x.reshape(Bw, N, C)))
+
+
+class _TokenGather(torch.autograd.Function):
+    """``x.index_select(1, fwd)`` whose backward is ALSO an index_select (``bwd`` = the inverse map;
+    a trailing all-zero row absorbs positions without a source).  The window partition and its
+    reverse are permutations of the token axis (plus padding): autograd's generic index backward
+    is a sort + scatter that cost 25 % of the Swin-T step on MI355X."""
+
+    @staticmethod
+    def forward(ctx, x, fwd, bwd, n_in):
+        ctx.save_for_backward(bwd)
+        ctx.n_in = n_in
+        return x.index_select(1, fwd)
+
+    @staticmethod
+    def backward(ctx, g):
+        (bwd,) = ctx.saved_tensors
+        pad = g.new_zeros(g.shape[0], 1, g.shape[2])
+        return torch.cat([g, pad], 1).index_select(1, bwd)[:, :ctx.n_in], None, None, None
 
 
 class ShiftWindowMSA(nn.Module):
@@ -214,10 +236,12 @@ class ShiftWindowMSA(nn.Module):
         assert L == H * W, "input feature has wrong size"
         part, inv, mask, Lp = self._geometry(H, W, query.device)
         ws2 = self.window_size ** 2
-        padded = torch.cat([query, query.new_zeros(B, 1, C)], 1) if Lp != L else query
-        windows = padded[:, part].view(B * (Lp // ws2), ws2, C)
-        out = self.w_msa(windows, mask=mask).view(B, Lp, C)
-        return self.drop(out[:, inv])
+        padded = torch.cat([query, query.new_zeros(B, 1, C)], 1)           # row L = the zero padding token
+        # partition: windows[pos] = padded[part[pos]]; gradient: d(padded)[t] = d(windows)[inv[t]] (row L: dropped)
+        windows = _TokenGather.apply(padded, part, torch.cat([inv, inv.new_full((1,), Lp)]), L + 1)
+        out = self.w_msa(windows.view(B * (Lp // ws2), ws2, C), mask=mask).view(B, Lp, C)
+        # reverse: tokens[t] = out[inv[t]]; gradient: d(out)[pos] = d(tokens)[part[pos]], pad slots (part == L) get 0
+        return self.drop(_TokenGather.apply(out, inv, part, Lp))
 
 
 class _SwinFFN(nn.Module):

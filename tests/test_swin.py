@@ -146,6 +146,35 @@ def test_swin_detector_step_on_cpu(cpu_ops):
     assert m.neck.convs[0].conv.weight.grad is not None
 
 
+@pytest.mark.parametrize("shift", [0, 3])
+def test_window_partition_gradients(shift, monkeypatch):
+    """The window partition / reverse are token gathers with a hand-written (gather) backward:
+    gradients must equal autograd's generic index backward, padded sizes included."""
+    from dskd_amd import swin
+    torch.manual_seed(3)
+    att = swin.ShiftWindowMSA(32, 4, 7, shift_size=shift).eval()
+    with torch.no_grad():
+        att.w_msa.relative_position_bias_table.normal_(std=0.5)
+    x = torch.randn(2, 9 * 13, 32)
+    gy = torch.randn(2, 9 * 13, 32)
+    xa = x.clone().requires_grad_(True)
+    att(xa, (9, 13)).backward(gy)
+    ga = [xa.grad.clone()] + [p.grad.clone() for p in att.parameters()]
+    for p in att.parameters():
+        p.grad = None
+
+    class Plain:
+        @staticmethod
+        def apply(t, fwd, bwd, n_in):
+            return t[:, fwd]
+    monkeypatch.setattr(swin, "_TokenGather", Plain)
+    xb = x.clone().requires_grad_(True)
+    att(xb, (9, 13)).backward(gy)
+    gb = [xb.grad] + [p.grad for p in att.parameters()]
+    for a, b in zip(ga, gb):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+
+
 def test_swin_registry_surface_and_freezing():
     """Constructor kwargs of the reference configs, state-dict names, frozen stages, gradients."""
     m = BACKBONES.build(dict(type="SwinTransformer", embed_dims=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24],
