@@ -75,19 +75,27 @@ class TeacherAhead:
                 tuple(tuple(m.get("batch_input_shape", ())) for m in img_metas))
 
     def _capture(self, img, img_metas, amp_dtype):
-        """Two graphs (double buffer) on the side stream; None when the replay does not reproduce
-        the eager forward."""
+        """Two graphs (double buffer) on the side stream; None when capture fails or the replay does
+        not reproduce the eager forward (the eager path then stays in use for this signature)."""
         entries = []
-        with torch.cuda.stream(self.stream):
-            ref_feats, ref_outs = self._forward(img, img_metas, amp_dtype)
-        for _ in range(2):
-            static = img.detach().clone(memory_format=torch.preserve_format)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=self.stream):
-                feats, outs = self._forward(static, img_metas, amp_dtype)
-            g.replay()
-            entries.append(dict(graph=g, img=static, feats=feats, outs=outs))
-        torch.cuda.synchronize(img.device)
+        try:
+            with torch.cuda.stream(self.stream):
+                ref_feats, ref_outs = self._forward(img, img_metas, amp_dtype)
+            for _ in range(2):
+                static = img.detach().clone(memory_format=torch.preserve_format)
+                g = torch.cuda.CUDAGraph()
+                # thread_local: other threads of the process (RCCL watchdog under DDP) keep making HIP
+                # calls while this thread captures
+                with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local"):
+                    feats, outs = self._forward(static, img_metas, amp_dtype)
+                g.replay()
+                entries.append(dict(graph=g, img=static, feats=feats, outs=outs))
+            torch.cuda.synchronize(img.device)
+        except Exception as e:  # noqa: BLE001  (an accelerator, not a requirement)
+            import warnings
+            warnings.warn(f"TeacherAhead: hipGraph capture failed ({type(e).__name__}: {e}); staying eager")
+            torch.cuda.synchronize(img.device)
+            return None
         for e in entries:
             for a, r in zip(_tensors((e["feats"], e["outs"])), _tensors((ref_feats, ref_outs))):
                 if a.dtype.is_floating_point:
