@@ -184,11 +184,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP hot path has no CPU fallback)")
+    # Rehearsal switch (one-GPU box): DSKD_BENCH_REHEARSE=1 runs all ranks on cuda:0 over gloo, to
+    # exercise the multi-process path (DDP, flat collectives, per-rank teacher stream / graphs).
+    rehearse = bool(os.environ.get("DSKD_BENCH_REHEARSE"))
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if rehearse else "nccl", rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     native.load()
 
