@@ -332,16 +332,17 @@ def main():
             # process; the number comes from the committed rocprofv3 --pmc passes over the same
             # launch shape (profiles/r01_msda_pmc_hbm_B4_bf16.json: FETCH_SIZE doubled per the
             # gfx950 correction + WRITE_SIZE), valid for the default B=4 bf16 workload only.
-            traffic = None
+            traffic = traffic_detail = None
             pmc = os.path.join(ROOT, "profiles", "r01_msda_pmc_hbm_B4_bf16.json")
             if args.batch == 4 and args.dtype == "bf16" and os.path.exists(pmc):
                 with open(pmc) as f:
                     t_mb = json.load(f).get("traffic_corrected_MB", {}).get(dom)
-                if t_mb:
-                    traffic = {"MB_per_launch": t_mb, "GBs": round(t_mb / 1e3 / (kernels[dom]["avg_us"] * 1e-6), 1),
-                               "source": "profiles/r01_msda_pmc_hbm_B4_bf16.json (rocprofv3 --pmc, separate passes)"}
+                if t_mb:      # same unit as `achieved`: PMC bytes of one launch / measured launch time
+                    traffic = round(t_mb / 1e3 / (kernels[dom]["avg_us"] * 1e-6), 1)
+                    traffic_detail = {"MB_per_launch": t_mb, "algorithmic_MB_per_launch": kernels[dom]["algorithmic_MB"],
+                                      "source": "profiles/r01_msda_pmc_hbm_B4_bf16.json (rocprofv3 --pmc, separate passes)"}
             roofline = {"bound": "hbm", "kernel": dom, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(a / HBM_PEAK_GBS, 4), "traffic": traffic,
+                        "frac": round(a / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_detail": traffic_detail,
                         "timing": f"HIP events around each launch, {args.probe_steps} eager steps of the same "
                                   "workload right after the timed region", "kernels": kernels}
         ips = args.batch * world * args.steps / dt
