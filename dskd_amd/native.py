@@ -248,37 +248,42 @@ class _MSDAPrepFunction(torch.autograd.Function):
     def forward(ctx, both, ref, shapes, heads, levels, points):
         dt = {torch.float32: DTYPE_F32, torch.bfloat16: DTYPE_BF16}[both.dtype]
         both = both.contiguous()
-        ref = ref.contiguous().float()
+        ref_f = ref.detach().contiguous().float()
         lead = both.shape[:-1]
         nq = both.numel() // both.shape[-1]
         loc = torch.empty(lead + (heads, levels, points, 2), dtype=torch.float32, device=both.device)
         attn = torch.empty(lead + (heads, levels, points), dtype=torch.float32, device=both.device)
         ss, _, _ = _geom(shapes)
-        rc = load().dskd_msda_prep_fwd(both.data_ptr(), ref.data_ptr(), ss, loc.data_ptr(), attn.data_ptr(), nq, heads,
+        rc = load().dskd_msda_prep_fwd(both.data_ptr(), ref_f.data_ptr(), ss, loc.data_ptr(), attn.data_ptr(), nq, heads,
                                        levels, points, dt, _stream(both))
         _check(rc, "dskd_msda_prep_fwd")
         ctx.save_for_backward(attn)
-        ctx.meta = (shapes, heads, levels, points, dt, both.dtype, both.shape, nq)
+        ctx.meta = (shapes, heads, levels, points, dt, both.dtype, both.shape, nq, ref.shape, ref.dtype)
         return loc, attn
 
     @staticmethod
     def backward(ctx, grad_loc, grad_attn):
         (attn,) = ctx.saved_tensors
-        shapes, heads, levels, points, dt, dtype, shape, nq = ctx.meta
+        shapes, heads, levels, points, dt, dtype, shape, nq, ref_shape, ref_dtype = ctx.meta
         ss, _, _ = _geom(shapes)
         grad_both = torch.empty(shape, dtype=dtype, device=attn.device)
         gl, ga = grad_loc.contiguous().float(), grad_attn.contiguous().float()
         rc = load().dskd_msda_prep_bwd(gl.data_ptr(), ga.data_ptr(), attn.data_ptr(), ss, grad_both.data_ptr(), nq, heads,
                                        levels, points, dt, _stream(attn))
         _check(rc, "dskd_msda_prep_bwd")
-        return grad_both, None, None, None, None, None
+        grad_ref = None
+        if ctx.needs_input_grad[1]:
+            # loc = ref[..., None, :, None, :] + off / (W, H): d(ref) = sum of d(loc) over heads and points
+            grad_ref = gl.reshape(nq, heads, levels, points, 2).sum((1, 3)).view(ref_shape).to(ref_dtype)
+        return grad_both, grad_ref, None, None, None, None
 
 
 def msda_prepare(both: torch.Tensor, reference_points: torch.Tensor, spatial_shapes, heads: int, levels: int,
                  points: int):
     """softmax of the attention logits + sampling locations from the projection output
-    (``both[..., :heads*L*P*2]`` offsets, the rest logits) and NON-differentiable reference
-    points [.., levels, 2]; one launch each way instead of the module's elementwise chain
+    (``both[..., :heads*L*P*2]`` offsets, the rest logits) and reference points [.., levels, 2]
+    (differentiable: the decoder's come from a trainable Linear); one launch each way (plus one
+    small reduction for d(reference points)) instead of the module's elementwise chain
     (ext-mmcv MultiScaleDeformableAttention.forward).  Returns (loc, attn) in f32."""
     f = _dispatch_cpu("msda_prepare", both)
     if f is not None:

@@ -393,9 +393,8 @@ class MultiScaleDeformableAttention(nn.Module):
             w_cat = torch.cat([sw, ww], 0)
             b_cat = torch.cat([sb, wb], 0)
         both = tall_linear(query, w_cat, b_cat)
-        if reference_points.shape[-1] == 2 and not reference_points.requires_grad and \
-                self.num_levels * self.num_points == 16 and self.num_levels <= 4:
-            # encoder: softmax + location arithmetic in one HIP pass each way
+        if reference_points.shape[-1] == 2 and self.num_levels * self.num_points == 16 and self.num_levels <= 4:
+            # softmax + location arithmetic in one HIP pass each way (encoder and decoder)
             sampling_locations, attention_weights = native.msda_prepare(
                 both, reference_points, shapes, self.num_heads, self.num_levels, self.num_points)
         else:

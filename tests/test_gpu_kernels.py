@@ -178,19 +178,22 @@ def test_msda_prepare_vs_module_chain(dtype, oracle_checker):
     gl = torch.randn(B, Nq, 8, 4, 4, 2, generator=g)
     ga = torch.randn(B, Nq, 8, 4, 4, generator=g)
     bc = both.clone().requires_grad_(True)
-    loc_r, attn_r = oracle_checker.msda_prepare(bc, ref, shapes, 8, 4, 4)
+    rc = ref.clone().requires_grad_(True)          # the decoder's reference points are differentiable
+    loc_r, attn_r = oracle_checker.msda_prepare(bc, rc, shapes, 8, 4, 4)
     (loc_r * gl).sum().backward(retain_graph=True)
     g1 = bc.grad.clone()
     bc.grad = None
     (attn_r * ga).sum().backward()
     g2 = bc.grad.clone()
     bd = both.to(DEV).requires_grad_(True)
-    loc, attn = native.msda_prepare(bd, ref.to(DEV), shapes, 8, 4, 4)
+    rd = ref.to(DEV).requires_grad_(True)
+    loc, attn = native.msda_prepare(bd, rd, shapes, 8, 4, 4)
     torch.testing.assert_close(loc.cpu(), loc_r.detach(), rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(attn.cpu(), attn_r.detach(), rtol=1e-5, atol=1e-7)
     ((loc * gl.to(DEV)).sum() + (attn * ga.to(DEV)).sum()).backward()
     tol = dict(rtol=1e-5, atol=1e-6) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-3)
     torch.testing.assert_close(bd.grad.float().cpu(), (g1 + g2).float(), **tol)
+    torch.testing.assert_close(rd.grad.cpu(), rc.grad, rtol=1e-4, atol=1e-4)
 
 
 # ----------------------------------------------------------------------------- add + dropout + LayerNorm
