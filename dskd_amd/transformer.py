@@ -180,19 +180,29 @@ class lowp_params:
             mods = [m for m in self.root.modules() if isinstance(m, Linear)]
             self.root.__dict__["_lowp_mods"] = mods
         self.live = [m for m in mods if m.weight.requires_grad and (m.bias is None or m.bias.requires_grad)]
+        mhas = self.root.__dict__.get("_lowp_mhas")
+        if mhas is None:
+            mhas = [m for m in self.root.modules() if isinstance(m, MultiheadAttention)]
+            self.root.__dict__["_lowp_mhas"] = mhas
+        self.live_mha = [m for m in mhas if m.attn.in_proj_weight is not None and m.attn.in_proj_weight.requires_grad
+                         and m.attn.in_proj_bias is not None and m.attn.out_proj.bias is not None]
         params = []
         for m in self.live:
             params.append(m.weight)
             if m.bias is not None:
                 params.append(m.bias)
+        for m in self.live_mha:
+            params += [m.attn.in_proj_weight, m.attn.in_proj_bias, m.attn.out_proj.weight, m.attn.out_proj.bias]
         if params:
             outs = iter(_CastParams.apply(self.dtype, *params))
             for m in self.live:
                 m.__dict__["_live_lp"] = (next(outs), next(outs) if m.bias is not None else None)
+            for m in self.live_mha:
+                m.__dict__["_live_lp"] = (next(outs), next(outs), next(outs), next(outs))
         return self
 
     def __exit__(self, *exc):
-        for m in self.live:
+        for m in self.live + self.live_mha:
             m.__dict__.pop("_live_lp", None)
         return False
 
@@ -438,6 +448,28 @@ class MultiheadAttention(nn.Module):
         self.proj_drop = nn.Dropout(proj_drop)
         self.dropout_layer = nn.Dropout(dropout_layer["drop_prob"]) if dropout_layer else nn.Identity()
 
+    def _attend(self, query, key, value):
+        """``nn.MultiheadAttention`` without masks on the GPU, same arithmetic with fewer launches:
+        q and k projected by ONE GEMM when they are the same tensor (DETR self-attention: q = k =
+        query + query_pos, v = query), fused ``scaled_dot_product_attention``, the step's
+        low-precision parameter copies (``lowp_params``) when present.  [L, B, E] in and out."""
+        E, H = self.embed_dims, self.num_heads
+        live = self.__dict__.get("_live_lp")
+        w, b, wo, bo = live if live is not None else (self.attn.in_proj_weight, self.attn.in_proj_bias,
+                                                      self.attn.out_proj.weight, self.attn.out_proj.bias)
+        L, B, _ = query.shape
+        S = key.shape[0]
+        if query is key:
+            q, k = F.linear(query, w[:2 * E], b[:2 * E]).split(E, dim=-1)
+        else:
+            q, k = F.linear(query, w[:E], b[:E]), F.linear(key, w[E:2 * E], b[E:2 * E])
+        v = F.linear(value, w[2 * E:], b[2 * E:])
+        q = q.reshape(L, B, H, E // H).permute(1, 2, 0, 3)
+        k = k.reshape(S, B, H, E // H).permute(1, 2, 0, 3)
+        v = v.reshape(S, B, H, E // H).permute(1, 2, 0, 3)
+        out = F.scaled_dot_product_attention(q, k, v, dropout_p=self.attn.dropout if self.training else 0.0)
+        return F.linear(out.permute(2, 0, 1, 3).reshape(L, B, E), wo, bo)
+
     def tail_dropout_p(self):
         """p of ``dropout_layer`` when the tail can be fused (no extra ``proj_drop``), else None."""
         if self.proj_drop.p != 0 and self.training:
@@ -456,14 +488,21 @@ class MultiheadAttention(nn.Module):
             identity = query
         if key_pos is None and query_pos is not None and query_pos.shape == key.shape:
             key_pos = query_pos
+        shared_qk = key is query and key_pos is query_pos       # self-attention: one tensor for q and k
         if query_pos is not None:
             query = query + query_pos
-        if key_pos is not None:
+        if shared_qk:
+            key = query
+        elif key_pos is not None:
             key = key + key_pos
         if self.batch_first:
             query, key, value = query.transpose(0, 1), key.transpose(0, 1), value.transpose(0, 1)
-        out = self.attn(query=query, key=key, value=value, attn_mask=attn_mask, key_padding_mask=key_padding_mask,
-                        need_weights=False)[0]
+        if attn_mask is None and key_padding_mask is None and query.is_cuda and self.attn.in_proj_weight is not None \
+                and self.attn.in_proj_bias is not None and self.attn._qkv_same_embed_dim:
+            out = self._attend(query, key, value)
+        else:
+            out = self.attn(query=query, key=key, value=value, attn_mask=attn_mask, key_padding_mask=key_padding_mask,
+                            need_weights=False)[0]
         if self.batch_first:
             out = out.transpose(0, 1)
         if fuse_tail:

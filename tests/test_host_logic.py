@@ -227,3 +227,21 @@ def test_checkpoint_hand_over_in_reference_layout(tmp_path):
     assert "teacher_model.backbone.conv1.weight" not in dst.state_dict()
     dst.load_student(str(ckpt))                                   # drops the teacher (:116-121 of the reference flow)
     assert not dst.has_teacher
+
+
+def test_lean_self_attention_equals_nn_multihead_attention():
+    """The mask-free GPU path of the MultiheadAttention wrapper (shared q/k projection + fused SDPA)
+    is the same function as ``nn.MultiheadAttention`` -- checked on the CPU by calling it directly."""
+    from dskd_amd.transformer import MultiheadAttention
+    torch.manual_seed(4)
+    m = MultiheadAttention(embed_dims=256, num_heads=8, dropout=0.0).eval()
+    q, pos = torch.randn(30, 2, 256), torch.randn(30, 2, 256)
+    ref = m.attn(q + pos, q + pos, q, need_weights=False)[0]
+    qp = q + pos
+    torch.testing.assert_close(m._attend(qp, qp, q), ref, rtol=1e-5, atol=1e-5)            # shared q/k
+    k2 = torch.randn(17, 2, 256)
+    ref2 = m.attn(qp, k2, k2, need_weights=False)[0]
+    torch.testing.assert_close(m._attend(qp, k2, k2), ref2, rtol=1e-5, atol=1e-5)          # cross attention
+    # and through forward(): identity + attention (dropout 0)
+    out = m(q, query_pos=pos)
+    torch.testing.assert_close(out, q + ref, rtol=1e-5, atol=1e-5)
