@@ -15,47 +15,64 @@
 // The dropout mask is never stored: Philox4x32-10 keyed by (seed, offset) and counted by
 // (row, lane) is regenerated in backward.
 //
-// HBM-bound streaming kernels.  D == 256 only (the DSKD transformer width): one 64-lane wave
-// owns a row, a lane owns 4 consecutive columns (8-byte bf16 / 16-byte f32 accesses), the row
-// statistics are two wave reductions.
+// HBM-bound streaming kernels.  D == 256 only (the DSKD transformer width): 16 bytes per lane
+// (4 f32 / 8 bf16 columns), so a 64-lane wave owns one f32 row or two bf16 rows per step; the
+// row statistics are two shuffle reductions over the row's lanes.
 #include "common.h"
 
 namespace dskd {
 namespace {
 
 constexpr int kD = 256;
-constexpr int kRowsPerBlock = 4;       // waves per workgroup, one row each per step
+constexpr int kRowsPerBlock = 4;       // waves per workgroup
 
 __device__ __forceinline__ float as_float(unsigned u) { return __builtin_bit_cast(float, u); }
 
+// 16 bytes per lane: 4 f32 or 8 bf16 elements; a 256-wide row takes 64 or 32 lanes, so a wave
+// owns one f32 row or two bf16 rows per step.
+template <typename T> struct Lay;
+template <> struct Lay<float> { static constexpr int EPL = 4, LPR = 64, RPW = 1; };
+template <> struct Lay<__bf16> { static constexpr int EPL = 8, LPR = 32, RPW = 2; };
+
 template <typename T>
-__device__ __forceinline__ void load4(const T* __restrict__ p, float* f) {
+__device__ __forceinline__ void load_vec(const T* __restrict__ p, float* f) {
   if constexpr (sizeof(T) == 4) {
     const f32x4 v = *reinterpret_cast<const f32x4*>(p);
     f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
   } else {
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    const u32x2 v = *reinterpret_cast<const u32x2*>(p);
-    const unsigned lo = v.x, hi = v.y;
-    f[0] = as_float(lo << 16); f[1] = as_float(lo & 0xFFFF0000u);
-    f[2] = as_float(hi << 16); f[3] = as_float(hi & 0xFFFF0000u);
+    const u32x4 v = *reinterpret_cast<const u32x4*>(p);
+    const unsigned a = v.x, b = v.y, c = v.z, d = v.w;      // scalars first (bit_cast of a vector element reads [0])
+    f[0] = as_float(a << 16); f[1] = as_float(a & 0xFFFF0000u);
+    f[2] = as_float(b << 16); f[3] = as_float(b & 0xFFFF0000u);
+    f[4] = as_float(c << 16); f[5] = as_float(c & 0xFFFF0000u);
+    f[6] = as_float(d << 16); f[7] = as_float(d & 0xFFFF0000u);
   }
 }
 
 // round to T and return the rounded values in f (what a later reader of the store will see)
 template <typename T>
-__device__ __forceinline__ void store4(T* __restrict__ p, float* f) {
+__device__ __forceinline__ void store_vec(T* __restrict__ p, float* f) {
   if constexpr (sizeof(T) == 4) {
     *reinterpret_cast<f32x4*>(p) = f32x4{f[0], f[1], f[2], f[3]};
   } else {
-    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-    const bf16x4 v = {(__bf16)f[0], (__bf16)f[1], (__bf16)f[2], (__bf16)f[3]};
-    *reinterpret_cast<bf16x4*>(p) = v;
-    f[0] = (float)v.x; f[1] = (float)v.y; f[2] = (float)v.z; f[3] = (float)v.w;
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    const bf16x8 v = {(__bf16)f[0], (__bf16)f[1], (__bf16)f[2], (__bf16)f[3],
+                      (__bf16)f[4], (__bf16)f[5], (__bf16)f[6], (__bf16)f[7]};
+    *reinterpret_cast<bf16x8*>(p) = v;
+    f[0] = (float)v[0]; f[1] = (float)v[1]; f[2] = (float)v[2]; f[3] = (float)v[3];
+    f[4] = (float)v[4]; f[5] = (float)v[5]; f[6] = (float)v[6]; f[7] = (float)v[7];
   }
 }
 
-// Philox4x32-10 (Salmon et al. 2011): 4 x 32 random bits per (row, lane).
+// sum over the LPR lanes of a row (LPR = 32: the two halves of the wave reduce independently)
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// Philox4x32-10 (Salmon et al. 2011): 4 x 32 random bits per (row, lane) = 8 x 16-bit fields.
 __device__ __forceinline__ u32x4 philox(unsigned long long row, unsigned lane, unsigned long long seed,
                                         unsigned long long offset) {
   unsigned c0 = (unsigned)row, c1 = (unsigned)(row >> 32), c2 = lane, c3 = (unsigned)offset;
@@ -71,55 +88,83 @@ __device__ __forceinline__ u32x4 philox(unsigned long long row, unsigned lane, u
 }
 
 struct Drop {
-  unsigned thresh;          // drop when the random word < thresh  (thresh = p * 2^32)
+  unsigned thresh;          // drop when the element's 16-bit random field < thresh  (thresh = p * 2^16)
   float scale;              // 1 / (1 - p)
   unsigned long long seed, offset;
 };
+
+// element i (< 8) of a lane is dropped when its 16-bit field is below the threshold
+__device__ __forceinline__ bool dropped(const u32x4& rnd, int i, unsigned thresh) {
+  const unsigned w[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
+  return ((w[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu) < thresh;
+}
 
 template <typename T>
 __global__ __launch_bounds__(kRowsPerBlock * 64) void add_ln_fwd_kernel(
     const T* __restrict__ h, const T* __restrict__ res, const float* __restrict__ pos, long long pos_rows,
     const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y, T* __restrict__ q,
     T* __restrict__ z, float* __restrict__ stats, long long rows, float eps, Drop dr) {
+  using L = Lay<T>;
+  constexpr int E = L::EPL;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int c = lane * 4;
-  const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c);
-  const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + c);
-  const float g4[4] = {gm.x, gm.y, gm.z, gm.w}, b4[4] = {bt.x, bt.y, bt.z, bt.w};
-  for (long long row = (long long)blockIdx.x * kRowsPerBlock + wave; row < rows;
-       row += (long long)gridDim.x * kRowsPerBlock) {
-    float hv[4], zv[4];
-    load4(h + row * kD + c, hv);
-    load4(res + row * kD + c, zv);
-    if (dr.thresh) {
-      const u32x4 rnd = philox((unsigned long long)row, (unsigned)lane, dr.seed, dr.offset);
-      const unsigned r4[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
+  const int rl = lane % L::LPR, rsub = lane / L::LPR;       // lane inside its row, row of the wave
+  const int c = rl * E;
+  float g4[E], b4[E];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) hv[i] = r4[i] < dr.thresh ? 0.f : hv[i] * dr.scale;
+  for (int i = 0; i < E; i += 4) {
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c + i);
+    const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + c + i);
+    g4[i] = gm.x; g4[i + 1] = gm.y; g4[i + 2] = gm.z; g4[i + 3] = gm.w;
+    b4[i] = bt.x; b4[i + 1] = bt.y; b4[i + 2] = bt.z; b4[i + 3] = bt.w;
+  }
+  const long long stride = (long long)gridDim.x * kRowsPerBlock * L::RPW;
+  for (long long row0 = ((long long)blockIdx.x * kRowsPerBlock + wave) * L::RPW; row0 < rows; row0 += stride) {
+    const long long row = row0 + rsub;
+    const bool ok = row < rows;
+    const long long rr = ok ? row : rows - 1;               // the idle half of a wave recomputes the last row
+    float hv[E], zv[E];
+    load_vec(h + rr * kD + c, hv);
+    load_vec(res + rr * kD + c, zv);
+    if (dr.thresh) {
+      const u32x4 rnd = philox((unsigned long long)rr, (unsigned)rl, dr.seed, dr.offset);
+#pragma unroll
+      for (int i = 0; i < E; ++i) hv[i] = dropped(rnd, i, dr.thresh) ? 0.f : hv[i] * dr.scale;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) zv[i] += hv[i];
+    for (int i = 0; i < E; ++i) zv[i] += hv[i];
     if (z) {
-      store4(z + row * kD + c, zv);            // statistics of the ROUNDED sum: backward sees the same z
+      if (ok) store_vec(z + rr * kD + c, zv);              // statistics of the ROUNDED sum: backward sees the same z
+      else if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int i = 0; i < E; ++i) zv[i] = (float)(__bf16)zv[i];
+      }
     } else if constexpr (sizeof(T) == 2) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) zv[i] = (float)(__bf16)zv[i];
+      for (int i = 0; i < E; ++i) zv[i] = (float)(__bf16)zv[i];
     }
-    const float mean = wave_sum(zv[0] + zv[1] + zv[2] + zv[3]) * (1.0f / kD);
-    float d[4], ss = 0.f;
+    float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { d[i] = zv[i] - mean; ss += d[i] * d[i]; }
-    const float rstd = rsqrtf(wave_sum(ss) * (1.0f / kD) + eps);
-    if (stats && lane == 0) *reinterpret_cast<f32x2*>(stats + row * 2) = f32x2{mean, rstd};
-    float yv[4];
+    for (int i = 0; i < E; ++i) s += zv[i];
+    const float mean = row_sum<L::LPR>(s) * (1.0f / kD);
+    float d[E], ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) yv[i] = d[i] * rstd * g4[i] + b4[i];
-    store4(y + row * kD + c, yv);
+    for (int i = 0; i < E; ++i) { d[i] = zv[i] - mean; ss += d[i] * d[i]; }
+    const float rstd = rsqrtf(row_sum<L::LPR>(ss) * (1.0f / kD) + eps);
+    if (!ok) continue;
+    if (stats && rl == 0) *reinterpret_cast<f32x2*>(stats + row * 2) = f32x2{mean, rstd};
+    float yv[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) yv[i] = d[i] * rstd * g4[i] + b4[i];
+    store_vec(y + row * kD + c, yv);
     if (q) {
-      const f32x4 pv = *reinterpret_cast<const f32x4*>(pos + (row % pos_rows) * kD + c);
-      float qv[4] = {yv[0] + pv.x, yv[1] + pv.y, yv[2] + pv.z, yv[3] + pv.w};
-      store4(q + row * kD + c, qv);
+      float qv[E];
+#pragma unroll
+      for (int i = 0; i < E; i += 4) {
+        const f32x4 pv = *reinterpret_cast<const f32x4*>(pos + (row % pos_rows) * kD + c + i);
+        qv[i] = yv[i] + pv.x; qv[i + 1] = yv[i + 1] + pv.y; qv[i + 2] = yv[i + 2] + pv.z; qv[i + 3] = yv[i + 3] + pv.w;
+      }
+      store_vec(q + row * kD + c, qv);
     }
   }
 }
@@ -128,70 +173,88 @@ template <typename T>
 __global__ __launch_bounds__(kRowsPerBlock * 64) void add_ln_bwd_kernel(
     const T* __restrict__ dy, const T* __restrict__ dq, const T* __restrict__ z,
     const float* __restrict__ stats, const float* __restrict__ gamma, T* __restrict__ dres,
-    T* __restrict__ dh, float* __restrict__ dgamma, float* __restrict__ dbeta, long long rows, Drop dr) {
-  __shared__ float s_part[2][kRowsPerBlock][kD];
+    T* __restrict__ dh, float* __restrict__ dgamma, float* __restrict__ dbeta, int copies, long long rows,
+    Drop dr) {
+  using L = Lay<T>;
+  constexpr int E = L::EPL;
+  __shared__ float s_part[2][kRowsPerBlock * L::RPW][kD];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int c = lane * 4;
-  const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c);
-  const float g4[4] = {gm.x, gm.y, gm.z, gm.w};
-  float accg[4] = {0.f, 0.f, 0.f, 0.f}, accb[4] = {0.f, 0.f, 0.f, 0.f};
-  for (long long row = (long long)blockIdx.x * kRowsPerBlock + wave; row < rows;
-       row += (long long)gridDim.x * kRowsPerBlock) {
-    float g[4], zv[4];
-    load4(dy + row * kD + c, g);
+  const int rl = lane % L::LPR, rsub = lane / L::LPR;
+  const int c = rl * E;
+  float g4[E];
+#pragma unroll
+  for (int i = 0; i < E; i += 4) {
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c + i);
+    g4[i] = gm.x; g4[i + 1] = gm.y; g4[i + 2] = gm.z; g4[i + 3] = gm.w;
+  }
+  float accg[E], accb[E];
+#pragma unroll
+  for (int i = 0; i < E; ++i) { accg[i] = 0.f; accb[i] = 0.f; }
+  const long long stride = (long long)gridDim.x * kRowsPerBlock * L::RPW;
+  for (long long row0 = ((long long)blockIdx.x * kRowsPerBlock + wave) * L::RPW; row0 < rows; row0 += stride) {
+    const long long row = row0 + rsub;
+    const bool ok = row < rows;
+    const long long rr = ok ? row : rows - 1;
+    float g[E], zv[E];
+    load_vec(dy + rr * kD + c, g);
     if (dq) {
-      float t[4];
-      load4(dq + row * kD + c, t);
+      float t[E];
+      load_vec(dq + rr * kD + c, t);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) g[i] += t[i];
+      for (int i = 0; i < E; ++i) g[i] += t[i];
     }
-    load4(z + row * kD + c, zv);
-    const f32x2 st = *reinterpret_cast<const f32x2*>(stats + row * 2);
-    float xh[4], gg[4], s1 = 0.f, s2 = 0.f;
+    load_vec(z + rr * kD + c, zv);
+    const f32x2 st = *reinterpret_cast<const f32x2*>(stats + rr * 2);
+    float xh[E], gg[E], s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < E; ++i) {
       xh[i] = (zv[i] - st.x) * st.y;
       gg[i] = g[i] * g4[i];
       s1 += gg[i];
       s2 += gg[i] * xh[i];
+    }
+    s1 = row_sum<L::LPR>(s1) * (1.0f / kD);
+    s2 = row_sum<L::LPR>(s2) * (1.0f / kD);
+    if (!ok) continue;
+    float dz[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
       accg[i] += g[i] * xh[i];
       accb[i] += g[i];
+      dz[i] = st.y * (gg[i] - s1 - xh[i] * s2);
     }
-    s1 = wave_sum(s1) * (1.0f / kD);
-    s2 = wave_sum(s2) * (1.0f / kD);
-    float dz[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dz[i] = st.y * (gg[i] - s1 - xh[i] * s2);
     if (dh) {
-      float dv[4];
-      const u32x4 rnd = philox((unsigned long long)row, (unsigned)lane, dr.seed, dr.offset);
-      const unsigned r4[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
+      float dv[E];
+      const u32x4 rnd = philox((unsigned long long)row, (unsigned)rl, dr.seed, dr.offset);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) dv[i] = r4[i] < dr.thresh ? 0.f : dz[i] * dr.scale;
-      store4(dh + row * kD + c, dv);
+      for (int i = 0; i < E; ++i) dv[i] = dropped(rnd, i, dr.thresh) ? 0.f : dz[i] * dr.scale;
+      store_vec(dh + row * kD + c, dv);
     }
-    store4(dres + row * kD + c, dz);
+    store_vec(dres + row * kD + c, dz);
   }
-  *reinterpret_cast<f32x4*>(&s_part[0][wave][c]) = f32x4{accg[0], accg[1], accg[2], accg[3]};
-  *reinterpret_cast<f32x4*>(&s_part[1][wave][c]) = f32x4{accb[0], accb[1], accb[2], accb[3]};
+  const int slot = wave * L::RPW + rsub;
+#pragma unroll
+  for (int i = 0; i < E; ++i) { s_part[0][slot][c + i] = accg[i]; s_part[1][slot][c + i] = accb[i]; }
   __syncthreads();
   const int col = threadIdx.x;     // 256 threads, 256 columns
   float sg = 0.f, sb = 0.f;
 #pragma unroll
-  for (int w = 0; w < kRowsPerBlock; ++w) { sg += s_part[0][w][col]; sb += s_part[1][w][col]; }
-  atomicAdd(dgamma + col, sg);
-  atomicAdd(dbeta + col, sb);
+  for (int w = 0; w < kRowsPerBlock * L::RPW; ++w) { sg += s_part[0][w][col]; sb += s_part[1][w][col]; }
+  const int copy = blockIdx.x % copies;      // several copies: fewer workgroups contend for one address
+  atomicAdd(dgamma + copy * kD + col, sg);
+  atomicAdd(dbeta + copy * kD + col, sb);
 }
 
-inline int grid_for(long long rows) {
-  const long long blocks = (rows + kRowsPerBlock - 1) / kRowsPerBlock;
+inline int grid_for(long long rows, int rows_per_wave) {
+  const long long per_block = (long long)kRowsPerBlock * rows_per_wave;
+  const long long blocks = (rows + per_block - 1) / per_block;
   return (int)(blocks < 2048 ? blocks : 2048);     // 8 workgroups per CU, grid-stride over rows
 }
 
 inline bool make_drop(float p, unsigned long long seed, unsigned long long offset, Drop* d) {
   if (!(p >= 0.f) || p >= 1.f) return false;
-  const double t = (double)p * 4294967296.0;
+  const double t = (double)p * 65536.0 + 0.5;
   d->thresh = p > 0.f ? (unsigned)(t < 1.0 ? 1.0 : t) : 0u;
   d->scale = 1.0f / (1.0f - p);
   d->seed = seed;
@@ -226,7 +289,7 @@ extern "C" int dskd_add_ln_fwd(const void* h, const void* res, const float* pos,
   if (!make_drop(drop_p, seed, offset, &dr)) return fail(DSKD_ERR_INVALID_ARG, "dskd_add_ln_fwd: drop_p=%f", drop_p);
   if (rows == 0) return DSKD_OK;
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid(grid_for(rows)), block(kRowsPerBlock * 64);
+  const dim3 grid(grid_for(rows, dtype == DSKD_DTYPE_F32 ? 1 : 2)), block(kRowsPerBlock * 64);
   if (dtype == DSKD_DTYPE_F32)
     hipLaunchKernelGGL(add_ln_fwd_kernel<float>, grid, block, 0, st, (const float*)h, (const float*)res, pos,
                        (long long)pos_rows, gamma, beta, (float*)y, (float*)q, (float*)z, stats, (long long)rows,
@@ -240,13 +303,13 @@ extern "C" int dskd_add_ln_fwd(const void* h, const void* res, const float* pos,
 
 extern "C" int dskd_add_ln_bwd(const void* dy, const void* dq, const void* z, const float* stats,
                                const float* gamma, void* dres, void* dh, float* dgamma, float* dbeta,
-                               int64_t rows, int D, float drop_p, uint64_t seed, uint64_t offset,
-                               int dtype, void* stream) {
+                               int copies, int64_t rows, int D, float drop_p, uint64_t seed,
+                               uint64_t offset, int dtype, void* stream) {
   if (D != kD) return fail(DSKD_ERR_INVALID_ARG, "dskd_add_ln_bwd: only D=256 supported (got %d)", D);
   if (dtype != DSKD_DTYPE_F32 && dtype != DSKD_DTYPE_BF16)
     return fail(DSKD_ERR_INVALID_ARG, "dskd_add_ln_bwd: unknown dtype %d", dtype);
-  if (rows < 0 || !dy || !z || !stats || !gamma || !dres || !dgamma || !dbeta)
-    return fail(DSKD_ERR_INVALID_ARG, "dskd_add_ln_bwd: null pointer or negative row count");
+  if (rows < 0 || copies < 1 || !dy || !z || !stats || !gamma || !dres || !dgamma || !dbeta)
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_add_ln_bwd: null pointer, negative row count or copies < 1");
   if (!aligned16(dy) || !aligned16(dq) || !aligned16(z) || !aligned16(stats) || !aligned16(gamma) ||
       !aligned16(dres) || !aligned16(dh))
     return fail(DSKD_ERR_INVALID_ARG, "dskd_add_ln_bwd: pointers must be 16-byte aligned");
@@ -256,13 +319,13 @@ extern "C" int dskd_add_ln_bwd(const void* dy, const void* dq, const void* z, co
     return fail(DSKD_ERR_INVALID_ARG, "dskd_add_ln_bwd: dh is written exactly when drop_p > 0 (else d(h) == d(res))");
   if (rows == 0) return DSKD_OK;
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid(grid_for(rows)), block(kRowsPerBlock * 64);
+  const dim3 grid(grid_for(rows, dtype == DSKD_DTYPE_F32 ? 1 : 2)), block(kRowsPerBlock * 64);
   if (dtype == DSKD_DTYPE_F32)
     hipLaunchKernelGGL(add_ln_bwd_kernel<float>, grid, block, 0, st, (const float*)dy, (const float*)dq,
-                       (const float*)z, stats, gamma, (float*)dres, (float*)dh, dgamma, dbeta, (long long)rows, dr);
+                       (const float*)z, stats, gamma, (float*)dres, (float*)dh, dgamma, dbeta, copies, (long long)rows, dr);
   else
     hipLaunchKernelGGL(add_ln_bwd_kernel<__bf16>, grid, block, 0, st, (const __bf16*)dy, (const __bf16*)dq,
-                       (const __bf16*)z, stats, gamma, (__bf16*)dres, (__bf16*)dh, dgamma, dbeta,
+                       (const __bf16*)z, stats, gamma, (__bf16*)dres, (__bf16*)dh, dgamma, dbeta, copies,
                        (long long)rows, dr);
   return check_launch("dskd_add_ln_bwd");
 }

@@ -65,7 +65,7 @@ template <int TPR>
 __global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const __bf16* __restrict__ g,
                                                                const __bf16* __restrict__ yd,
                                                                __bf16* __restrict__ out, float* __restrict__ colsum,
-                                                               long long rows, float scale) {
+                                                               int copies, long long rows, float scale) {
   constexpr int RPB = 256 / TPR;                  // rows per workgroup and step
   constexpr int C = TPR * 8;
   __shared__ float s_part[RPB][C];
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const __bf16* __r
       float s = 0.f;
 #pragma unroll
       for (int r = 0; r < RPB; ++r) s += s_part[r][c];
-      atomicAdd(colsum + c, s);
+      atomicAdd(colsum + (blockIdx.x % copies) * C + c, s);
     }
   }
 }
@@ -104,14 +104,28 @@ __global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const __bf16* __r
 // LDS, one atomic per column and workgroup.
 template <int TPR>
 __global__ __launch_bounds__(256) void colsum_kernel(const __bf16* __restrict__ x, float* __restrict__ colsum,
-                                                     long long rows) {
+                                                     int copies, long long rows) {
   constexpr int RPB = 256 / TPR;
   constexpr int C = TPR * 8;
   __shared__ float s_part[RPB][C];
   const int t = threadIdx.x % TPR, rsub = threadIdx.x / TPR;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (rsub < RPB) {
-    for (long long row = (long long)blockIdx.x * RPB + rsub; row < rows; row += (long long)gridDim.x * RPB) {
+    const long long step = (long long)gridDim.x * RPB;
+    long long row = (long long)blockIdx.x * RPB + rsub;
+    for (; row + 3 * step < rows; row += 4 * step) {       // four independent 16-byte loads in flight
+      u32x4 r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) r[u] = *reinterpret_cast<const u32x4*>(x + (row + u * step) * C + t * 8);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float v[8];
+        unpack8(r[u], v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += v[k];
+      }
+    }
+    for (; row < rows; row += step) {
       float v[8];
       unpack8(*reinterpret_cast<const u32x4*>(x + row * C + t * 8), v);
 #pragma unroll
@@ -125,7 +139,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const __bf16* __restrict__ 
     float s = 0.f;
 #pragma unroll
     for (int r = 0; r < RPB; ++r) s += s_part[r][c];
-    atomicAdd(colsum + c, s);
+    atomicAdd(colsum + (blockIdx.x % copies) * C + c, s);
   }
 }
 
@@ -134,18 +148,19 @@ __global__ __launch_bounds__(256) void colsum_kernel(const __bf16* __restrict__ 
 
 using namespace dskd;
 
-extern "C" int dskd_colsum(const void* x, float* colsum, int64_t rows, int C, int dtype, void* stream) {
+extern "C" int dskd_colsum(const void* x, float* colsum, int copies, int64_t rows, int C, int dtype,
+                           void* stream) {
   if (dtype != DSKD_DTYPE_BF16) return fail(DSKD_ERR_INVALID_ARG, "dskd_colsum: bf16 only");
   if (rows == 0) return DSKD_OK;
-  if (!x || !colsum || rows < 0 || (reinterpret_cast<uintptr_t>(x) & 15))
-    return fail(DSKD_ERR_INVALID_ARG, "dskd_colsum: null / unaligned pointer or negative row count");
+  if (!x || !colsum || rows < 0 || copies < 1 || (reinterpret_cast<uintptr_t>(x) & 15))
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_colsum: null / unaligned pointer, negative row count or copies < 1");
   hipStream_t st = (hipStream_t)stream;
   const __bf16* xp = (const __bf16*)x;
 #define DSKD_LAUNCH_COLSUM(TPR)                                                                          \
   {                                                                                                      \
     const long long want = (rows + (256 / TPR) - 1) / (256 / TPR);                                       \
     hipLaunchKernelGGL(colsum_kernel<TPR>, dim3((unsigned)(want < 1024 ? want : 1024)), dim3(256), 0,   \
-                       st, xp, colsum, (long long)rows);                                                 \
+                       st, xp, colsum, copies, (long long)rows);                                         \
   }
   switch (C) {
     case 256: DSKD_LAUNCH_COLSUM(32) break;
@@ -175,10 +190,10 @@ extern "C" int dskd_dropout_fwd(void* y, int64_t n, float p, uint64_t seed, uint
 }
 
 extern "C" int dskd_relu_dropout_bwd(const void* g, const void* y_dropped, void* out, float* colsum,
-                                     int64_t rows, int C, float p, int dtype, void* stream) {
+                                     int copies, int64_t rows, int C, float p, int dtype, void* stream) {
   if (dtype != DSKD_DTYPE_BF16) return fail(DSKD_ERR_INVALID_ARG, "dskd_relu_dropout_bwd: bf16 only");
-  if (!g || !y_dropped || !out || rows < 0)
-    return fail(DSKD_ERR_INVALID_ARG, "dskd_relu_dropout_bwd: null pointer or negative row count");
+  if (!g || !y_dropped || !out || rows < 0 || copies < 1)
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_relu_dropout_bwd: null pointer, negative row count or copies < 1");
   if ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(y_dropped) | reinterpret_cast<uintptr_t>(out)) & 15)
     return fail(DSKD_ERR_INVALID_ARG, "dskd_relu_dropout_bwd: pointers must be 16-byte aligned");
   if (!(p >= 0.f) || p >= 1.f) return fail(DSKD_ERR_INVALID_ARG, "dskd_relu_dropout_bwd: p=%f", p);
@@ -192,7 +207,7 @@ extern "C" int dskd_relu_dropout_bwd(const void* g, const void* y_dropped, void*
   {                                                                                                   \
     const long long want = (rows + (256 / TPR) - 1) / (256 / TPR);                                    \
     hipLaunchKernelGGL(relu_dropout_bwd_kernel<TPR>, dim3((unsigned)(want < 2048 ? want : 2048)),    \
-                       dim3(256), 0, st, gp, yp, op, colsum, (long long)rows, scale);                 \
+                       dim3(256), 0, st, gp, yp, op, colsum, copies, (long long)rows, scale);         \
   }
   switch (C) {
     case 256: DSKD_LAUNCH_TPR(32) break;

@@ -32,11 +32,11 @@ _SIGNATURES = {
     "dskd_msda_prep_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_add_ln_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, _f32, _f32,
                                    C.c_uint64, C.c_uint64, C.c_int, _vp]),
-    "dskd_add_ln_bwd": (C.c_int, [_vp] * 9 + [_i64, C.c_int, _f32, C.c_uint64, C.c_uint64, C.c_int, _vp]),
+    "dskd_add_ln_bwd": (C.c_int, [_vp] * 9 + [C.c_int, _i64, C.c_int, _f32, C.c_uint64, C.c_uint64, C.c_int, _vp]),
     "dskd_bias_act": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_dropout_fwd": (C.c_int, [_vp, _i64, _f32, C.c_uint64, C.c_uint64, C.c_int, _vp]),
-    "dskd_relu_dropout_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int, _f32, C.c_int, _vp]),
-    "dskd_colsum": (C.c_int, [_vp, _vp, _i64, C.c_int, C.c_int, _vp]),
+    "dskd_relu_dropout_bwd": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _i64, C.c_int, _f32, C.c_int, _vp]),
+    "dskd_colsum": (C.c_int, [_vp, _vp, C.c_int, _i64, C.c_int, C.c_int, _vp]),
     "dskd_lsap_host": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "dskd_lsap_batched": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "dskd_match_cost": (C.c_int, [_vp] * 7 + [C.c_int] * 3 + [_f32] * 3 + [_vp]),
@@ -339,11 +339,13 @@ class _AddLNFunction(torch.autograd.Function):
         dq = dq.contiguous().to(z.dtype) if (want_q and dq is not None) else None
         dres = torch.empty_like(z)
         dh = torch.empty_like(z) if p > 0 else None
-        dgb = torch.zeros((2, D), dtype=torch.float32, device=z.device)
+        copies = _colsum_copies(rows)
+        dgb = torch.zeros((2, copies, D), dtype=torch.float32, device=z.device)
         rc = load().dskd_add_ln_bwd(dy.data_ptr(), None if dq is None else dq.data_ptr(), z.data_ptr(), stats.data_ptr(),
                                     gamma_f.data_ptr(), dres.data_ptr(), None if dh is None else dh.data_ptr(),
-                                    dgb[0].data_ptr(), dgb[1].data_ptr(), rows, D, p, seed, offset, dt, _stream(z))
+                                    dgb[0].data_ptr(), dgb[1].data_ptr(), copies, rows, D, p, seed, offset, dt, _stream(z))
         _check(rc, "dskd_add_ln_bwd")
+        dgb = dgb.sum(1) if copies > 1 else dgb[:, 0]
         dpos = None
         if pos_shape is not None and ctx.needs_input_grad[4] and dq is not None:
             # q = y + pos[r % pos_rows]: d(pos) = sum of dq over the repeats (the images of a batch)
@@ -391,24 +393,36 @@ def relu_dropout_bwd(g: torch.Tensor, y_dropped: torch.Tensor, p: float, want_co
     Cc = g.shape[-1]
     rows = g.numel() // Cc
     out = torch.empty_like(g)
-    colsum = torch.zeros(Cc, dtype=torch.float32, device=g.device) if want_colsum else None
+    copies = _colsum_copies(rows)
+    colsum = torch.zeros((copies, Cc), dtype=torch.float32, device=g.device) if want_colsum else None
     rc = load().dskd_relu_dropout_bwd(g.data_ptr(), y_dropped.data_ptr(), out.data_ptr(),
-                                      None if colsum is None else colsum.data_ptr(), rows, Cc, p, DTYPE_BF16, _stream(g))
+                                      None if colsum is None else colsum.data_ptr(), copies, rows, Cc, p, DTYPE_BF16,
+                                      _stream(g))
     _check(rc, "dskd_relu_dropout_bwd")
+    if colsum is not None:
+        colsum = colsum.sum(0) if copies > 1 else colsum[0]
     return out, colsum
 
 
 COLSUM_WIDTHS = (256, 384, 512, 1024, 2048)
 
 
+def _colsum_copies(rows: int) -> int:
+    """Accumulator copies for the column-sum atomics: tall inputs run ~1000-2000 workgroups, all
+    adding to the same C addresses; 32 copies cut that contention 32x for one tiny extra sum."""
+    return 32 if rows >= 8192 else 1
+
+
 def colsum(x: torch.Tensor) -> torch.Tensor:
     """fp32 column sums of a contiguous [rows, C] bf16 GPU matrix (bias gradient of a Linear)."""
     _need_gpu(x)
     Cc = x.shape[-1]
-    out = torch.zeros(Cc, dtype=torch.float32, device=x.device)
-    rc = load().dskd_colsum(x.data_ptr(), out.data_ptr(), x.numel() // Cc, Cc, DTYPE_BF16, _stream(x))
+    rows = x.numel() // Cc
+    copies = _colsum_copies(rows)
+    out = torch.zeros((copies, Cc), dtype=torch.float32, device=x.device)
+    rc = load().dskd_colsum(x.data_ptr(), out.data_ptr(), copies, rows, Cc, DTYPE_BF16, _stream(x))
     _check(rc, "dskd_colsum")
-    return out
+    return out.sum(0) if copies > 1 else out[0]
 
 
 # --------------------------------------------------------------------------- conv epilogue

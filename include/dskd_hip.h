@@ -233,12 +233,14 @@ int dskd_add_ln_fwd(const void* h, const void* res, const float* pos, int64_t po
  * dres        device, [rows, D] dtype: d loss / d res (overwritten)
  * dh          device, [rows, D] dtype: d loss / d h; pass NULL exactly when drop_p == 0
  *             (then d loss / d h == dres)
- * dgamma, dbeta device, [D] f32, MUST be zeroed by the caller (accumulated with atomics)
+ * dgamma, dbeta device, [copies, D] f32, MUST be zeroed by the caller: workgroup w accumulates into
+ *             copy w % copies with atomics (thousands of workgroups on ONE 1 KB row serialise in
+ *             the L2 atomic units); the gradient is the sum over the copies.  copies >= 1.
  */
 int dskd_add_ln_bwd(const void* dy, const void* dq, const void* z, const float* stats,
                     const float* gamma, void* dres, void* dh, float* dgamma, float* dbeta,
-                    int64_t rows, int D, float drop_p, uint64_t seed, uint64_t offset, int dtype,
-                    void* stream);
+                    int copies, int64_t rows, int D, float drop_p, uint64_t seed, uint64_t offset,
+                    int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
  * In-place epilogue of a folded convolution:  x = act(x + bias[c] (+ identity))
@@ -263,11 +265,13 @@ int dskd_bias_act(void* x, const void* bias, const void* identity, int64_t n, in
 int dskd_dropout_fwd(void* y, int64_t n, float p, uint64_t seed, uint64_t offset, int dtype,
                      void* stream);
 int dskd_relu_dropout_bwd(const void* g, const void* y_dropped, void* out, float* colsum,
-                          int64_t rows, int C, float p, int dtype, void* stream);
+                          int copies, int64_t rows, int C, float p, int dtype, void* stream);
 /* colsum[c] += sum over rows of x[:, c]  -- the bias gradient of a Linear (`grad.sum(0)` in
  * AddmmBackward of every nn.Linear of the transformer).  x device [rows, C] bf16, C in
- * {256, 384, 512, 1024, 2048}; colsum device [C] f32, zeroed by the caller. */
-int dskd_colsum(const void* x, float* colsum, int64_t rows, int C, int dtype, void* stream);
+ * {256, 384, 512, 1024, 2048}; colsum device [copies, C] f32, zeroed by the caller (copies as in
+ * dskd_add_ln_bwd; same for dskd_relu_dropout_bwd). */
+int dskd_colsum(const void* x, float* colsum, int copies, int64_t rows, int C, int dtype,
+                void* stream);
 
 #ifdef __cplusplus
 }

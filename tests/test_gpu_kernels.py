@@ -279,7 +279,7 @@ def test_add_layer_norm_dropout_mask_through_abi():
     dres, dh = torch.empty_like(h), torch.empty_like(h)
     dg, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
     rc = lib.dskd_add_ln_bwd(dy.data_ptr(), None, z.data_ptr(), stats.data_ptr(), gamma.data_ptr(), dres.data_ptr(),
-                             dh.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, D, p, 1234, 7, native.DTYPE_F32, st)
+                             dh.data_ptr(), dg.data_ptr(), db.data_ptr(), 1, rows, D, p, 1234, 7, native.DTYPE_F32, st)
     assert rc == 0, lib.dskd_last_error()
     assert torch.equal(dh != 0, keep & (dres != 0))
     torch.testing.assert_close(dh[keep], (dres / (1 - p))[keep], rtol=1e-6, atol=0)
@@ -288,7 +288,15 @@ def test_add_layer_norm_dropout_mask_through_abi():
     assert lib.dskd_add_ln_fwd(h.data_ptr(), res.data_ptr(), None, 0, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
                                None, None, None, rows, 128, 1e-5, 0.0, 0, 0, native.DTYPE_F32, st) == -1
     assert lib.dskd_add_ln_bwd(dy.data_ptr(), None, z.data_ptr(), stats.data_ptr(), gamma.data_ptr(), dres.data_ptr(),
-                               None, dg.data_ptr(), db.data_ptr(), rows, D, p, 1, 1, native.DTYPE_F32, st) == -1
+                               None, dg.data_ptr(), db.data_ptr(), 1, rows, D, p, 1, 1, native.DTYPE_F32, st) == -1
+    # several accumulator copies: the column sums are spread over them
+    dg4, db4 = torch.zeros(4, D, device=DEV), torch.zeros(4, D, device=DEV)
+    rc = lib.dskd_add_ln_bwd(dy.data_ptr(), None, z.data_ptr(), stats.data_ptr(), gamma.data_ptr(), dres.data_ptr(),
+                             dh.data_ptr(), dg4.data_ptr(), db4.data_ptr(), 4, rows, D, p, 1234, 7, native.DTYPE_F32, st)
+    assert rc == 0
+    torch.testing.assert_close(db4.sum(0), db, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(dg4.sum(0), dg, rtol=1e-4, atol=1e-3)
+    assert int((db4.abs().sum(1) > 0).sum()) == 4
 
 
 def test_add_layer_norm_full_size_properties():
@@ -336,7 +344,7 @@ def test_ffn_dropout_kernels_through_ops():
         o2, c2 = native.relu_dropout_bwd(gr[:, :Cc].contiguous(), yd[:, :Cc].contiguous(), p)
         torch.testing.assert_close(c2, ref[:, :Cc].sum(0), rtol=2e-3, atol=0.15) if Cc <= 1024 else None
     lib = native.load()
-    assert lib.dskd_relu_dropout_bwd(gr.data_ptr(), yd.data_ptr(), out.data_ptr(), None, rows, 768, p, native.DTYPE_BF16,
+    assert lib.dskd_relu_dropout_bwd(gr.data_ptr(), yd.data_ptr(), out.data_ptr(), None, 1, rows, 768, p, native.DTYPE_BF16,
                                      torch.cuda.current_stream().cuda_stream) == -1
 
 
@@ -344,7 +352,7 @@ def test_ffn_dropout_kernels_through_ops():
 def test_colsum_bias_gradient(C):
     """Column sums of a tall bf16 matrix (the bias gradient of a Linear) against fp64 torch."""
     g = torch.Generator().manual_seed(C)
-    x = torch.randn(7013, C, generator=g).to(torch.bfloat16)
+    x = torch.randn(9013, C, generator=g).to(torch.bfloat16)          # >= 8192 rows: 32 accumulator copies
     out = native.colsum(x.to(DEV)).cpu()
     torch.testing.assert_close(out.double(), x.double().sum(0), rtol=1e-4, atol=1e-2)
     assert native.colsum(x[:0].to(DEV)).abs().max() == 0
