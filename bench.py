@@ -160,7 +160,7 @@ def cpu_baseline(seed, num_prev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4, help="images per GPU (weak scaling)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
