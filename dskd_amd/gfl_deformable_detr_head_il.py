@@ -32,7 +32,7 @@ from .bbox import bbox_cxcywh_to_xyxy, bbox_overlaps, bbox_xyxy_to_cxcywh
 from .builder import HEADS, build_assigner, build_loss, build_positional_encoding, build_sampler, build_transformer
 from .dist import reduce_mean
 from .transformer import Linear, inverse_sigmoid, lowp_params
-from .utils import device_const
+from .utils import GraphedFunction, device_const
 
 
 def multi_apply(func, *args, **kwargs):
@@ -298,6 +298,40 @@ class GFLDeformableDETRHead_il(nn.Module):
         loss_dfl = per_layer(dfl.reshape(nl, N, 4), bbox_weights, avg_pos * 4)
         return loss_cls, loss_bbox, loss_iou, loss_dfl
 
+    graph_dense_losses = True      # replay the dense detection losses as hipGraphs on the GPU (utils.GraphedFunction)
+
+    def _dense_losses(self, cls_scores, bbox_cxcywh, bbox_lrtb, labels, bbox_targets, pos, factors, avg_pos):
+        """``loss_layers_dense``, as a hipGraph replay (forward and backward) once the shapes have
+        repeated: 378 tiny launches become ~6.  Eager when gradients are off, on the CPU, inside
+        another capture, or if capture fails."""
+        if not (self.graph_dense_losses and cls_scores.is_cuda and torch.is_grad_enabled() and cls_scores.requires_grad
+                and not torch.cuda.is_current_stream_capturing()):
+            return self.loss_layers_dense(cls_scores, bbox_cxcywh, bbox_lrtb, labels, bbox_targets, pos, factors, avg_pos)
+        if not torch.is_tensor(avg_pos):
+            avg_pos = device_const(float(avg_pos), torch.float32, cls_scores.device)
+        args = (cls_scores.contiguous(), bbox_cxcywh.contiguous(), bbox_lrtb.contiguous(), labels.contiguous(),
+                bbox_targets.contiguous(), pos.contiguous(), factors.contiguous(), avg_pos.detach().reshape(()).float())
+        sig = tuple((tuple(a.shape), a.dtype, a.requires_grad) for a in args)
+        graphs = self.__dict__.setdefault("_dense_graphs", {})
+        g = graphs.get(sig)
+        if g is None:
+            seen = self.__dict__.setdefault("_dense_seen", {})
+            seen[sig] = seen.get(sig, 0) + 1
+            if seen[sig] <= 2:                    # a couple of eager steps first (allocator, caches)
+                return self.loss_layers_dense(*args)
+            try:
+                with torch.autocast(cls_scores.device.type, enabled=False):
+                    g = GraphedFunction(lambda *a: self.loss_layers_dense(*a), args)
+            except Exception as e:  # noqa: BLE001  (an accelerator, not a requirement)
+                import warnings
+                warnings.warn(f"dense-loss hipGraph capture failed ({type(e).__name__}: {e}); staying eager")
+                g = False
+            graphs[sig] = g
+        if g is False:
+            return self.loss_layers_dense(*args)
+        with torch.autocast(cls_scores.device.type, enabled=False):
+            return g(*args)
+
     def loss(self, all_cls_scores, all_bbox_preds, info_all, hs, gt_bboxes_list, gt_labels_list, img_metas,
              gt_bboxes_ignore=None, student_feat=[], teacher_info={}, task_labels={}):
         """:411-1195 for the DSKD configuration."""
@@ -340,7 +374,7 @@ class GFLDeformableDETRHead_il(nn.Module):
         factors = device_const([[float(m["img_shape"][1]), float(m["img_shape"][0]), float(m["img_shape"][1]),
                                  float(m["img_shape"][0])] for m in img_metas], all_bbox_preds.dtype,
                                all_bbox_preds.device).repeat_interleave(Q, dim=0)
-        losses_cls, losses_bbox, losses_iou, losses_dfl = self.loss_layers_dense(
+        losses_cls, losses_bbox, losses_iou, losses_dfl = self._dense_losses(
             all_cls_scores.reshape(nl, B * Q, self.cls_out_channels), bbox_cxcywh.reshape(nl, B * Q, 4),
             bbox_lrtb.reshape(nl, B * Q, -1), labels, bbox_targets, pos, factors, avg_pos)
 

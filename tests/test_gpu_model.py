@@ -243,3 +243,38 @@ def test_teacher_ahead_graph_replay_tracks_eager_teacher():
         prev = (ti["neck_feats"][0], ti["neck_feats"][0].clone())
     entries = [v for v in ahead._graphs.values() if v]
     assert len(entries) == 1 and len(entries[0]) == 2        # captured, verified, double-buffered
+
+
+def test_graphed_dense_losses_equal_eager():
+    """The dense detection losses replayed as hipGraphs (forward + backward) against the eager
+    computation: new inputs every call, non-unit upstream gradients."""
+    cfg, m = _build(seed=9)
+    head = m.bbox_head.to("cuda:0")
+    nl, N, C = 6, 2 * 300, 80
+    g = torch.Generator().manual_seed(12)
+
+    def inputs():
+        cls = torch.randn(nl, N, C, generator=g).to("cuda:0").requires_grad_(True)
+        cx = torch.rand(nl, N, 4, generator=g).mul(0.5).add(0.2).to("cuda:0").requires_grad_(True)
+        lr = torch.rand(nl, N, 4 * 17, generator=g).to("cuda:0").requires_grad_(True)
+        labels = torch.randint(0, 81, (nl, N), generator=g).to("cuda:0")
+        tgt = torch.rand(nl, N, 4, generator=g).mul(0.5).add(0.2).to("cuda:0")
+        factors = torch.tensor([[256., 192., 256., 192.]]).repeat(N, 1).to("cuda:0")
+        return cls, cx, lr, labels, tgt, labels < 80, factors
+
+    head.graph_dense_losses = True
+    for step in range(6):
+        a = inputs()
+        w = [torch.rand(nl, generator=g).to("cuda:0") + 0.5 for _ in range(4)]
+        avg = float(3 + step)
+        out = head._dense_losses(*a, avg)
+        sum((o * wi).sum() for o, wi in zip(out, w)).backward()
+        got = [t.detach().clone() for t in out] + [a[0].grad.clone(), a[1].grad.clone(), a[2].grad.clone()]
+        b = [t.detach().clone().requires_grad_(t.requires_grad) if t.is_floating_point() else t for t in a]
+        ref = head.loss_layers_dense(*b, avg)
+        sum((o * wi).sum() for o, wi in zip(ref, w)).backward()
+        exp = [t.detach() for t in ref] + [b[0].grad, b[1].grad, b[2].grad]
+        for x, y in zip(got, exp):
+            torch.testing.assert_close(x, y, rtol=1e-5, atol=1e-6)
+    graphs = head.__dict__["_dense_graphs"]
+    assert len(graphs) == 1 and all(v is not False for v in graphs.values())       # captured after two eager calls
