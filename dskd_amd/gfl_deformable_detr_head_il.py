@@ -298,14 +298,18 @@ class GFLDeformableDETRHead_il(nn.Module):
         loss_dfl = per_layer(dfl.reshape(nl, N, 4), bbox_weights, avg_pos * 4)
         return loss_cls, loss_bbox, loss_iou, loss_dfl
 
-    graph_dense_losses = True      # replay the dense detection losses as hipGraphs on the GPU (utils.GraphedFunction)
+    # replay the dense detection losses as hipGraphs on the GPU (utils.GraphedFunction); DSKD_EAGER_LOSSES=1 disables
+    graph_dense_losses = not os.environ.get("DSKD_EAGER_LOSSES")
 
     def _dense_losses(self, cls_scores, bbox_cxcywh, bbox_lrtb, labels, bbox_targets, pos, factors, avg_pos):
         """``loss_layers_dense``, as a hipGraph replay (forward and backward) once the shapes have
         repeated: 378 tiny launches become ~6.  Eager when gradients are off, on the CPU, inside
         another capture, or if capture fails."""
+        # Single-process only: with two ranks sharing one GPU over gloo (the only multi-process set-up that
+        # can be rehearsed here) the replays stalled for seconds per step; until that is understood on a real
+        # multi-GPU node the data-parallel path keeps the eager losses.
         if not (self.graph_dense_losses and cls_scores.is_cuda and torch.is_grad_enabled() and cls_scores.requires_grad
-                and not torch.cuda.is_current_stream_capturing()):
+                and not _dist_on() and not torch.cuda.is_current_stream_capturing()):
             return self.loss_layers_dense(cls_scores, bbox_cxcywh, bbox_lrtb, labels, bbox_targets, pos, factors, avg_pos)
         if not torch.is_tensor(avg_pos):
             avg_pos = device_const(float(avg_pos), torch.float32, cls_scores.device)
