@@ -45,12 +45,13 @@ class TeacherAhead:
     ``finish()`` at the top of a step (falls back to an inline teacher when nothing is
     pending), ``launch(next batch)`` right after the student forward has been enqueued."""
 
-    def __init__(self, detector, use_graphs=True, graph_warmup=2):
+    def __init__(self, detector, use_graphs=True, graph_warmup=2, max_graphs=4):
         self.det = detector
         self.stream = None
         self.pending = None
         self.use_graphs = use_graphs
         self.graph_warmup = graph_warmup
+        self.max_graphs = max_graphs          # batch signatures kept as graphs (each holds its activations twice)
         self._graphs, self._seen, self._flip = {}, {}, 0
 
     # The teacher FORWARD is also replayed as a hipGraph once a batch signature has been seen
@@ -120,7 +121,7 @@ class TeacherAhead:
             if entries is None and sig not in self._graphs:
                 n = self._seen.get(sig, 0)
                 self._seen[sig] = n + 1
-                if n >= self.graph_warmup:
+                if n >= self.graph_warmup and sum(1 for v in self._graphs.values() if v) < self.max_graphs:
                     self.stream.wait_stream(main)
                     entries = self._graphs[sig] = self._capture(img, img_metas, amp_dtype)   # None = keep eager
         self.stream.wait_stream(main)                      # the batch (and anything it depends on) is ready
