@@ -301,6 +301,33 @@ class GFLDeformableDETRHead_il(nn.Module):
     # replay the dense detection losses as hipGraphs on the GPU (utils.GraphedFunction); DSKD_EAGER_LOSSES=1 disables
     graph_dense_losses = not os.environ.get("DSKD_EAGER_LOSSES")
 
+    def _decode_v2(self, student_feat, teacher_info, img_metas, hs):
+        """``decode_v2`` (:721-772): per level and image, every teacher box paints
+        ``softmax(hs_teacher[keepid])`` (a 256-vector, no student term) over its cell range --
+        exclusive ends, later boxes overwrite, the box counter runs across the images of a level
+        -- and the loss is ``loss_fg_feature(pred = F_teacher * M, soft = F_student * M)`` summed
+        over levels and images, / B.  As in the reference the prediction slot holds the TEACHER
+        features and the soft target is detached: the term carries no gradient."""
+        hs_soft = teacher_info["head_outs"][3][-1].reshape(-1, hs.shape[-1])
+        id_soft = teacher_info["pred_keepid"]
+        fg_loss = 0
+        for sp, (f_pred, f_soft) in enumerate(zip(student_feat, teacher_info["neck_feats"])):
+            N, C, H, W = f_pred.shape
+            idx = 0
+            for i in range(N):
+                boxes = teacher_info["pred_bboxes"][i]
+                img_h, img_w = img_metas[i]["img_shape"][0], img_metas[i]["img_shape"][1]
+                wmin = torch.floor(boxes[:, 0] / img_w * W).int().tolist()
+                wmax = torch.ceil(boxes[:, 2] / img_w * W).int().tolist()
+                hmin = torch.floor(boxes[:, 1] / img_h * H).int().tolist()
+                hmax = torch.ceil(boxes[:, 3] / img_h * H).int().tolist()
+                mask = f_pred.new_zeros((C, H, W))
+                for j in range(boxes.shape[0]):
+                    mask[:, hmin[j]:hmax[j], wmin[j]:wmax[j]] = hs_soft[id_soft[idx]].softmax(dim=0)[:, None, None]
+                    idx += 1
+                fg_loss = fg_loss + self.loss_fg_feature(f_soft[i] * mask, f_pred[i] * mask, weight=None, avg_factor=None)
+        return fg_loss / len(img_metas)
+
     def _dense_losses(self, cls_scores, bbox_cxcywh, bbox_lrtb, labels, bbox_targets, pos, factors, avg_pos):
         """``loss_layers_dense``, as a hipGraph replay (forward and backward) once the shapes have
         repeated: 378 tiny launches become ~6.  Eager when gradients are off, on the CPU, inside
@@ -340,12 +367,18 @@ class GFLDeformableDETRHead_il(nn.Module):
              gt_bboxes_ignore=None, student_feat=[], teacher_info={}, task_labels={}):
         """:411-1195 for the DSKD configuration."""
         assert gt_bboxes_ignore is None, f"{self.__class__.__name__} only supports for gt_bboxes_ignore setting to None."
-        for name, val, ok in (("cates_distill", self.cates_distill, ("", "hard", "hard + teacher-first")),
-                              ("locat_distill", self.locat_distill, ("",)), ("memory_distill", self.memory_distill, ("",)),
-                              ("feats_distill", self.feats_distill, ("", "corr + fg_info + decode_v1", "corr",
-                                                                     "fg_info + decode_v1"))):
-            if val not in ok:
-                raise NotImplementedError(f"{name}={val!r}: only the DSKD configuration is implemented {ok}")
+        if self.cates_distill not in ("", "hard", "hard + teacher-first"):
+            raise NotImplementedError(f"cates_distill={self.cates_distill!r}: only '', 'hard', 'hard + teacher-first'")
+        if self.locat_distill != "":
+            raise NotImplementedError(f"locat_distill={self.locat_distill!r} is not implemented")
+        if self.memory_distill not in ("", "memory"):
+            raise NotImplementedError(f"memory_distill={self.memory_distill!r}: only '' or 'memory'")
+        fd_tokens = {t.strip() for t in self.feats_distill.split("+") if t.strip()}
+        fd_known = {"corr", "fg_info", "decode_v1", "decode_v2", "kldv"}
+        if not fd_tokens <= fd_known or ("fg_info" in fd_tokens) != bool(fd_tokens & {"decode_v1", "decode_v2"}) \
+                or {"decode_v1", "decode_v2"} <= fd_tokens:
+            raise NotImplementedError(f"feats_distill={self.feats_distill!r}: implemented are combinations of 'corr', "
+                                      "'kldv' and 'fg_info + decode_v1' | 'fg_info + decode_v2'")
         gt_bboxes_list = list(gt_bboxes_list)
         gt_labels_list = list(gt_labels_list)
         if self.has_teacher and "hard" in self.cates_distill:            # :462-465 teacher boxes first
@@ -406,6 +439,20 @@ class GFLDeformableDETRHead_il(nn.Module):
             loss_dict[f"d{i}.loss_bbox"] = losses_bbox[i]
             loss_dict[f"d{i}.loss_iou"] = losses_iou[i]
             loss_dict[f"d{i}.loss_dfl"] = losses_dfl[i]
+
+        if self.has_teacher and "kldv" in self.feats_distill:            # :646-651 whole-map KL, all levels
+            loss_fd = [self.loss_fd(sf, tf, weight=None, avg_factor=None)
+                       for sf, tf in zip(student_feat, teacher_info["neck_feats"])]
+            loss_dict["loss_fd"] = sum(loss_fd) / len(img_metas)
+        if self.has_teacher and "memory" in self.memory_distill:         # :652-661 encoder memories, per image
+            memory = info_all[0]
+            pred_memory = memory.permute(1, 2, 0)                         # [B, C, sum HW]
+            soft_memory = teacher_info["head_outs"][2][0].permute(1, 2, 0)
+            loss_memory = [self.loss_memory(sm, tm, weight=None, avg_factor=None)
+                           for sm, tm in zip(pred_memory, soft_memory)]
+            loss_dict["loss_memory"] = sum(loss_memory) / len(img_metas)
+        if self.has_teacher and "fg_info" in self.feats_distill and "decode_v2" in self.feats_distill:   # :721-772
+            loss_dict["loss_fg_feature"] = self._decode_v2(student_feat, teacher_info, img_metas, hs)
 
         if self.has_teacher and "fg_info" in self.feats_distill and "bg_info" not in self.feats_distill \
                 and "decode_v1" in self.feats_distill:                    # :664-718

@@ -227,6 +227,83 @@ def run_reference_loss(ref, inp, L, img_hw, shapes):
     return out
 
 
+def run_reference_variant(ref, inp, L, img_hw, shapes, feats_distill, memory_distill, mem_s, mem_t):
+    """The other feature-distillation branches of the reference's loss():
+    ``decode_v2`` (:721-772), ``kldv`` (:646-651), ``memory`` (:652-661).  Same harness as
+    run_reference_loss; returns the branch's loss and the gradients it sends anywhere."""
+    H, L_ = ref["head"], ref["losses"]
+    cls_ = H.GFLDeformableDETRHead_il
+    self = types.SimpleNamespace()
+    self.has_teacher = True
+    self.cates_distill, self.feats_distill = "hard + teacher-first", feats_distill
+    self.locat_distill, self.memory_distill = "", memory_distill
+    self.num_classes = self.cls_out_channels = 80
+    self.bg_cls_weight, self.sync_cls_avg_factor, self.reg_max = 0, True, 16
+    self.integral_average = H.Integral_average(16)
+    self.assigner = ref["ga"].GFLHungarianAssigner(
+        cls_cost=dict(type="QualityFocalLossCost", weight=2.0), reg_cost=dict(type="BBoxL1Cost", weight=5.0, box_format="xywh"),
+        iou_cost=dict(type="IoUCost", iou_mode="giou", weight=2.0))
+    self.sampler = ref["ps"].PseudoSampler()
+    self.loss_cls = L_["gfocal_loss"].QualityFocalLoss(use_sigmoid=True, beta=2.0, loss_weight=2.0)
+    self.loss_dfl = L_["gfocal_loss"].DistributionFocalLoss(loss_weight=0.5)
+    self.loss_bbox = L_["smooth_l1_loss"].L1Loss(loss_weight=5.0)
+    self.loss_iou = L_["iou_loss"].GIoULoss(loss_weight=2.0)
+    kd = L_["kd_loss"].KnowledgeDistillationKLDivLoss
+    self.loss_fg_feature = kd(loss_weight=1, T=2, reduction="sum")
+    self.loss_fd = kd(loss_weight=1, T=2)
+    self.loss_memory = kd(loss_weight=1, T=2)
+    self.loss_corr = L_["mse_loss"].MSELoss(loss_weight=1, reduction="mean")
+    for name in ("loss_single_split", "get_targets", "_get_target_single", "correlation_mat"):
+        setattr(self, name, types.MethodType(getattr(cls_, name), self))
+    B = inp["cls"].shape[1]
+    metas = [dict(img_shape=(img_hw[b][0], img_hw[b][1], 3)) for b in range(B)]
+    hs = inp["hs"].clone().requires_grad_(True)
+    fs = [f.clone().requires_grad_(True) for f in inp["feats_s"]]
+    ms = mem_s.clone().requires_grad_(True)
+    spatial = torch.tensor(shapes)
+    teacher_info = dict(neck_feats=inp["feats_t"], head_outs=(None, None, (mem_t, spatial), inp["hs_t"]),
+                        pred_keepid=inp["keep"], pred_labels=[t.clone() for t in inp["t_l"]],
+                        pred_bboxes=[t.clone() for t in inp["t_b"]])
+    losses = cls_.loss(self, inp["cls"].clone(), inp["box"].clone(), (ms, spatial), hs, [b.clone() for b in inp["gt_b"]],
+                       [l.clone() for l in inp["gt_l"]], metas, gt_bboxes_ignore=None, student_feat=fs,
+                       teacher_info=teacher_info, task_labels={"prev": list(range(L)), "curr": list(range(L, 80)), "next": []})
+    out = {}
+    for key in ("loss_fg_feature", "loss_fd", "loss_memory"):
+        if key in losses:
+            out[f"loss/{key}"] = losses[key].detach().numpy()
+            if losses[key].requires_grad:
+                g = torch.autograd.grad(losses[key], [hs, ms] + fs, allow_unused=True, retain_graph=True)
+                out[f"grad_hs_absmax/{key}"] = np.array(0.0 if g[0] is None else float(g[0].abs().max()))
+                if g[1] is not None:
+                    out[f"grad_mem/{key}"] = g[1].numpy()
+                for i, gi in enumerate(g[2:]):
+                    if gi is not None:
+                        out[f"grad_feat{i}/{key}"] = gi.numpy()
+            else:
+                out[f"nograd/{key}"] = np.array(1)
+    out["keys"] = np.array(sorted(losses.keys()))
+    return out
+
+
+def main_variants():
+    """tests/golden/loss_variants_b2_l70.npz: inputs of loss_b2_l70 + student / teacher memories."""
+    ref = load_reference()
+    B, L, shapes, img_hw = 2, 70, [(9, 14), (5, 7)], [(72, 112), (70, 100)]
+    inp = make_loss_inputs(B, L, 11 + B, shapes, img_hw)
+    g = torch.Generator().manual_seed(77)
+    n = sum(h * w for h, w in shapes)
+    mem_s = torch.randn(n, B, 256, generator=g)
+    mem_t = mem_s + 0.3 * torch.randn(n, B, 256, generator=g)
+    flat = {"mem_s": mem_s.numpy(), "mem_t": mem_t.numpy()}
+    for tag, fd, md in (("decode_v2", "corr + fg_info + decode_v2", ""), ("kldv", "corr + kldv", ""),
+                        ("memory", "corr", "memory")):
+        out = run_reference_variant(ref, inp, L, img_hw, shapes, fd, md, mem_s, mem_t)
+        for k, v in out.items():
+            flat[f"{tag}/{k}"] = v
+        print(tag, {k: (float(v) if v.ndim == 0 else v.shape) for k, v in out.items() if k != "keys"})
+    np.savez_compressed(os.path.join(OUT, "loss_variants_b2_l70.npz"), **flat)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(4)
@@ -306,4 +383,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--variants" in sys.argv:
+        main_variants()
+    else:
+        main()

@@ -179,3 +179,40 @@ def test_dskd_loss_oracles_vs_reference(name):
     lf.backward()
     torch.testing.assert_close(lf.detach(), t(z["loss/loss_fg_feature"]), rtol=1e-5, atol=1e-9)
     torch.testing.assert_close(x2.grad, t(z["grad_hs/loss_fg_feature"]).reshape(-1, 256), rtol=1e-4, atol=1e-9)
+
+
+@pytest.mark.parametrize("tag,feats_distill,memory_distill,key", [
+    ("decode_v2", "corr + fg_info + decode_v2", "", "loss_fg_feature"),
+    ("kldv", "corr + kldv", "", "loss_fd"),
+    ("memory", "corr", "memory", "loss_memory")])
+def test_other_distill_variants_vs_reference(tag, feats_distill, memory_distill, key, cpu_ops):
+    """the other feature / memory distillation branches of the reference's
+    loss() -- decode_v2 (:721-772), kldv (:646-651), memory (:652-661) -- against goldens made by
+    running the reference on the inputs of loss_b2_l70 (tests/golden/gen_golden.py --variants)."""
+    d = _load_loss_case("loss_b2_l70.npz")
+    v = np.load(os.path.join(G, "loss_variants_b2_l70.npz"))
+    head = _make_head(d["L"])
+    head.feats_distill, head.memory_distill = feats_distill, memory_distill
+    head.loss_fd = plosses.KnowledgeDistillationKLDivLoss(loss_weight=1, T=2)
+    head.loss_memory = plosses.KnowledgeDistillationKLDivLoss(loss_weight=1, T=2)
+    hs = d["hs"].clone().requires_grad_(True)
+    fs = [f.clone().requires_grad_(True) for f in d["feats_s"]]
+    mem_s = t(v["mem_s"]).clone().requires_grad_(True)
+    metas = [dict(img_shape=(d["img_hw"][b][0], d["img_hw"][b][1], 3)) for b in range(d["B"])]
+    spatial = torch.tensor(d["shapes"])
+    tinfo = dict(neck_feats=d["feats_t"], head_outs=(None, None, (t(v["mem_t"]), spatial), d["hs_t"][None]),
+                 pred_keepid=d["keep"], pred_labels=d["t_l"], pred_bboxes=d["t_b"])
+    losses = head.loss(d["cls"].clone(), d["box"].clone(), (mem_s, spatial), hs, d["gt_b"], d["gt_l"], metas,
+                       student_feat=fs, teacher_info=tinfo, task_labels={"prev": list(range(d["L"])), "curr": [], "next": []})
+    assert sorted(losses.keys()) == sorted(v[f"{tag}/keys"].tolist())
+    torch.testing.assert_close(losses[key].detach(), t(v[f"{tag}/loss/{key}"]), rtol=2e-4, atol=1e-9)
+    if f"{tag}/nograd/{key}" in v.files:
+        assert not losses[key].requires_grad           # decode_v2: teacher features in the prediction slot
+        return
+    g = torch.autograd.grad(losses[key], [hs, mem_s] + fs, allow_unused=True)
+    assert g[0] is None or float(g[0].abs().max()) == 0.0
+    if f"{tag}/grad_mem/{key}" in v.files:
+        torch.testing.assert_close(g[1], t(v[f"{tag}/grad_mem/{key}"]), rtol=1e-3, atol=1e-10)
+    for i in range(len(fs)):
+        if f"{tag}/grad_feat{i}/{key}" in v.files:
+            torch.testing.assert_close(g[2 + i], t(v[f"{tag}/grad_feat{i}/{key}"]), rtol=1e-3, atol=1e-10)
