@@ -301,6 +301,48 @@ class GFLDeformableDETRHead_il(nn.Module):
     # replay the dense detection losses as hipGraphs on the GPU (utils.GraphedFunction); DSKD_EAGER_LOSSES=1 disables
     graph_dense_losses = not os.environ.get("DSKD_EAGER_LOSSES")
 
+    def _masked_memory_kl(self, info_all, student_feat, teacher_info, img_metas, gt_bboxes_original, sg_out):
+        """``sg_out`` (:860-925) and ``fg_only`` (:1082-1129): the encoder memories, cut back into
+        per-level maps, under a foreground mask made from the teacher boxes with INCLUSIVE cell
+        ranges (``hmin:hmax+1``):
+          sg_out   mask = 1 on teacher-box cells, then 0 on the cells of the image's own GT boxes
+          fg_only  mask = max over boxes of 1 / ((hmax+1-hmin)(wmax+1-wmin))
+        each entering as ``sqrt(mask)``; loss = ``loss_fg_feature(pred = M_teacher * m, soft =
+        M_student * m)`` summed over levels and images, / B.  Teacher memory in the prediction slot
+        and a detached soft target: no gradient, as in the reference."""
+        memory, spatial_shapes = info_all
+        shapes = [(int(h), int(w)) for h, w in (spatial_shapes.tolist() if torch.is_tensor(spatial_shapes) else spatial_shapes)]
+        pred_mem = memory.permute(1, 2, 0)
+        soft_mem = teacher_info["head_outs"][2][0].permute(1, 2, 0)
+        start, fg_loss = 0, 0
+
+        def cells(boxes, img_h, img_w, H, W):
+            return (torch.floor(boxes[:, 0] / img_w * W).int().tolist(), torch.ceil(boxes[:, 2] / img_w * W).int().tolist(),
+                    torch.floor(boxes[:, 1] / img_h * H).int().tolist(), torch.ceil(boxes[:, 3] / img_h * H).int().tolist())
+        for sp, (H, W) in enumerate(shapes):
+            N, C = student_feat[sp].shape[:2]
+            m_pred = pred_mem[:, :, start:start + H * W].reshape(N, C, H, W)
+            m_soft = soft_mem[:, :, start:start + H * W].reshape(N, C, H, W)
+            start += H * W
+            for i in range(N):
+                img_h, img_w = img_metas[i]["img_shape"][0], img_metas[i]["img_shape"][1]
+                mask = m_pred.new_zeros((H, W))
+                wmin, wmax, hmin, hmax = cells(teacher_info["pred_bboxes"][i], img_h, img_w, H, W)
+                for j in range(len(wmin)):
+                    if sg_out:
+                        mask[hmin[j]:hmax[j] + 1, wmin[j]:wmax[j] + 1] = 1
+                    else:
+                        area = 1.0 / (hmax[j] + 1 - hmin[j]) / (wmax[j] + 1 - wmin[j])
+                        region = mask[hmin[j]:hmax[j] + 1, wmin[j]:wmax[j] + 1]
+                        mask[hmin[j]:hmax[j] + 1, wmin[j]:wmax[j] + 1] = torch.clamp(region, min=area)
+                if sg_out:
+                    wmin, wmax, hmin, hmax = cells(gt_bboxes_original[i], img_h, img_w, H, W)
+                    for j in range(len(wmin)):
+                        mask[hmin[j]:hmax[j] + 1, wmin[j]:wmax[j] + 1] = 0
+                m = torch.sqrt(mask).unsqueeze(0)
+                fg_loss = fg_loss + self.loss_fg_feature(m_soft[i] * m, m_pred[i] * m, weight=None, avg_factor=None)
+        return fg_loss / len(img_metas)
+
     def _decode_v2(self, student_feat, teacher_info, img_metas, hs):
         """``decode_v2`` (:721-772): per level and image, every teacher box paints
         ``softmax(hs_teacher[keepid])`` (a 256-vector, no student term) over its cell range --
@@ -374,13 +416,15 @@ class GFLDeformableDETRHead_il(nn.Module):
         if self.memory_distill not in ("", "memory"):
             raise NotImplementedError(f"memory_distill={self.memory_distill!r}: only '' or 'memory'")
         fd_tokens = {t.strip() for t in self.feats_distill.split("+") if t.strip()}
-        fd_known = {"corr", "fg_info", "decode_v1", "decode_v2", "kldv"}
-        if not fd_tokens <= fd_known or ("fg_info" in fd_tokens) != bool(fd_tokens & {"decode_v1", "decode_v2"}) \
-                or {"decode_v1", "decode_v2"} <= fd_tokens:
+        fg_kinds = {"decode_v1", "decode_v2", "sg_out", "fg_only"}
+        fd_known = {"corr", "fg_info", "kldv"} | fg_kinds
+        if not fd_tokens <= fd_known or ("fg_info" in fd_tokens) != (len(fd_tokens & fg_kinds) == 1) \
+                or len(fd_tokens & fg_kinds) > 1:
             raise NotImplementedError(f"feats_distill={self.feats_distill!r}: implemented are combinations of 'corr', "
-                                      "'kldv' and 'fg_info + decode_v1' | 'fg_info + decode_v2'")
+                                      "'kldv' and 'fg_info + <one of decode_v1, decode_v2, sg_out, fg_only>'")
         gt_bboxes_list = list(gt_bboxes_list)
         gt_labels_list = list(gt_labels_list)
+        gt_bboxes_original = list(gt_bboxes_list)                         # :459 (sg_out zeroes the GT cells)
         if self.has_teacher and "hard" in self.cates_distill:            # :462-465 teacher boxes first
             for i in range(len(img_metas)):
                 gt_labels_list[i] = torch.cat([teacher_info["pred_labels"][i], gt_labels_list[i]], dim=0)
@@ -453,6 +497,10 @@ class GFLDeformableDETRHead_il(nn.Module):
             loss_dict["loss_memory"] = sum(loss_memory) / len(img_metas)
         if self.has_teacher and "fg_info" in self.feats_distill and "decode_v2" in self.feats_distill:   # :721-772
             loss_dict["loss_fg_feature"] = self._decode_v2(student_feat, teacher_info, img_metas, hs)
+        if self.has_teacher and "fg_info" in self.feats_distill and \
+                ("sg_out" in self.feats_distill or "fg_only" in self.feats_distill):                     # :860-925, :1082-1129
+            loss_dict["loss_fg_feature"] = self._masked_memory_kl(
+                info_all, student_feat, teacher_info, img_metas, gt_bboxes_original, "sg_out" in self.feats_distill)
 
         if self.has_teacher and "fg_info" in self.feats_distill and "bg_info" not in self.feats_distill \
                 and "decode_v1" in self.feats_distill:                    # :664-718

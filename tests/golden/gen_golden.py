@@ -296,7 +296,8 @@ def main_variants():
     mem_t = mem_s + 0.3 * torch.randn(n, B, 256, generator=g)
     flat = {"mem_s": mem_s.numpy(), "mem_t": mem_t.numpy()}
     for tag, fd, md in (("decode_v2", "corr + fg_info + decode_v2", ""), ("kldv", "corr + kldv", ""),
-                        ("memory", "corr", "memory")):
+                        ("memory", "corr", "memory"), ("sg_out", "corr + fg_info + sg_out", ""),
+                        ("fg_only", "corr + fg_info + fg_only", "")):
         out = run_reference_variant(ref, inp, L, img_hw, shapes, fd, md, mem_s, mem_t)
         for k, v in out.items():
             flat[f"{tag}/{k}"] = v

@@ -184,10 +184,13 @@ def test_dskd_loss_oracles_vs_reference(name):
 @pytest.mark.parametrize("tag,feats_distill,memory_distill,key", [
     ("decode_v2", "corr + fg_info + decode_v2", "", "loss_fg_feature"),
     ("kldv", "corr + kldv", "", "loss_fd"),
-    ("memory", "corr", "memory", "loss_memory")])
+    ("memory", "corr", "memory", "loss_memory"),
+    ("sg_out", "corr + fg_info + sg_out", "", "loss_fg_feature"),
+    ("fg_only", "corr + fg_info + fg_only", "", "loss_fg_feature")])
 def test_other_distill_variants_vs_reference(tag, feats_distill, memory_distill, key, cpu_ops):
     """the other feature / memory distillation branches of the reference's
-    loss() -- decode_v2 (:721-772), kldv (:646-651), memory (:652-661) -- against goldens made by
+    loss() -- decode_v2 (:721-772), kldv (:646-651), memory (:652-661), sg_out (:860-925), fg_only
+    (:1082-1129) -- against goldens made by
     running the reference on the inputs of loss_b2_l70 (tests/golden/gen_golden.py --variants)."""
     d = _load_loss_case("loss_b2_l70.npz")
     v = np.load(os.path.join(G, "loss_variants_b2_l70.npz"))
