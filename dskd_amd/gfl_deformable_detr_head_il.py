@@ -409,10 +409,13 @@ class GFLDeformableDETRHead_il(nn.Module):
              gt_bboxes_ignore=None, student_feat=[], teacher_info={}, task_labels={}):
         """:411-1195 for the DSKD configuration."""
         assert gt_bboxes_ignore is None, f"{self.__class__.__name__} only supports for gt_bboxes_ignore setting to None."
-        if self.cates_distill not in ("", "hard", "hard + teacher-first"):
-            raise NotImplementedError(f"cates_distill={self.cates_distill!r}: only '', 'hard', 'hard + teacher-first'")
-        if self.locat_distill != "":
-            raise NotImplementedError(f"locat_distill={self.locat_distill!r} is not implemented")
+        cd_tokens = {t.strip() for t in self.cates_distill.split("+") if t.strip()}
+        if not cd_tokens <= {"hard", "soft", "teacher-first"} or (cd_tokens and "hard" not in cd_tokens):
+            raise NotImplementedError(f"cates_distill={self.cates_distill!r}: implemented are 'hard' with optional "
+                                      "'soft' and 'teacher-first'")
+        ld_tokens = {t.strip() for t in self.locat_distill.split("+") if t.strip()}
+        if not ld_tokens <= {"bbox", "logit"}:
+            raise NotImplementedError(f"locat_distill={self.locat_distill!r}: implemented are 'bbox' and 'logit'")
         if self.memory_distill not in ("", "memory"):
             raise NotImplementedError(f"memory_distill={self.memory_distill!r}: only '' or 'memory'")
         fd_tokens = {t.strip() for t in self.feats_distill.split("+") if t.strip()}
@@ -484,6 +487,31 @@ class GFLDeformableDETRHead_il(nn.Module):
             loss_dict[f"d{i}.loss_iou"] = losses_iou[i]
             loss_dict[f"d{i}.loss_dfl"] = losses_dfl[i]
 
+        if self.has_teacher and "soft" in self.cates_distill:            # :590-622 logits of the matched queries
+            n_t = teacher_info["pred_keepid"].shape[0]
+            teacher_label = teacher_info["head_outs"][0][-1].reshape(-1, self.cls_out_channels)[teacher_info["pred_keepid"]]
+            # `teacher_only_weights[-1]` (:1453-1455): last-layer queries whose assigned label is a previous-task label
+            mask_student = torch.nonzero(prev_mask[labels[-1].clamp(max=self.cls_out_channels - 1)]
+                                         & (labels[-1] < self.cls_out_channels)).squeeze(1)
+            student_label = all_cls_scores[-1].reshape(-1, self.cls_out_channels)[mask_student]
+            loss_dict["loss_kd"] = self.loss_kd(student_label, teacher_label, weight=None, avg_factor=n_t)
+        if self.has_teacher and "bbox" in self.locat_distill:            # :624-635
+            n_t = teacher_info["pred_keepid"].shape[0]
+            pred_box, soft_box = all_bbox_preds[-1], teacher_info["head_outs"][1][-1].float()
+            wh_pred, wh_soft = self.integral_average(pred_box[:, :, 2:]), self.integral_average(soft_box[:, :, 2:])
+            soft_weight = wh_soft.new_zeros((wh_soft.shape[0], 1))
+            soft_weight[teacher_info["pred_keepid"]] = 1
+            cxcywh_pred = torch.cat((pred_box[:, :, :2].reshape(-1, 2), wh_pred), dim=1)
+            cxcywh_soft = torch.cat((soft_box[:, :, :2].reshape(-1, 2), wh_soft), dim=1)
+            loss_dict["loss_ld_bbox"] = self.loss_ld_bbox(cxcywh_pred, cxcywh_soft, weight=soft_weight, avg_factor=n_t)
+        if self.has_teacher and "logit" in self.locat_distill:           # :636-645
+            n_t = teacher_info["pred_keepid"].shape[0]
+            width = 4 * (self.reg_max + 1) + 2
+            pred_box = all_bbox_preds[-1].reshape(-1, width)
+            soft_box = teacher_info["head_outs"][1][-1].float().reshape(-1, width)
+            soft_weight = soft_box.new_zeros((soft_box.shape[0], 1))
+            soft_weight[teacher_info["pred_keepid"]] = 1
+            loss_dict["loss_ld_logit"] = self.loss_ld_logit(pred_box, soft_box, weight=soft_weight, avg_factor=n_t)
         if self.has_teacher and "kldv" in self.feats_distill:            # :646-651 whole-map KL, all levels
             loss_fd = [self.loss_fd(sf, tf, weight=None, avg_factor=None)
                        for sf, tf in zip(student_feat, teacher_info["neck_feats"])]

@@ -227,7 +227,8 @@ def run_reference_loss(ref, inp, L, img_hw, shapes):
     return out
 
 
-def run_reference_variant(ref, inp, L, img_hw, shapes, feats_distill, memory_distill, mem_s, mem_t):
+def run_reference_variant(ref, inp, L, img_hw, shapes, feats_distill, memory_distill, mem_s, mem_t,
+                          cates_distill="hard + teacher-first", locat_distill="", cls_t=None, box_t=None):
     """The other feature-distillation branches of the reference's loss():
     ``decode_v2`` (:721-772), ``kldv`` (:646-651), ``memory`` (:652-661).  Same harness as
     run_reference_loss; returns the branch's loss and the gradients it sends anywhere."""
@@ -235,8 +236,8 @@ def run_reference_variant(ref, inp, L, img_hw, shapes, feats_distill, memory_dis
     cls_ = H.GFLDeformableDETRHead_il
     self = types.SimpleNamespace()
     self.has_teacher = True
-    self.cates_distill, self.feats_distill = "hard + teacher-first", feats_distill
-    self.locat_distill, self.memory_distill = "", memory_distill
+    self.cates_distill, self.feats_distill = cates_distill, feats_distill
+    self.locat_distill, self.memory_distill = locat_distill, memory_distill
     self.num_classes = self.cls_out_channels = 80
     self.bg_cls_weight, self.sync_cls_avg_factor, self.reg_max = 0, True, 16
     self.integral_average = H.Integral_average(16)
@@ -252,6 +253,9 @@ def run_reference_variant(ref, inp, L, img_hw, shapes, feats_distill, memory_dis
     self.loss_fg_feature = kd(loss_weight=1, T=2, reduction="sum")
     self.loss_fd = kd(loss_weight=1, T=2)
     self.loss_memory = kd(loss_weight=1, T=2)
+    self.loss_kd = kd(loss_weight=10, T=2)                                        # ctor defaults (:98-106)
+    self.loss_ld_bbox = L_["smooth_l1_loss"].SmoothL1Loss(loss_weight=10, reduction="mean")
+    self.loss_ld_logit = kd(loss_weight=0.25, T=10)
     self.loss_corr = L_["mse_loss"].MSELoss(loss_weight=1, reduction="mean")
     for name in ("loss_single_split", "get_targets", "_get_target_single", "correlation_mat"):
         setattr(self, name, types.MethodType(getattr(cls_, name), self))
@@ -260,14 +264,24 @@ def run_reference_variant(ref, inp, L, img_hw, shapes, feats_distill, memory_dis
     hs = inp["hs"].clone().requires_grad_(True)
     fs = [f.clone().requires_grad_(True) for f in inp["feats_s"]]
     ms = mem_s.clone().requires_grad_(True)
+    cls_in = inp["cls"].clone().requires_grad_(True)
+    box_in = inp["box"].clone().requires_grad_(True)
     spatial = torch.tensor(shapes)
-    teacher_info = dict(neck_feats=inp["feats_t"], head_outs=(None, None, (mem_t, spatial), inp["hs_t"]),
+    teacher_info = dict(neck_feats=inp["feats_t"], head_outs=(cls_t, box_t, (mem_t, spatial), inp["hs_t"]),
                         pred_keepid=inp["keep"], pred_labels=[t.clone() for t in inp["t_l"]],
                         pred_bboxes=[t.clone() for t in inp["t_b"]])
-    losses = cls_.loss(self, inp["cls"].clone(), inp["box"].clone(), (ms, spatial), hs, [b.clone() for b in inp["gt_b"]],
+    losses = cls_.loss(self, cls_in, box_in, (ms, spatial), hs, [b.clone() for b in inp["gt_b"]],
                        [l.clone() for l in inp["gt_l"]], metas, gt_bboxes_ignore=None, student_feat=fs,
                        teacher_info=teacher_info, task_labels={"prev": list(range(L)), "curr": list(range(L, 80)), "next": []})
     out = {}
+    for key in ("loss_kd", "loss_ld_bbox", "loss_ld_logit"):
+        if key in losses:
+            out[f"loss/{key}"] = losses[key].detach().numpy()
+            g = torch.autograd.grad(losses[key], [cls_in, box_in], allow_unused=True, retain_graph=True)
+            if g[0] is not None:
+                out[f"grad_cls_last/{key}"] = g[0][-1].numpy()
+            if g[1] is not None:
+                out[f"grad_box_last/{key}"] = g[1][-1].numpy()
     for key in ("loss_fg_feature", "loss_fd", "loss_memory"):
         if key in losses:
             out[f"loss/{key}"] = losses[key].detach().numpy()
@@ -294,11 +308,19 @@ def main_variants():
     n = sum(h * w for h, w in shapes)
     mem_s = torch.randn(n, B, 256, generator=g)
     mem_t = mem_s + 0.3 * torch.randn(n, B, 256, generator=g)
-    flat = {"mem_s": mem_s.numpy(), "mem_t": mem_t.numpy()}
+    cls_t = inp["cls"][-1:] + 0.5 * torch.randn(inp["cls"][-1:].shape, generator=g)      # teacher head outputs (last layer)
+    box_t = (inp["box"][-1:] + 0.05 * torch.randn(inp["box"][-1:].shape, generator=g)).clamp(0.01, 0.99)
+    flat = {"mem_s": mem_s.numpy(), "mem_t": mem_t.numpy(), "cls_t": cls_t.numpy(), "box_t": box_t.numpy()}
     for tag, fd, md in (("decode_v2", "corr + fg_info + decode_v2", ""), ("kldv", "corr + kldv", ""),
                         ("memory", "corr", "memory"), ("sg_out", "corr + fg_info + sg_out", ""),
                         ("fg_only", "corr + fg_info + fg_only", "")):
         out = run_reference_variant(ref, inp, L, img_hw, shapes, fd, md, mem_s, mem_t)
+        for k, v in out.items():
+            flat[f"{tag}/{k}"] = v
+        print(tag, {k: (float(v) if v.ndim == 0 else v.shape) for k, v in out.items() if k != "keys"})
+    for tag, cd, ld in (("soft", "hard + soft + teacher-first", ""), ("ld", "hard + teacher-first", "bbox + logit")):
+        out = run_reference_variant(ref, inp, L, img_hw, shapes, "corr", "", mem_s, mem_t, cates_distill=cd,
+                                    locat_distill=ld, cls_t=cls_t, box_t=box_t)
         for k, v in out.items():
             flat[f"{tag}/{k}"] = v
         print(tag, {k: (float(v) if v.ndim == 0 else v.shape) for k, v in out.items() if k != "keys"})
