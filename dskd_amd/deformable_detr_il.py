@@ -304,6 +304,10 @@ class DeformableDETR_il(nn.Module):
                 pred_keepid = torch.cat([pk + i * head_outs[0].shape[2] for i, pk in enumerate(pred_keepid)])
         return neck_feat, head_outs, pred_keepid, pred_logits, pred_labels, pred_scores, pred_bboxes
 
+    def __deepcopy__(self, memo):
+        from .utils import deepcopy_without
+        return deepcopy_without(self, memo, ("_teacher_ahead",))
+
     def teacher_ahead(self):
         """The :class:`TeacherAhead` pipeline of this detector (created on first use)."""
         ta = self.__dict__.get("_teacher_ahead")

@@ -32,7 +32,7 @@ from .bbox import bbox_cxcywh_to_xyxy, bbox_overlaps, bbox_xyxy_to_cxcywh
 from .builder import HEADS, build_assigner, build_loss, build_positional_encoding, build_sampler, build_transformer
 from .dist import reduce_mean
 from .transformer import Linear, inverse_sigmoid, lowp_params
-from .utils import GraphedFunction, device_const
+from .utils import GraphedFunction, deepcopy_without, device_const
 
 
 def multi_apply(func, *args, **kwargs):
@@ -297,6 +297,9 @@ class GFLDeformableDETRHead_il(nn.Module):
         dfl = self.loss_dfl(pred_corners, target_corners, None, reduction_override="none")
         loss_dfl = per_layer(dfl.reshape(nl, N, 4), bbox_weights, avg_pos * 4)
         return loss_cls, loss_bbox, loss_iou, loss_dfl
+
+    def __deepcopy__(self, memo):
+        return deepcopy_without(self, memo, ("_dense_graphs", "_dense_seen"))
 
     # replay the dense detection losses as hipGraphs on the GPU (utils.GraphedFunction); DSKD_EAGER_LOSSES=1 disables
     graph_dense_losses = not os.environ.get("DSKD_EAGER_LOSSES")

@@ -96,3 +96,15 @@ class GraphedFunction:
 
     def __call__(self, *args):
         return self._fn.apply(*args)
+
+
+def deepcopy_without(obj, memo, skip):
+    """``copy.deepcopy`` of a module minus run-time accelerator state (hipGraphs, streams): the
+    incremental driver deep-copies the trained student to make the next task's teacher."""
+    import copy
+    new = obj.__class__.__new__(obj.__class__)
+    memo[id(obj)] = new
+    for k, v in obj.__dict__.items():
+        if k not in skip:
+            new.__dict__[k] = copy.deepcopy(v, memo)
+    return new

@@ -245,3 +245,20 @@ def test_lean_self_attention_equals_nn_multihead_attention():
     # and through forward(): identity + attention (dropout 0)
     out = m(q, query_pos=pos)
     torch.testing.assert_close(out, q + ref, rtol=1e-5, atol=1e-5)
+
+
+def test_deepcopy_drops_runtime_accelerator_state():
+    """The incremental driver deep-copies the trained student into the next teacher
+    (train_increment.py:250-251): hipGraph / stream holders cached on the modules must not be
+    copied (they cannot be) and must not survive in the copy."""
+    import threading
+    cfg, m = _tiny_model()
+    m.__dict__["_teacher_ahead"] = threading.Lock()                 # stands in for streams + CUDAGraphs
+    m.bbox_head.__dict__["_dense_graphs"] = {"sig": threading.Lock()}
+    m.bbox_head.__dict__["_dense_seen"] = {"sig": 3}
+    c = copy.deepcopy(m)
+    assert "_teacher_ahead" not in c.__dict__ and "_dense_graphs" not in c.bbox_head.__dict__
+    assert "_teacher_ahead" in m.__dict__ and "_dense_graphs" in m.bbox_head.__dict__
+    for (n, a), (_, b) in zip(m.state_dict().items(), c.state_dict().items()):
+        assert torch.equal(a, b) and a.data_ptr() != b.data_ptr(), n
+    assert c.bbox_head is not m.bbox_head and c.bbox_head.transformer is not m.bbox_head.transformer
