@@ -50,13 +50,22 @@ def allreduce_scalars(values):
     return flat
 
 
-def wrap_ddp(model, device_ids=None, bucket_cap_mb=50, find_unused_parameters=True, **kwargs):
-    """DDP over RCCL with bucketed gradient all-reduce overlapped with backward
-    (train_increment.py:301-303 uses broadcast_buffers=False, find_unused_parameters=True:
-    the ``prototype`` embedding never receives a gradient).  xGMI is point-to-point
+def wrap_ddp(model, device_ids=None, bucket_cap_mb=50, find_unused_parameters=None, **kwargs):
+    """DDP over RCCL with bucketed gradient all-reduce overlapped with backward.
+    The reference wraps with ``find_unused_parameters=True`` (train_increment.py:301-303) because
+    the head's ``prototype`` embedding never receives a gradient; that makes DDP walk the autograd
+    graph and all-reduce a used-parameter bitmap every iteration.  Here the parameters that are
+    unused BY CONSTRUCTION (``*.prototype.weight``) are excluded from DDP instead
+    (``_ddp_params_and_buffers_to_ignore``) and the search is off; pass
+    ``find_unused_parameters=True`` to get the reference behaviour.  xGMI is point-to-point
     (7 links x ~153 GB/s per GPU): ~160 MB of fp32 gradients in 50 MB buckets keeps several
     ring steps in flight per link while the backward still runs."""
     from torch.nn.parallel import DistributedDataParallel
+    if find_unused_parameters is None:
+        ignore = [n for n, _ in model.named_parameters() if n.endswith("prototype.weight")]
+        if ignore:
+            DistributedDataParallel._set_params_and_buffers_to_ignore_for_model(model, ignore)
+        find_unused_parameters = False
     return DistributedDataParallel(model, device_ids=device_ids, broadcast_buffers=False,
                                    find_unused_parameters=find_unused_parameters, bucket_cap_mb=bucket_cap_mb,
                                    gradient_as_bucket_view=True, **kwargs)

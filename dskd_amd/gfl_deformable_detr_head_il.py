@@ -381,7 +381,8 @@ class GFLDeformableDETRHead_il(nn.Module):
         # can be rehearsed here) the replays stalled for seconds per step; until that is understood on a real
         # multi-GPU node the data-parallel path keeps the eager losses.
         if not (self.graph_dense_losses and cls_scores.is_cuda and torch.is_grad_enabled() and cls_scores.requires_grad
-                and not _dist_on() and not torch.cuda.is_current_stream_capturing()):
+                and (not _dist_on() or os.environ.get("DSKD_FORCE_GRAPHED_LOSSES"))
+                and not torch.cuda.is_current_stream_capturing()):
             return self.loss_layers_dense(cls_scores, bbox_cxcywh, bbox_lrtb, labels, bbox_targets, pos, factors, avg_pos)
         if not torch.is_tensor(avg_pos):
             avg_pos = device_const(float(avg_pos), torch.float32, cls_scores.device)
