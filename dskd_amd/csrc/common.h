@@ -58,6 +58,25 @@ __device__ __forceinline__ float group8_sum(float v) {
   return v;
 }
 
+__device__ __forceinline__ float dpp_row_mirror(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+}
+// reductions over an aligned group of 16 lanes (one DPP row); every lane gets the result
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_quad_xor1(v);
+  v += dpp_quad_xor2(v);
+  v += dpp_half_mirror(v);
+  v += dpp_row_mirror(v);
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_quad_xor1(v));
+  v = fmaxf(v, dpp_quad_xor2(v));
+  v = fmaxf(v, dpp_half_mirror(v));
+  v = fmaxf(v, dpp_row_mirror(v));
+  return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

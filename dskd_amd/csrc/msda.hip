@@ -187,12 +187,52 @@ __device__ __forceinline__ void stage_points(const float* __restrict__ loc,
   }
 }
 
-// ------------------------------------------------------------------ forward
+// The same pass when the MODULE prologue is folded in (no-grad forward: frozen teacher, inference):
+// the points come straight from the projection output ``both`` ([.., heads*16*2] offsets then
+// [.., heads*16] logits, as written by the fused offsets/logits GEMM) and the reference points --
+// softmax over the 16 (level, point) logits of a head with DPP row reductions, loc = ref + off /
+// (W, H) -- with the arithmetic of msda_prep.hip, so the result is bit-identical to prologue
+// kernel + sampling kernel while loc / attn (1.5 KB per query, f32) are never written or read.
 template <typename T>
+__device__ __forceinline__ void stage_points_fused(const T* __restrict__ both, const float* __restrict__ ref,
+                                                   const i32x4* g, int b, int Nq, int q0, int q_end,
+                                                   int levels, int points, int lane, i32x4* s_off,
+                                                   f32x4* s_wt) {
+  using TR = Traits<T>;
+  constexpr int PQ = kHeads * 16;                  // points per query (levels * points == 16)
+  const int npts = TR::QPW * PQ;
+  for (int pi = lane; pi < npts; pi += 64) {       // 16 consecutive lanes = the 16 points of one (query, head)
+    const int qs = pi / PQ;
+    const int r = pi - qs * PQ;
+    const int h = r >> 4, s = r & 15;
+    const int q = q0 + qs;
+    const int qc = q < q_end ? q : q_end - 1;
+    const T* row = both + ((size_t)b * Nq + qc) * (size_t)(PQ * 3);
+    const float ox = (float)row[r * 2], oy = (float)row[r * 2 + 1];
+    const float lg = (float)row[PQ * 2 + r];
+    const float mx = row16_max(lg);
+    const float e = __expf(lg - mx);
+    const float a = e / row16_sum(e);
+    const int lvl = s / points;
+    const i32x4 lt = g[lvl];                        // {H, W, start, 0}
+    const f32x2 rf = *reinterpret_cast<const f32x2*>(ref + (((size_t)b * Nq + qc) * levels + lvl) * 2);
+    i32x4 off = i32x4{kOOB, kOOB, kOOB, kOOB};
+    f32x4 w = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 aux = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (q < q_end) point_params<TR::ROWB>(rf.x + ox / (float)lt.y, rf.y + oy / (float)lt.x, a, lvl, g, off, w, aux);
+    const int slot = (qs * kHeads + h) * kHeadStride + s;
+    s_off[slot] = off;
+    s_wt[slot] = w * aux.z;
+  }
+}
+
+// ------------------------------------------------------------------ forward
+template <typename T, bool FUSED>
 __global__ __launch_bounds__(kWaves * 64) void msda_fwd_kernel(
     const T* __restrict__ value, const float* __restrict__ loc,
-    const float* __restrict__ attn, T* __restrict__ out, LevelGeom g, int Nv, int Nq,
-    int LP, int points, int qpb, int blocks_per_img) {
+    const float* __restrict__ attn, const T* __restrict__ both, const float* __restrict__ ref,
+    T* __restrict__ out, LevelGeom g, int Nv, int Nq, int LP, int points, int qpb,
+    int blocks_per_img) {
   using TR = Traits<T>;
   constexpr int SLOTS = TR::QPW * kHeads * kHeadStride;
   __shared__ i32x4 s_off_all[kWaves][SLOTS];
@@ -225,8 +265,10 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_kernel(
   const f32x4* my_wt = s_wt + (qs * kHeads + h) * kHeadStride;
 
   for (int q0 = q_begin + wave * TR::QPW; q0 < q_end; q0 += kWaves * TR::QPW) {
-    stage_points<T, false>(loc, attn, s_lvl, b, Nq, q0, q_end, LP, points, lane, s_off, s_wt,
-                           nullptr);
+    if constexpr (FUSED)
+      stage_points_fused<T>(both, ref, s_lvl, b, Nq, q0, q_end, LP / points, points, lane, s_off, s_wt);
+    else
+      stage_points<T, false>(loc, attn, s_lvl, b, Nq, q0, q_end, LP, points, lane, s_off, s_wt, nullptr);
     wave_lds_sync();
 
     float acc[TR::NACC];
@@ -968,12 +1010,41 @@ extern "C" int dskd_msda_fwd(const void* value, const int64_t* spatial_shapes,
   const dim3 grid((unsigned)(B * bpi)), block(kWaves * 64);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DSKD_DTYPE_F32)
-    hipLaunchKernelGGL(msda_fwd_kernel<float>, grid, block, 0, st, (const float*)value, loc,
-                       attn, (float*)out, g, Nv, Nq, levels * points, points, qpb, bpi);
+    hipLaunchKernelGGL((msda_fwd_kernel<float, false>), grid, block, 0, st, (const float*)value, loc, attn,
+                       (const float*)nullptr, (const float*)nullptr, (float*)out, g, Nv, Nq, levels * points,
+                       points, qpb, bpi);
   else
-    hipLaunchKernelGGL(msda_fwd_kernel<__bf16>, grid, block, 0, st, (const __bf16*)value, loc,
-                       attn, (__bf16*)out, g, Nv, Nq, levels * points, points, qpb, bpi);
+    hipLaunchKernelGGL((msda_fwd_kernel<__bf16, false>), grid, block, 0, st, (const __bf16*)value, loc, attn,
+                       (const __bf16*)nullptr, (const float*)nullptr, (__bf16*)out, g, Nv, Nq, levels * points,
+                       points, qpb, bpi);
   return check_launch("dskd_msda_fwd");
+}
+
+extern "C" int dskd_msda_fwd_fused(const void* value, const int64_t* spatial_shapes,
+                                   const int64_t* level_start, const void* both, const float* ref,
+                                   void* out, int B, int Nv, int Nq, int heads, int ch, int levels,
+                                   int points, int dtype, void* stream) {
+  if (int rc = check_shapes("dskd_msda_fwd_fused", B, Nv, Nq, heads, ch, levels, points, dtype)) return rc;
+  if (levels * points != 16)
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_msda_fwd_fused: needs levels*points == 16 (got %d x %d)", levels, points);
+  if (!value || !both || !ref || !out || !spatial_shapes || !level_start)
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_msda_fwd_fused: null pointer");
+  if (B == 0 || Nq == 0) return DSKD_OK;
+  LevelGeom g;
+  if (int rc = fill_geom(spatial_shapes, level_start, levels, Nv, &g)) return rc;
+  const int qpb = pick_qpb(B, Nq, dtype);
+  const int bpi = (Nq + qpb - 1) / qpb;
+  const dim3 grid((unsigned)(B * bpi)), block(kWaves * 64);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DSKD_DTYPE_F32)
+    hipLaunchKernelGGL((msda_fwd_kernel<float, true>), grid, block, 0, st, (const float*)value,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)both, ref, (float*)out, g, Nv,
+                       Nq, 16, points, qpb, bpi);
+  else
+    hipLaunchKernelGGL((msda_fwd_kernel<__bf16, true>), grid, block, 0, st, (const __bf16*)value,
+                       (const float*)nullptr, (const float*)nullptr, (const __bf16*)both, ref, (__bf16*)out, g,
+                       Nv, Nq, 16, points, qpb, bpi);
+  return check_launch("dskd_msda_fwd_fused");
 }
 
 extern "C" int dskd_msda_bwd(const void* value, const int64_t* spatial_shapes,

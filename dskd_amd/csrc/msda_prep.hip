@@ -19,25 +19,6 @@ struct PrepGeom {
   float W[kMaxLevels], H[kMaxLevels];
 };
 
-__device__ __forceinline__ float dpp_row_mirror(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
-}
-// reductions over an aligned group of 16 lanes (one DPP row); every lane gets the result
-__device__ __forceinline__ float row16_sum(float v) {
-  v += dpp_quad_xor1(v);
-  v += dpp_quad_xor2(v);
-  v += dpp_half_mirror(v);
-  v += dpp_row_mirror(v);
-  return v;
-}
-__device__ __forceinline__ float row16_max(float v) {
-  v = fmaxf(v, dpp_quad_xor1(v));
-  v = fmaxf(v, dpp_quad_xor2(v));
-  v = fmaxf(v, dpp_half_mirror(v));
-  v = fmaxf(v, dpp_row_mirror(v));
-  return v;
-}
-
 __device__ __forceinline__ float sel4(const float* a, int i) {
   // arithmetic select (no branches): levels <= 4
   const float m1 = i >= 1 ? 1.f : 0.f, m2 = i >= 2 ? 1.f : 0.f, m3 = i >= 3 ? 1.f : 0.f;

@@ -27,6 +27,7 @@ _SIGNATURES = {
     "dskd_last_error": (C.c_char_p, []),
     "dskd_device_count": (C.c_int, []),
     "dskd_msda_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [C.c_int] * 8 + [_vp]),
+    "dskd_msda_fwd_fused": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [C.c_int] * 8 + [_vp]),
     "dskd_msda_bwd": (C.c_int, [_vp] * 9 + [C.c_int] * 8 + [_vp]),
     "dskd_msda_prep_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_msda_prep_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
@@ -241,6 +242,29 @@ def ms_deform_attn(value: torch.Tensor, spatial_shapes: Sequence[Tuple[int, int]
         return f(value, spatial_shapes, sampling_locations, attention_weights)
     shapes = tuple((int(h), int(w)) for h, w in spatial_shapes)
     return _MSDAFunction.apply(value, sampling_locations, attention_weights, shapes)
+
+
+def ms_deform_attn_fused(value: torch.Tensor, spatial_shapes, both: torch.Tensor, reference_points: torch.Tensor,
+                         levels: int, points: int) -> torch.Tensor:
+    """No-gradient forward of the whole sampling step of the module: softmax + sampling locations
+    (:func:`msda_prepare`) folded into the sampling kernel, so loc / attn are never materialised.
+    value [B,Nv,heads,ch], both [B,Nq,heads*16*3] (same dtype), reference_points [B,Nq,levels,2].
+    Bit-identical to ``ms_deform_attn(value, shapes, *msda_prepare(...))``.  Raw op: no autograd."""
+    _need_gpu(value, both, reference_points)
+    B, Nv, heads, ch = value.shape
+    Nq = both.shape[1]
+    shapes = tuple((int(h), int(w)) for h, w in spatial_shapes)
+    ss, ls, _ = _geom(shapes)
+    dt = {torch.float32: DTYPE_F32, torch.bfloat16: DTYPE_BF16}[value.dtype]
+    value = value.contiguous()
+    both = both.contiguous().to(value.dtype)
+    ref = reference_points.detach().contiguous().float()
+    out = torch.empty((B, Nq, heads * ch), dtype=value.dtype, device=value.device)
+    with _timed("msda_fwd_enc" if Nq == Nv else "msda_fwd_dec"):
+        rc = load().dskd_msda_fwd_fused(value.data_ptr(), ss, ls, both.data_ptr(), ref.data_ptr(), out.data_ptr(), B, Nv, Nq,
+                                        heads, ch, levels, points, dt, _stream(value))
+    _check(rc, "dskd_msda_fwd_fused")
+    return out
 
 
 class _MSDAPrepFunction(torch.autograd.Function):

@@ -403,6 +403,12 @@ class MultiScaleDeformableAttention(nn.Module):
             w_cat = torch.cat([sw, ww], 0)
             b_cat = torch.cat([sb, wb], 0)
         both = tall_linear(query, w_cat, b_cat)
+        if value.is_cuda and reference_points.shape[-1] == 2 and self.num_levels * self.num_points == 16 \
+                and self.num_levels <= 4 and both.dtype == value.dtype and not (
+                    torch.is_grad_enabled() and (both.requires_grad or value.requires_grad or reference_points.requires_grad)):
+            # no gradients (frozen teacher, inference): prologue folded into the sampling kernel
+            output = native.ms_deform_attn_fused(value, shapes, both, reference_points, self.num_levels, self.num_points)
+            return self.output_proj(output)
         if reference_points.shape[-1] == 2 and self.num_levels * self.num_points == 16 and self.num_levels <= 4:
             # softmax + location arithmetic in one HIP pass each way (encoder and decoder)
             sampling_locations, attention_weights = native.msda_prepare(

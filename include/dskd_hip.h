@@ -90,6 +90,16 @@ int dskd_msda_fwd(const void* value, const int64_t* spatial_shapes,
                   void* out, int B, int Nv, int Nq, int heads, int ch, int levels,
                   int points, int dtype, void* stream);
 
+/* The same with the module's prologue folded in (no-gradient forward: frozen teacher, inference):
+ * `both` (device, [B*Nq, heads*16*3] same dtype as value: offsets [heads,16,2] then logits
+ * [heads,16], as for dskd_msda_prep_fwd) and `ref` (device, [B*Nq, levels, 2] f32) replace loc /
+ * attn, which are never materialised.  Bit-identical to dskd_msda_prep_fwd + dskd_msda_fwd.
+ * Requires levels*points == 16. */
+int dskd_msda_fwd_fused(const void* value, const int64_t* spatial_shapes,
+                        const int64_t* level_start, const void* both, const float* ref, void* out,
+                        int B, int Nv, int Nq, int heads, int ch, int levels, int points, int dtype,
+                        void* stream);
+
 /* Backward of the above.
  * grad_out    device, [B, Nq, heads*ch]  same dtype as value
  * grad_value  device, [B, Nv, heads, ch] f32, MUST be zeroed by the caller

@@ -196,6 +196,29 @@ def test_msda_prepare_vs_module_chain(dtype, oracle_checker):
     torch.testing.assert_close(rd.grad.cpu(), rc.grad, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Nq", [None, 301])          # None: encoder shape (queries == pixels)
+def test_msda_fused_prologue_is_bit_identical(dtype, Nq):
+    """No-grad forward with the module prologue folded in (dskd_msda_fwd_fused) against prologue
+    kernel + sampling kernel: identical bits, and close to the oracle chain."""
+    g = torch.Generator().manual_seed(23)
+    shapes = [(25, 42), (13, 21), (7, 11), (4, 6)]
+    Nv = sum(h * w for h, w in shapes)
+    B = 2
+    nq = Nv if Nq is None else Nq
+    value = torch.randn(B, Nv, 8, 32, generator=g).to(dtype).to(DEV)
+    both = (torch.randn(B, nq, 384, generator=g) * 2).to(dtype).to(DEV)
+    ref = torch.rand(B, nq, 4, 2, generator=g).to(DEV)
+    with torch.no_grad():
+        loc, attn = native.msda_prepare(both, ref, shapes, 8, 4, 4)
+        two = native.ms_deform_attn(value, shapes, loc, attn)
+        one = native.ms_deform_attn_fused(value, shapes, both, ref, 4, 4)
+    assert torch.equal(one, two)
+    want = msda_ref.msda_grid_sample(value.float().cpu(), shapes, loc.cpu(), attn.cpu())
+    tol = dict(atol=1e-5, rtol=1e-4) if dtype == torch.float32 else dict(atol=3e-2, rtol=2e-2)
+    torch.testing.assert_close(one.float().cpu(), want, **tol)
+
+
 # ----------------------------------------------------------------------------- add + dropout + LayerNorm
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("want_q", [False, True])
