@@ -54,6 +54,8 @@ def msda_algorithmic_bytes(kind, B, Nq, esz):
     """compulsory unique bytes of one launch (esz = value/out element
     size; loc 1024 B and attn 512 B per query are fp32)."""
     fwd = B * (NV * 256 * esz + Nq * 1024 + Nq * 512 + Nq * 256 * esz)
+    if kind == "fwd_fused":      # prologue folded in: the projection output (384 values) + reference points replace loc/attn
+        return B * (NV * 256 * esz + Nq * (384 * esz + 4 * 2 * 4) + Nq * 256 * esz)
     if kind == "fwd":
         return fwd
     # bwd = fwd - out + grad_out + grad_value(fp32) + grad_loc + grad_attn
@@ -318,8 +320,8 @@ def main():
         esz = 2 if args.dtype == "bf16" else 4
         kernels = {}
         for tag, (n, ms) in kt.items():
-            kind = "fwd" if "fwd" in tag else "bwd"
-            nq = NV if tag.endswith("enc") else 300
+            kind = "fwd_fused" if tag.endswith("_fused") else ("fwd" if "fwd" in tag else "bwd")
+            nq = NV if "enc" in tag else 300
             byts = msda_algorithmic_bytes(kind, args.batch, nq, esz)
             avg_ms = ms / max(n, 1)
             kernels[tag] = {"launches": n, "avg_us": round(avg_ms * 1e3, 2), "algorithmic_MB": round(byts / 1e6, 2),

@@ -260,7 +260,7 @@ def ms_deform_attn_fused(value: torch.Tensor, spatial_shapes, both: torch.Tensor
     both = both.contiguous().to(value.dtype)
     ref = reference_points.detach().contiguous().float()
     out = torch.empty((B, Nq, heads * ch), dtype=value.dtype, device=value.device)
-    with _timed("msda_fwd_enc" if Nq == Nv else "msda_fwd_dec"):
+    with _timed("msda_fwd_enc_fused" if Nq == Nv else "msda_fwd_dec_fused"):
         rc = load().dskd_msda_fwd_fused(value.data_ptr(), ss, ls, both.data_ptr(), ref.data_ptr(), out.data_ptr(), B, Nv, Nq,
                                         heads, ch, levels, points, dt, _stream(value))
     _check(rc, "dskd_msda_fwd_fused")
