@@ -241,39 +241,45 @@ class ResNet(nn.Module):
                 p.requires_grad = False
 
     def _conv_bn_pairs(self):
-        pairs = [(self.conv1, self.bn1)]
-        for name in self.res_layers:
+        """[(conv, bn, stage)]: stage 0 = stem, 1.. = res layers."""
+        pairs = [(self.conv1, self.bn1, 0)]
+        for si, name in enumerate(self.res_layers):
             for blk in getattr(self, name):
-                pairs.append((blk.conv1, blk.bn1))
-                pairs.append((blk.conv2, blk.bn2))
+                pairs.append((blk.conv1, blk.bn1, si + 1))
+                pairs.append((blk.conv2, blk.bn2, si + 1))
                 if hasattr(blk, "conv3"):
-                    pairs.append((blk.conv3, blk.bn3))
+                    pairs.append((blk.conv3, blk.bn3, si + 1))
                 if blk.downsample is not None:
-                    pairs.append((blk.downsample[0], blk.downsample[1]))
+                    pairs.append((blk.downsample[0], blk.downsample[1], si + 1))
         return pairs
 
     def _fold_trainable(self, x):
         """Folded (weight, bias) of every conv whose weight trains while its BN is frozen
         (stages 2-4 of the student), for this forward, in a handful of launches."""
-        pairs = [(c, b) for c, b in self._conv_bn_pairs()
+        pairs = [(c, b, st) for c, b, st in self._conv_bn_pairs()
                  if c.weight.requires_grad and not b.training and not b.weight.requires_grad and c.bias is None]
         if not pairs or not torch.is_grad_enabled():
             return []
         dtype = torch.get_autocast_dtype(x.device.type) if torch.is_autocast_enabled(x.device.type) else x.dtype
-        key = (tuple(b.running_var._version for _, b in pairs), dtype, x.device)
+        key = (tuple(b.running_var._version for _, b, _ in pairs), dtype, x.device)
         if getattr(self, "_fold_key", None) != key:      # BN statistics are frozen: constants
             scales, biases = [], []
             with torch.no_grad():
-                for c, b in pairs:
+                for c, b, _ in pairs:
                     sc = b.weight * torch.rsqrt(b.running_var + b.eps)
                     scales.append(sc.view(-1, 1, 1, 1).expand_as(c.weight).contiguous())
                     biases.append((b.bias - b.running_mean * sc).to(dtype))
             self._fold_key, self._fold_const = key, (scales, biases)
         scales, biases = self._fold_const
-        ws = _FoldTrainable.apply(scales, dtype, *[c.weight for c, _ in pairs])
-        for (c, _), w, bias in zip(pairs, ws, biases):
-            c.__dict__["_folded_live"] = (w, bias)
-        return [c for c, _ in pairs]
+        # One fold per stage: its backward hands the stage's weight gradients over as soon as that
+        # stage's backward is done (layer4 first: 2/3 of the backbone's parameters), so DDP can
+        # all-reduce them while the earlier stages still run their backward.
+        for st in sorted({p[2] for p in pairs}):
+            idx = [i for i, p in enumerate(pairs) if p[2] == st]
+            ws = _FoldTrainable.apply([scales[i] for i in idx], dtype, *[pairs[i][0].weight for i in idx])
+            for i, w in zip(idx, ws):
+                pairs[i][0].__dict__["_folded_live"] = (w, biases[i])
+        return [c for c, _, _ in pairs]
 
     def forward(self, x):
         live = self._fold_trainable(x)
