@@ -84,6 +84,7 @@ class _FoldTrainable(torch.autograd.Function):
     @staticmethod
     def forward(ctx, scales, dtype, *weights):
         ctx.scales, ctx.wdtype = scales, weights[0].dtype
+        ctx.pstrides = [w.stride() for w in weights]
         prod = torch._foreach_mul(list(weights), scales)
         if dtype == ctx.wdtype:
             return tuple(prod)
@@ -98,7 +99,12 @@ class _FoldTrainable(torch.autograd.Function):
             up = [torch.empty_like(g, dtype=ctx.wdtype) for g in gs]
             torch._foreach_copy_(up, gs)
             gs = up
-        return (None, None) + tuple(torch._foreach_mul(gs, ctx.scales))
+        outs = torch._foreach_mul(gs, ctx.scales)
+        # 1x1 kernels: [Cin, 1, 1, 1] and the parameter's channels_last [Cin, 1, Cin, Cin] describe the
+        # same memory; hand DDP the parameter's strides so it does not copy into its bucket view
+        outs = [o.as_strided(o.shape, st) if (o.stride() != st and o.shape[2:] == (1, 1)) else o
+                for o, st in zip(outs, ctx.pstrides)]
+        return (None, None) + tuple(outs)
 
 
 def _bn(ch, requires_grad):
