@@ -58,6 +58,13 @@ __device__ __forceinline__ float group8_sum(float v) {
   return v;
 }
 
+__device__ __forceinline__ float group8_max(float v) {
+  v = fmaxf(v, dpp_quad_xor1(v));
+  v = fmaxf(v, dpp_quad_xor2(v));
+  v = fmaxf(v, dpp_half_mirror(v));
+  return v;
+}
+
 __device__ __forceinline__ float dpp_row_mirror(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
 }

@@ -38,7 +38,6 @@ constexpr int kCh = 32;
 constexpr int kWaves = 4;       // waves per workgroup
 constexpr int kMaxLevels = 4;
 constexpr int kMaxLP = 16;      // levels * points
-constexpr int kHeadStride = 17; // LDS slots per head: 16 samples + 1 pad (bank spread)
 constexpr int kOOB = 0x7F000000;  // byte offset beyond every descriptor range
 
 struct LevelGeom {
@@ -153,33 +152,51 @@ __device__ __forceinline__ void load_vals(__amdgpu_buffer_rsrc_t rsrc, int voff,
 }
 
 // Cooperative parameter pass shared by forward and backward.
-template <typename T, bool WITH_AUX>
+//
+// PH > 1: the samples of a query are staged and consumed in PH phases of LP / PH samples per head
+// (phase ``ph`` holds samples [ph * LP/PH, (ph+1) * LP/PH)), so a wave's LDS slice shrinks by PH.
+// With two bf16 queries per wave the single-phase slices (34.9 KB per workgroup forward, 52.3 KB
+// backward) cap the CU at 4 / 3 waves per SIMD although the kernels need only 64 VGPRs; the
+// gathers are latency-bound, so resident waves are what hides them.  The accumulation order over
+// the samples does not change: results are bit-identical for every PH.
+// Head stride in 16-byte slots: LP/PH samples + 1 pad -> 17 / 9 / 5, which keeps the 16 (query,
+// head) groups of a wave on distinct LDS banks for the broadcast ds_read_b128 of the consumer.
+template <int PH>
+struct Phased {
+  static_assert(PH == 1 || PH == 2 || PH == 4, "phases");
+  static constexpr int HS = kMaxLP / PH + 1;
+};
+
+template <typename T, bool WITH_AUX, int PH, bool KEEP_WT>
 __device__ __forceinline__ void stage_points(const float* __restrict__ loc,
                                              const float* __restrict__ attn,
                                              const i32x4* g, int b, int Nq, int q0,
-                                             int q_end, int LP, int points, int lane,
+                                             int q_end, int LP, int points, int ph, int lane,
                                              i32x4* s_off, f32x4* s_wt, f32x4* s_aux) {
   using TR = Traits<T>;
-  const int npts = TR::QPW * kHeads * LP;
+  constexpr int HS = Phased<PH>::HS;
+  const int LPS = LP / PH;                 // samples per head in this phase
+  const int npts = TR::QPW * kHeads * LPS;
   for (int pi = lane; pi < npts; pi += 64) {
-    const int qs = pi / (kHeads * LP);
-    const int r = pi - qs * (kHeads * LP);
-    const int h = r / LP;
-    const int s = r - h * LP;
+    const int qs = pi / (kHeads * LPS);
+    const int r = pi - qs * (kHeads * LPS);
+    const int h = r / LPS;
+    const int sl = r - h * LPS;
+    const int s = ph * LPS + sl;
     const int q = q0 + qs;
     i32x4 off = i32x4{kOOB, kOOB, kOOB, kOOB};
     f32x4 w = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 aux = f32x4{0.f, 0.f, 0.f, 0.f};
     if (q < q_end) {
-      const size_t base = ((size_t)b * Nq + q) * (size_t)(kHeads * LP) + r;
+      const size_t base = ((size_t)b * Nq + q) * (size_t)(kHeads * LP) + h * LP + s;
       const f32x2 xy = *reinterpret_cast<const f32x2*>(loc + base * 2);
       const float a = attn[base];
       point_params<TR::ROWB>(xy.x, xy.y, a, s / points, g, off, w, aux);
     }
-    const int slot = (qs * kHeads + h) * kHeadStride + s;
+    const int slot = (qs * kHeads + h) * HS + sl;
     s_off[slot] = off;
     if constexpr (WITH_AUX) {
-      s_wt[slot] = w;  // raw bilinear weights; attn lives in aux.z
+      if constexpr (KEEP_WT) s_wt[slot] = w;  // raw bilinear weights; attn lives in aux.z
       s_aux[slot] = aux;
     } else {
       s_wt[slot] = w * aux.z;  // attn folded in
@@ -193,26 +210,41 @@ __device__ __forceinline__ void stage_points(const float* __restrict__ loc,
 // softmax over the 16 (level, point) logits of a head with DPP row reductions, loc = ref + off /
 // (W, H) -- with the arithmetic of msda_prep.hip, so the result is bit-identical to prologue
 // kernel + sampling kernel while loc / attn (1.5 KB per query, f32) are never written or read.
-template <typename T>
+// PH == 2: 8 consecutive lanes hold one half of a head's 16 points and fetch the other half's logit
+// as well; max is exact, and the sum is formed as (own half) + (other half) with the same three
+// DPP steps per half as row16_sum's first three, i.e. the same additions in the same order.
+template <typename T, int PH>
 __device__ __forceinline__ void stage_points_fused(const T* __restrict__ both, const float* __restrict__ ref,
                                                    const i32x4* g, int b, int Nq, int q0, int q_end,
-                                                   int levels, int points, int lane, i32x4* s_off,
+                                                   int levels, int points, int ph, int lane, i32x4* s_off,
                                                    f32x4* s_wt) {
+  static_assert(PH == 1 || PH == 2, "fused prologue: one or two phases");
   using TR = Traits<T>;
+  constexpr int HS = Phased<PH>::HS;
   constexpr int PQ = kHeads * 16;                  // points per query (levels * points == 16)
-  const int npts = TR::QPW * PQ;
-  for (int pi = lane; pi < npts; pi += 64) {       // 16 consecutive lanes = the 16 points of one (query, head)
-    const int qs = pi / PQ;
-    const int r = pi - qs * PQ;
-    const int h = r >> 4, s = r & 15;
+  constexpr int LPS = 16 / PH;
+  constexpr int npts = TR::QPW * kHeads * LPS;
+  for (int pi = lane; pi < npts; pi += 64) {       // 16 / PH consecutive lanes = the staged points of one (query, head)
+    const int qs = pi / (kHeads * LPS);
+    const int rr = pi - qs * (kHeads * LPS);
+    const int h = rr / LPS, s = ph * LPS + (rr - h * LPS);
+    const int r = h * 16 + s;
     const int q = q0 + qs;
     const int qc = q < q_end ? q : q_end - 1;
     const T* row = both + ((size_t)b * Nq + qc) * (size_t)(PQ * 3);
     const float ox = (float)row[r * 2], oy = (float)row[r * 2 + 1];
     const float lg = (float)row[PQ * 2 + r];
-    const float mx = row16_max(lg);
-    const float e = __expf(lg - mx);
-    const float a = e / row16_sum(e);
+    float a;
+    if constexpr (PH == 1) {
+      const float mx = row16_max(lg);
+      const float e = __expf(lg - mx);
+      a = e / row16_sum(e);
+    } else {
+      const float lg2 = (float)row[PQ * 2 + (r ^ 8)];
+      const float mx = group8_max(fmaxf(lg, lg2));
+      const float e = __expf(lg - mx), e2 = __expf(lg2 - mx);
+      a = e / (group8_sum(e) + group8_sum(e2));
+    }
     const int lvl = s / points;
     const i32x4 lt = g[lvl];                        // {H, W, start, 0}
     const f32x2 rf = *reinterpret_cast<const f32x2*>(ref + (((size_t)b * Nq + qc) * levels + lvl) * 2);
@@ -220,21 +252,22 @@ __device__ __forceinline__ void stage_points_fused(const T* __restrict__ both, c
     f32x4 w = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 aux = f32x4{0.f, 0.f, 0.f, 0.f};
     if (q < q_end) point_params<TR::ROWB>(rf.x + ox / (float)lt.y, rf.y + oy / (float)lt.x, a, lvl, g, off, w, aux);
-    const int slot = (qs * kHeads + h) * kHeadStride + s;
+    const int slot = (qs * kHeads + h) * HS + (s - ph * LPS);
     s_off[slot] = off;
     s_wt[slot] = w * aux.z;
   }
 }
 
 // ------------------------------------------------------------------ forward
-template <typename T, bool FUSED>
+template <typename T, bool FUSED, int PH>
 __global__ __launch_bounds__(kWaves * 64) void msda_fwd_kernel(
     const T* __restrict__ value, const float* __restrict__ loc,
     const float* __restrict__ attn, const T* __restrict__ both, const float* __restrict__ ref,
     T* __restrict__ out, LevelGeom g, int Nv, int Nq, int LP, int points, int qpb,
     int blocks_per_img) {
   using TR = Traits<T>;
-  constexpr int SLOTS = TR::QPW * kHeads * kHeadStride;
+  constexpr int HS = Phased<PH>::HS;
+  constexpr int SLOTS = TR::QPW * kHeads * HS;
   __shared__ i32x4 s_off_all[kWaves][SLOTS];
   __shared__ f32x4 s_wt_all[kWaves][SLOTS];
   __shared__ i32x4 s_lvl[kMaxLevels];
@@ -261,36 +294,42 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_kernel(
   const int h = (lane / TR::LPH) & (kHeads - 1);
   const int part = lane & (TR::LPH - 1);
   const int hb = h * (kCh * (int)sizeof(T)) + part * 16;
-  const i32x4* my_off = s_off + (qs * kHeads + h) * kHeadStride;
-  const f32x4* my_wt = s_wt + (qs * kHeads + h) * kHeadStride;
+  const i32x4* my_off = s_off + (qs * kHeads + h) * HS;
+  const f32x4* my_wt = s_wt + (qs * kHeads + h) * HS;
+  const int LPS = LP / PH;      // samples per head and phase
 
   for (int q0 = q_begin + wave * TR::QPW; q0 < q_end; q0 += kWaves * TR::QPW) {
-    if constexpr (FUSED)
-      stage_points_fused<T>(both, ref, s_lvl, b, Nq, q0, q_end, LP / points, points, lane, s_off, s_wt);
-    else
-      stage_points<T, false>(loc, attn, s_lvl, b, Nq, q0, q_end, LP, points, lane, s_off, s_wt, nullptr);
-    wave_lds_sync();
-
     float acc[TR::NACC];
 #pragma unroll
     for (int i = 0; i < TR::NACC; ++i) acc[i] = 0.f;
 
+#pragma unroll 1
+    for (int ph = 0; ph < PH; ++ph) {
+      if constexpr (FUSED)
+        stage_points_fused<T, PH>(both, ref, s_lvl, b, Nq, q0, q_end, LP / points, points, ph, lane, s_off, s_wt);
+      else
+        stage_points<T, false, PH, true>(loc, attn, s_lvl, b, Nq, q0, q_end, LP, points, ph, lane, s_off, s_wt,
+                                         nullptr);
+      wave_lds_sync();
+
 #pragma unroll 4
-    for (int s = 0; s < LP; ++s) {
-      const i32x4 o = my_off[s];
-      const f32x4 w = my_wt[s];
-      float v0[TR::NACC], v1[TR::NACC], v2[TR::NACC], v3[TR::NACC];
-      load_vals<T>(rsrc, o.x + hb, v0);
-      load_vals<T>(rsrc, o.y + hb, v1);
-      load_vals<T>(rsrc, o.z + hb, v2);
-      load_vals<T>(rsrc, o.w + hb, v3);
+      for (int s = 0; s < LPS; ++s) {
+        const i32x4 o = my_off[s];
+        const f32x4 w = my_wt[s];
+        float v0[TR::NACC], v1[TR::NACC], v2[TR::NACC], v3[TR::NACC];
+        load_vals<T>(rsrc, o.x + hb, v0);
+        load_vals<T>(rsrc, o.y + hb, v1);
+        load_vals<T>(rsrc, o.z + hb, v2);
+        load_vals<T>(rsrc, o.w + hb, v3);
 #pragma unroll
-      for (int i = 0; i < TR::NACC; ++i) {
-        acc[i] = fmaf(w.x, v0[i], acc[i]);
-        acc[i] = fmaf(w.y, v1[i], acc[i]);
-        acc[i] = fmaf(w.z, v2[i], acc[i]);
-        acc[i] = fmaf(w.w, v3[i], acc[i]);
+        for (int i = 0; i < TR::NACC; ++i) {
+          acc[i] = fmaf(w.x, v0[i], acc[i]);
+          acc[i] = fmaf(w.y, v1[i], acc[i]);
+          acc[i] = fmaf(w.z, v2[i], acc[i]);
+          acc[i] = fmaf(w.w, v3[i], acc[i]);
+        }
       }
+      wave_lds_sync();  // the next staging pass overwrites this wave's LDS slice
     }
 
     const int q = q0 + qs;
@@ -307,22 +346,29 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_kernel(
         *reinterpret_cast<u32x4*>(orow + part * 8) = p;
       }
     }
-    wave_lds_sync();  // the next pass overwrites this wave's LDS slice
   }
 }
 
 // ------------------------------------------------------------------ backward
-template <typename T, bool WITH_VALUE>
+// PH > 1 (grad_loc / grad_attn only, i.e. !WITH_VALUE): phased staging as in the forward; the raw
+// bilinear weights are then not parked in LDS at all -- the one lane per group that finishes a
+// sample recomputes them from (lx, ly) with the same multiplications (for a rejected location
+// they are (1,0,0,0) instead of zeros, against dot products that are exactly zero) -- and every
+// phase writes its finished gradients out as coalesced runs of LP/PH points per (query, head).
+template <typename T, bool WITH_VALUE, int PH>
 __global__ __launch_bounds__(kWaves * 64) void msda_bwd_kernel(
     const T* __restrict__ value, const float* __restrict__ loc,
     const float* __restrict__ attn, const T* __restrict__ grad_out,
     float* __restrict__ grad_value, float* __restrict__ grad_loc,
     float* __restrict__ grad_attn, LevelGeom g, int Nv, int Nq, int LP, int points,
     int qpb, int blocks_per_img) {
+  static_assert(PH == 1 || !WITH_VALUE, "the scatter phase needs every sample of the query staged");
   using TR = Traits<T>;
-  constexpr int SLOTS = TR::QPW * kHeads * kHeadStride;
+  constexpr bool KEEP_WT = (PH == 1);
+  constexpr int HS = Phased<PH>::HS;
+  constexpr int SLOTS = TR::QPW * kHeads * HS;
   __shared__ i32x4 s_off_all[kWaves][SLOTS];
-  __shared__ f32x4 s_wt_all[kWaves][SLOTS];
+  __shared__ f32x4 s_wt_all[kWaves][KEEP_WT ? SLOTS : 1];
   __shared__ f32x4 s_aux_all[kWaves][SLOTS];
   __shared__ i32x4 s_lvl[kMaxLevels];
   fill_level_table(s_lvl, g);
@@ -349,13 +395,10 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_kernel(
   const int h = (lane / TR::LPH) & (kHeads - 1);
   const int part = lane & (TR::LPH - 1);
   const int hb = h * (kCh * (int)sizeof(T)) + part * 16;
-  const int myslot = (qs * kHeads + h) * kHeadStride;
+  const int myslot = (qs * kHeads + h) * HS;
+  const int LPS = LP / PH;      // samples per head and phase
 
   for (int q0 = q_begin + wave * TR::QPW; q0 < q_end; q0 += kWaves * TR::QPW) {
-    stage_points<T, true>(loc, attn, s_lvl, b, Nq, q0, q_end, LP, points, lane, s_off, s_wt,
-                          s_aux);
-    wave_lds_sync();
-
     // ---- phase A: grad_attn / grad_loc.  Lane = (query slot, head, 16-B part).
     const int q = q0 + qs;
     const bool qv = q < q_end;
@@ -371,99 +414,107 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_kernel(
         unpack_bf16x8(t, go);
       }
     }
-    for (int s = 0; s < LP; ++s) {
-      const i32x4 o = s_off[myslot + s];
-      const f32x4 w = s_wt[myslot + s];
-      const f32x4 ax = s_aux[myslot + s];
-      float v0[TR::NACC], v1[TR::NACC], v2[TR::NACC], v3[TR::NACC];
-      load_vals<T>(rsrc, o.x + hb, v0);
-      load_vals<T>(rsrc, o.y + hb, v1);
-      load_vals<T>(rsrc, o.z + hb, v2);
-      load_vals<T>(rsrc, o.w + hb, v3);
-      float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll 1
+    for (int ph = 0; ph < PH; ++ph) {
+      stage_points<T, true, PH, KEEP_WT>(loc, attn, s_lvl, b, Nq, q0, q_end, LP, points, ph, lane, s_off, s_wt,
+                                         s_aux);
+      wave_lds_sync();
+      for (int s = 0; s < LPS; ++s) {
+        const i32x4 o = s_off[myslot + s];
+        const f32x4 ax = s_aux[myslot + s];
+        float v0[TR::NACC], v1[TR::NACC], v2[TR::NACC], v3[TR::NACC];
+        load_vals<T>(rsrc, o.x + hb, v0);
+        load_vals<T>(rsrc, o.y + hb, v1);
+        load_vals<T>(rsrc, o.z + hb, v2);
+        load_vals<T>(rsrc, o.w + hb, v3);
+        float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
 #pragma unroll
-      for (int i = 0; i < TR::NACC; ++i) {
-        d0 = fmaf(v0[i], go[i], d0);
-        d1 = fmaf(v1[i], go[i], d1);
-        d2 = fmaf(v2[i], go[i], d2);
-        d3 = fmaf(v3[i], go[i], d3);
-      }
-      if constexpr (TR::LPH == 8) {
-        d0 = group8_sum(d0); d1 = group8_sum(d1); d2 = group8_sum(d2); d3 = group8_sum(d3);
-      } else {
-        d0 = group4_sum(d0); d1 = group4_sum(d1); d2 = group4_sum(d2); d3 = group4_sum(d3);
-      }
-      // One lane of the group finishes this sample's gradients and parks them in the sample's
-      // (now dead) aux slot; they leave for HBM after the loop as coalesced rows.  Per-lane
-      // 4-/8-byte stores from here measured 3.9x write amplification (WRITE_SIZE 525 MB for
-      // 136 MB of gradients at B=4).
-      if (part == (s & (TR::LPH - 1))) {
-        const float lx = ax.x, ly = ax.y, a = ax.z;
-        const int lvl = (int)ax.w;
-        const i32x4 lt = s_lvl[lvl];
-        const float Wf = (float)lt.y, Hf = (float)lt.x;
-        const float hx = 1.f - lx, hy = 1.f - ly;
-        const float ga = w.x * d0 + w.y * d1 + w.z * d2 + w.w * d3;
-        const float gx = Wf * a * (hy * (d1 - d0) + ly * (d3 - d2));
-        const float gy = Hf * a * (hx * (d2 - d0) + lx * (d3 - d1));
-        s_aux[myslot + s] = f32x4{gx, gy, a, ga};   // .z (attn) stays for the scatter phase
-      }
-    }
-    wave_lds_sync();
-    {
-      const int npts = TR::QPW * kHeads * LP;
-      for (int pi = lane; pi < npts; pi += 64) {
-        const int qs2 = pi / (kHeads * LP);
-        const int r = pi - qs2 * (kHeads * LP);
-        const int h2 = r / LP;
-        const int q2 = q0 + qs2;
-        if (q2 < q_end) {
-          const f32x4 res = s_aux[(qs2 * kHeads + h2) * kHeadStride + (r - h2 * LP)];
-          const size_t base = ((size_t)b * Nq + q2) * (size_t)(kHeads * LP) + r;
-          grad_attn[base] = res.w;
-          *reinterpret_cast<f32x2*>(grad_loc + base * 2) = f32x2{res.x, res.y};
+        for (int i = 0; i < TR::NACC; ++i) {
+          d0 = fmaf(v0[i], go[i], d0);
+          d1 = fmaf(v1[i], go[i], d1);
+          d2 = fmaf(v2[i], go[i], d2);
+          d3 = fmaf(v3[i], go[i], d3);
+        }
+        if constexpr (TR::LPH == 8) {
+          d0 = group8_sum(d0); d1 = group8_sum(d1); d2 = group8_sum(d2); d3 = group8_sum(d3);
+        } else {
+          d0 = group4_sum(d0); d1 = group4_sum(d1); d2 = group4_sum(d2); d3 = group4_sum(d3);
+        }
+        // One lane of the group finishes this sample's gradients and parks them in the sample's
+        // (now dead) aux slot; they leave for HBM after the loop as coalesced rows.  Per-lane
+        // 4-/8-byte stores from here measured 3.9x write amplification (WRITE_SIZE 525 MB for
+        // 136 MB of gradients at B=4).
+        if (part == (s & (TR::LPH - 1))) {
+          const float lx = ax.x, ly = ax.y, a = ax.z;
+          const int lvl = (int)ax.w;
+          const i32x4 lt = s_lvl[lvl];
+          const float Wf = (float)lt.y, Hf = (float)lt.x;
+          const float hx = 1.f - lx, hy = 1.f - ly;
+          f32x4 w;
+          if constexpr (KEEP_WT) w = s_wt[myslot + s];
+          else w = f32x4{hy * hx, hy * lx, ly * hx, ly * lx};
+          const float ga = w.x * d0 + w.y * d1 + w.z * d2 + w.w * d3;
+          const float gx = Wf * a * (hy * (d1 - d0) + ly * (d3 - d2));
+          const float gy = Hf * a * (hx * (d2 - d0) + lx * (d3 - d1));
+          s_aux[myslot + s] = f32x4{gx, gy, a, ga};   // .z (attn) stays for the scatter phase
         }
       }
+      wave_lds_sync();
+      {
+        const int npts = TR::QPW * kHeads * LPS;
+        for (int pi = lane; pi < npts; pi += 64) {
+          const int qs2 = pi / (kHeads * LPS);
+          const int r = pi - qs2 * (kHeads * LPS);
+          const int h2 = r / LPS;
+          const int sl = r - h2 * LPS;
+          const int q2 = q0 + qs2;
+          if (q2 < q_end) {
+            const f32x4 res = s_aux[(qs2 * kHeads + h2) * HS + sl];
+            const size_t base = ((size_t)b * Nq + q2) * (size_t)(kHeads * LP) + h2 * LP + ph * LPS + sl;
+            grad_attn[base] = res.w;
+            *reinterpret_cast<f32x2*>(grad_loc + base * 2) = f32x2{res.x, res.y};
+          }
+        }
+      }
+      if constexpr (!WITH_VALUE) wave_lds_sync();   // the next staging pass overwrites the slice
     }
 
-    if constexpr (!WITH_VALUE) {
-      wave_lds_sync();
-      continue;
-    }
-    // ---- phase B: grad_value scatter.  Lane = (corner parity, channel): one wave
-    // instruction adds two complete 128-B head lines.
-    const int ch = lane & 31;
-    const int cpar = lane >> 5;
+    if constexpr (WITH_VALUE) {
+      // ---- phase B: grad_value scatter.  Lane = (corner parity, channel): one wave
+      // instruction adds two complete 128-B head lines.
+      const int ch = lane & 31;
+      const int cpar = lane >> 5;
 #pragma unroll 1
-    for (int qq = 0; qq < TR::QPW; ++qq) {
-      const int q2 = q0 + qq;
-      if (q2 >= q_end) break;
-      const T* grow = grad_out + ((size_t)b * Nq + q2) * (kHeads * kCh);
-      float gch[kHeads];
+      for (int qq = 0; qq < TR::QPW; ++qq) {
+        const int q2 = q0 + qq;
+        if (q2 >= q_end) break;
+        const T* grow = grad_out + ((size_t)b * Nq + q2) * (kHeads * kCh);
+        float gch[kHeads];
 #pragma unroll
-      for (int hh = 0; hh < kHeads; ++hh) gch[hh] = (float)grow[hh * kCh + ch];
+        for (int hh = 0; hh < kHeads; ++hh) gch[hh] = (float)grow[hh * kCh + ch];
 #pragma unroll
-      for (int hh = 0; hh < kHeads; ++hh) {
-        const int slot = (qq * kHeads + hh) * kHeadStride;
-        const int hoff = hh * kCh + ch;
-        for (int s = 0; s < LP; ++s) {
-          const i32x4 o = s_off[slot + s];
-          const f32x4 w = s_wt[slot + s];
-          const float a = s_aux[slot + s].z;
-          const float ga = a * gch[hh];
-          // corners (0,1) then (2,3); each half-wave takes one corner
-          const int oa = cpar ? o.y : o.x;
-          const float wa = cpar ? w.y : w.x;
-          const int ob = cpar ? o.w : o.z;
-          const float wb = cpar ? w.w : w.z;
-          if (oa != kOOB)
-            atomicAdd(gvb + (size_t)(oa / TR::ROWB) * (kHeads * kCh) + hoff, wa * ga);
-          if (ob != kOOB)
-            atomicAdd(gvb + (size_t)(ob / TR::ROWB) * (kHeads * kCh) + hoff, wb * ga);
+        for (int hh = 0; hh < kHeads; ++hh) {
+          const int slot = (qq * kHeads + hh) * HS;
+          const int hoff = hh * kCh + ch;
+          for (int s = 0; s < LP; ++s) {
+            const i32x4 o = s_off[slot + s];
+            const f32x4 w = s_wt[slot + s];
+            const float a = s_aux[slot + s].z;
+            const float ga = a * gch[hh];
+            // corners (0,1) then (2,3); each half-wave takes one corner
+            const int oa = cpar ? o.y : o.x;
+            const float wa = cpar ? w.y : w.x;
+            const int ob = cpar ? o.w : o.z;
+            const float wb = cpar ? w.w : w.z;
+            if (oa != kOOB)
+              atomicAdd(gvb + (size_t)(oa / TR::ROWB) * (kHeads * kCh) + hoff, wa * ga);
+            if (ob != kOOB)
+              atomicAdd(gvb + (size_t)(ob / TR::ROWB) * (kHeads * kCh) + hoff, wb * ga);
+          }
         }
       }
+      wave_lds_sync();
     }
-    wave_lds_sync();
   }
 }
 
@@ -989,6 +1040,22 @@ inline int pick_qpb(int B, int Nq, int dtype) {
   return qpb < min_qpb ? min_qpb : qpb;
 }
 
+// Staging phases of the bf16 gather kernels (stage_points): two bf16 queries per wave make the
+// single-phase LDS slices the occupancy limit.  DSKD_MSDA_PHASES=1|2|4 overrides the default (A/B
+// tests; results are bit-identical for every value).  f32 keeps one phase (one query per wave).
+constexpr int kDefaultPhases = 1;
+inline int pick_phases(int LP, int dtype, int max_ph) {
+  if (dtype != DSKD_DTYPE_BF16) return 1;
+  int ph = kDefaultPhases;
+  if (const char* e = getenv("DSKD_MSDA_PHASES")) {
+    const int v = atoi(e);
+    if (v == 1 || v == 2 || v == 4) ph = v;
+  }
+  if (ph > max_ph) ph = max_ph;
+  while (ph > 1 && LP % ph != 0) ph >>= 1;
+  return ph;
+}
+
 }  // namespace
 }  // namespace dskd
 
@@ -1009,14 +1076,22 @@ extern "C" int dskd_msda_fwd(const void* value, const int64_t* spatial_shapes,
   const int bpi = (Nq + qpb - 1) / qpb;
   const dim3 grid((unsigned)(B * bpi)), block(kWaves * 64);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == DSKD_DTYPE_F32)
-    hipLaunchKernelGGL((msda_fwd_kernel<float, false>), grid, block, 0, st, (const float*)value, loc, attn,
+  if (dtype == DSKD_DTYPE_F32) {
+    hipLaunchKernelGGL((msda_fwd_kernel<float, false, 1>), grid, block, 0, st, (const float*)value, loc, attn,
                        (const float*)nullptr, (const float*)nullptr, (float*)out, g, Nv, Nq, levels * points,
                        points, qpb, bpi);
-  else
-    hipLaunchKernelGGL((msda_fwd_kernel<__bf16, false>), grid, block, 0, st, (const __bf16*)value, loc, attn,
-                       (const __bf16*)nullptr, (const float*)nullptr, (__bf16*)out, g, Nv, Nq, levels * points,
-                       points, qpb, bpi);
+  } else {
+#define DSKD_FWD_BF16(PH)                                                                                       \
+  hipLaunchKernelGGL((msda_fwd_kernel<__bf16, false, PH>), grid, block, 0, st, (const __bf16*)value, loc, attn, \
+                     (const __bf16*)nullptr, (const float*)nullptr, (__bf16*)out, g, Nv, Nq, levels * points,   \
+                     points, qpb, bpi)
+    switch (pick_phases(levels * points, dtype, 4)) {
+      case 4: DSKD_FWD_BF16(4); break;
+      case 2: DSKD_FWD_BF16(2); break;
+      default: DSKD_FWD_BF16(1); break;
+    }
+#undef DSKD_FWD_BF16
+  }
   return check_launch("dskd_msda_fwd");
 }
 
@@ -1037,11 +1112,15 @@ extern "C" int dskd_msda_fwd_fused(const void* value, const int64_t* spatial_sha
   const dim3 grid((unsigned)(B * bpi)), block(kWaves * 64);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DSKD_DTYPE_F32)
-    hipLaunchKernelGGL((msda_fwd_kernel<float, true>), grid, block, 0, st, (const float*)value,
+    hipLaunchKernelGGL((msda_fwd_kernel<float, true, 1>), grid, block, 0, st, (const float*)value,
                        (const float*)nullptr, (const float*)nullptr, (const float*)both, ref, (float*)out, g, Nv,
                        Nq, 16, points, qpb, bpi);
+  else if (pick_phases(16, dtype, 2) == 2)
+    hipLaunchKernelGGL((msda_fwd_kernel<__bf16, true, 2>), grid, block, 0, st, (const __bf16*)value,
+                       (const float*)nullptr, (const float*)nullptr, (const __bf16*)both, ref, (__bf16*)out, g,
+                       Nv, Nq, 16, points, qpb, bpi);
   else
-    hipLaunchKernelGGL((msda_fwd_kernel<__bf16, true>), grid, block, 0, st, (const __bf16*)value,
+    hipLaunchKernelGGL((msda_fwd_kernel<__bf16, true, 1>), grid, block, 0, st, (const __bf16*)value,
                        (const float*)nullptr, (const float*)nullptr, (const __bf16*)both, ref, (__bf16*)out, g,
                        Nv, Nq, 16, points, qpb, bpi);
   return check_launch("dskd_msda_fwd_fused");
@@ -1075,26 +1154,32 @@ extern "C" int dskd_msda_bwd(const void* value, const int64_t* spatial_shapes,
   const bool windowed = !force_v1 && Nq == Nv && make_value_geom(g, levels, points, Nq, &vg, var, lds);
   if (windowed) {
     if (dtype == DSKD_DTYPE_F32) {
-      hipLaunchKernelGGL((msda_bwd_kernel<float, false>), grid, block, 0, st, (const float*)value, loc, attn,
+      hipLaunchKernelGGL((msda_bwd_kernel<float, false, 1>), grid, block, 0, st, (const float*)value, loc, attn,
                          (const float*)grad_out, grad_value, grad_loc, grad_attn, g, Nv, Nq, LP, points, qpb,
                          bpi);
       if (int rc = launch_value<float>(loc, attn, (const float*)grad_out, grad_value, vg, var, lds, B, Nq, LP,
                                        points, st)) return rc;
     } else {
-      hipLaunchKernelGGL((msda_bwd_kernel<__bf16, false>), grid, block, 0, st, (const __bf16*)value, loc, attn,
-                         (const __bf16*)grad_out, grad_value, grad_loc, grad_attn, g, Nv, Nq, LP, points, qpb,
-                         bpi);
+#define DSKD_BWD_BF16(PH)                                                                                         \
+  hipLaunchKernelGGL((msda_bwd_kernel<__bf16, false, PH>), grid, block, 0, st, (const __bf16*)value, loc, attn,   \
+                     (const __bf16*)grad_out, grad_value, grad_loc, grad_attn, g, Nv, Nq, LP, points, qpb, bpi)
+      switch (pick_phases(LP, dtype, 4)) {
+        case 4: DSKD_BWD_BF16(4); break;
+        case 2: DSKD_BWD_BF16(2); break;
+        default: DSKD_BWD_BF16(1); break;
+      }
+#undef DSKD_BWD_BF16
       if (int rc = launch_value<__bf16>(loc, attn, (const __bf16*)grad_out, grad_value, vg, var, lds, B, Nq, LP,
                                         points, st)) return rc;
     }
     return check_launch("dskd_msda_bwd");
   }
   if (dtype == DSKD_DTYPE_F32)
-    hipLaunchKernelGGL((msda_bwd_kernel<float, true>), grid, block, 0, st, (const float*)value, loc,
+    hipLaunchKernelGGL((msda_bwd_kernel<float, true, 1>), grid, block, 0, st, (const float*)value, loc,
                        attn, (const float*)grad_out, grad_value, grad_loc, grad_attn, g, Nv,
                        Nq, LP, points, qpb, bpi);
   else
-    hipLaunchKernelGGL((msda_bwd_kernel<__bf16, true>), grid, block, 0, st, (const __bf16*)value, loc,
+    hipLaunchKernelGGL((msda_bwd_kernel<__bf16, true, 1>), grid, block, 0, st, (const __bf16*)value, loc,
                        attn, (const __bf16*)grad_out, grad_value, grad_loc, grad_attn, g, Nv,
                        Nq, LP, points, qpb, bpi);
   return check_launch("dskd_msda_bwd");

@@ -219,6 +219,49 @@ def test_msda_fused_prologue_is_bit_identical(dtype, Nq):
     torch.testing.assert_close(one.float().cpu(), want, **tol)
 
 
+@pytest.mark.parametrize("phases", [1, 2, 4])
+@pytest.mark.parametrize("shapes", [[(25, 42), (13, 21), (7, 11), (4, 6)], [(33, 47), (17, 24), (9, 12)], [(9, 5)]])
+def test_msda_phased_staging_is_bit_identical(monkeypatch, phases, shapes):
+    """bf16 gather kernels with the samples of a query staged in 1 / 2 / 4 phases (smaller LDS slices,
+    more resident waves; DSKD_MSDA_PHASES): the accumulation order is unchanged, so forward, fused
+    forward, grad_loc and grad_attn must carry identical bits for every phase count -- and phase
+    count 1 is what the oracle tests above pin."""
+    L = len(shapes)
+    value, loc, attn, go = _encoder_like_inputs(shapes, 2, 57, 2.0, torch.bfloat16)
+    loc[0, :7] = torch.tensor([-0.2, 0.0, 0.5, 1.0, 1.3, float("nan"), 0.999]).view(7, 1, 1, 1, 1)   # borders / rejected
+    args = (value.to(DEV), shapes, loc.to(DEV), attn.to(DEV))
+    g = torch.Generator().manual_seed(58)
+    Nv = value.shape[1]
+    both = (torch.randn(2, Nv, 384, generator=g) * 2).to(torch.bfloat16).to(DEV)
+    ref = torch.rand(2, Nv, L, 2, generator=g).to(DEV)
+    dec = tuple(t[:, :301].contiguous() for t in args[2:])            # decoder-like: Nq != Nv (plain-atomics backward)
+
+    def run():
+        out = native.msda_forward_raw(*args)
+        gv, gl, ga = native.msda_backward_raw(*args, go.to(DEV))
+        fused = native.ms_deform_attn_fused(args[0], shapes, both, ref, L, 4) if L == 4 else None
+        out_d = native.msda_forward_raw(args[0], shapes, *dec)
+        _, gl_d, ga_d = native.msda_backward_raw(args[0], shapes, *dec, go[:, :301].to(DEV))
+        return out, gv, gl, ga, fused, out_d, gl_d, ga_d
+
+    monkeypatch.setenv("DSKD_MSDA_PHASES", "1")
+    base = run()
+    monkeypatch.setenv("DSKD_MSDA_PHASES", str(phases))
+    got = run()
+    monkeypatch.delenv("DSKD_MSDA_PHASES")
+    for name, a, b in zip(("out", "grad_value", "grad_loc", "grad_attn", "fused", "out_dec", "grad_loc_dec", "grad_attn_dec"),
+                          got, base):
+        if a is None:
+            continue
+        if name == "grad_value":          # float atomics: order-dependent rounding
+            torch.testing.assert_close(a, b, atol=4e-3, rtol=4e-3)
+        else:                             # NaN-aware exact equality (a rejected location leaves zeros, not NaN)
+            assert torch.equal(a.float().nan_to_num(nan=12345.0), b.float().nan_to_num(nan=12345.0)), name
+    # and the phase-1 result is the oracle's
+    want = msda_ref.msda_grid_sample(value.float(), shapes, loc.nan_to_num(nan=-5.0), attn)
+    torch.testing.assert_close(got[0].float().cpu(), want, atol=3e-2, rtol=2e-2)
+
+
 # ----------------------------------------------------------------------------- add + dropout + LayerNorm
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("want_q", [False, True])
