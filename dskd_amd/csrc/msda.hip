@@ -84,7 +84,10 @@ __device__ __forceinline__ void fill_level_table(i32x4* tab, const LevelGeom& g)
     if (threadIdx.x == l) tab[l] = i32x4{g.H[l], g.W[l], g.start[l], 0};
 }
 
-template <int ROWB>
+// PAIR (layout experiment): a pixel's block holds (pixel, right neighbour), ROWB = 2 x head line, so
+// the corners (x0, x0+1) of a row are ONE aligned line; with x0 == -1 the right corner is the
+// first half of the next block.
+template <int ROWB, bool PAIR = false>
 __device__ __forceinline__ void point_params(float lx_n, float ly_n, float a, int lvl,
                                              const i32x4* tab, i32x4& off, f32x4& w,
                                              f32x4& aux) {
@@ -105,9 +108,10 @@ __device__ __forceinline__ void point_params(float lx_n, float ly_n, float a, in
     const bool vy0 = y0 >= 0, vy1 = y0 + 1 <= H - 1;
     const int r00 = (st + y0 * W + x0) * ROWB;
     off.x = (vy0 && vx0) ? r00 : kOOB;
-    off.y = (vy0 && vx1) ? r00 + ROWB : kOOB;
+    const int right = PAIR ? (vx0 ? ROWB / 2 : ROWB) : ROWB;
+    off.y = (vy0 && vx1) ? r00 + right : kOOB;
     off.z = (vy1 && vx0) ? r00 + W * ROWB : kOOB;
-    off.w = (vy1 && vx1) ? r00 + W * ROWB + ROWB : kOOB;
+    off.w = (vy1 && vx1) ? r00 + W * ROWB + right : kOOB;
     w = f32x4{hy * hx, hy * lx, ly * hx, ly * lx};
     aux.x = lx;
     aux.y = ly;
@@ -167,7 +171,7 @@ struct Phased {
   static constexpr int HS = kMaxLP / PH + 1;
 };
 
-template <typename T, bool WITH_AUX, int PH, bool KEEP_WT>
+template <typename T, bool WITH_AUX, int PH, bool KEEP_WT, int ROWB = Traits<T>::ROWB, bool PAIR = false>
 __device__ __forceinline__ void stage_points(const float* __restrict__ loc,
                                              const float* __restrict__ attn,
                                              const i32x4* g, int b, int Nq, int q0,
@@ -191,7 +195,7 @@ __device__ __forceinline__ void stage_points(const float* __restrict__ loc,
       const size_t base = ((size_t)b * Nq + q) * (size_t)(kHeads * LP) + h * LP + s;
       const f32x2 xy = *reinterpret_cast<const f32x2*>(loc + base * 2);
       const float a = attn[base];
-      point_params<TR::ROWB>(xy.x, xy.y, a, s / points, g, off, w, aux);
+      point_params<ROWB, PAIR>(xy.x, xy.y, a, s / points, g, off, w, aux);
     }
     const int slot = (qs * kHeads + h) * HS + sl;
     s_off[slot] = off;
@@ -259,7 +263,11 @@ __device__ __forceinline__ void stage_points_fused(const T* __restrict__ both, c
 }
 
 // ------------------------------------------------------------------ forward
-template <typename T, bool FUSED, int PH>
+// LAY (experiment, scratch/msda_layout_ab.py): 0 = [B, Nv, heads, ch] (the product layout);
+// 1 = head-major [B, heads, Nv, ch]: the two horizontally adjacent corners of a sample are contiguous
+// (one 128-B line when x0 is even, bf16); 2 = head-major with every pixel followed by a copy of its
+// right neighbour [B, heads, Nv, 2, ch]: the corner pair of a row is always one aligned 128-B line.
+template <typename T, bool FUSED, int PH, int LAY = 0>
 __global__ __launch_bounds__(kWaves * 64) void msda_fwd_kernel(
     const T* __restrict__ value, const float* __restrict__ loc,
     const float* __restrict__ attn, const T* __restrict__ both, const float* __restrict__ ref,
@@ -286,14 +294,16 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_kernel(
   const int q_end = min(q_begin + qpb, Nq);
 
   const T* vbase = value + (size_t)b * Nv * (kHeads * kCh);
+  constexpr int ROWB = LAY == 0 ? TR::ROWB : LAY * kCh * (int)sizeof(T);     // bytes between neighbouring pixels
+  const T* vimg = LAY == 2 ? value + (size_t)b * Nv * (2 * kHeads * kCh) : vbase;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<T*>(vbase), 0, Nv * TR::ROWB, 0x00020000);
+      const_cast<T*>(vimg), 0, Nv * (LAY == 2 ? 2 : 1) * TR::ROWB, 0x00020000);
 
   // lane -> (query slot, head, 16-byte part of the head's line)
   const int qs = lane / (kHeads * TR::LPH);
   const int h = (lane / TR::LPH) & (kHeads - 1);
   const int part = lane & (TR::LPH - 1);
-  const int hb = h * (kCh * (int)sizeof(T)) + part * 16;
+  const int hb = (LAY ? h * Nv * ROWB : h * (kCh * (int)sizeof(T))) + part * 16;
   const i32x4* my_off = s_off + (qs * kHeads + h) * HS;
   const f32x4* my_wt = s_wt + (qs * kHeads + h) * HS;
   const int LPS = LP / PH;      // samples per head and phase
@@ -308,8 +318,8 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_kernel(
       if constexpr (FUSED)
         stage_points_fused<T, PH>(both, ref, s_lvl, b, Nq, q0, q_end, LP / points, points, ph, lane, s_off, s_wt);
       else
-        stage_points<T, false, PH, true>(loc, attn, s_lvl, b, Nq, q0, q_end, LP, points, ph, lane, s_off, s_wt,
-                                         nullptr);
+        stage_points<T, false, PH, true, ROWB, LAY == 2>(loc, attn, s_lvl, b, Nq, q0, q_end, LP, points, ph, lane,
+                                                         s_off, s_wt, nullptr);
       wave_lds_sync();
 
 #pragma unroll 4
@@ -994,6 +1004,339 @@ int launch_value(const float* loc, const float* attn, const T* grad_out, float* 
   return launch_value_variant<T, 2>(loc, attn, grad_out, grad_value, g, var[2], lds[2], B, Nq, LP, points, st);
 }
 
+// ------------------------------------------------------------------ forward, windowed (encoder, bf16)
+// The plain forward above runs at the chip's L2 -> L1 gather rate (profiles/r01_msda_phased_staging_ab.txt,
+// r01_msda_layout_ab.txt: ~2.4 shader cycles per 64-B segment and CU whether it hits L1 or not, 16 TB/s
+// chip-wide): every (query, head) pulls 64 corners x 64 B = 4 KB through the texture path.  In the
+// encoder the queries are the pixels and sample near their own position, so here a workgroup owns
+// (image, region of <= 16x16 level-0 pixels, ONE head), copies that head's value windows of all four
+// levels (region footprint + the 5/6-pixel margins of the windowed backward) into LDS ONCE --
+// ~5 pixels of 64 B per (query, head) instead of 64 segments -- and gathers from LDS (256 B/clk/CU
+// against ~27 B/clk/CU).  Window pixels outside the image are zeros (= the zero padding); a sample
+// that leaves the window takes the plain buffer-load path, so the result is exact for ANY location;
+// a rejected sample reads a zero slot.  Same weights, same order of the 16 samples, same FMAs as the
+// plain kernel: bit-identical output.
+//   lane = (query of the pass, 16-B part of the head's 64-B line): 16 queries per wave pass;
+//   the 16 samples are staged level by level (4 points per query: one per lane), so the level
+//   geometry of a staging step is wave-uniform.
+struct FwdWinGeom {
+  int base[kMaxLevels];   // first window pixel of each level
+  int npos;               // window pixels over all levels (the zero slot follows)
+  int waves;              // workgroup size in waves (host side)
+};
+constexpr int kRegionF = 16;
+constexpr int kFwdHS = 5;       // staging slots per query: 4 points + 1 pad
+constexpr int kFwdSign = (int)0x80000000;
+
+template <typename T>
+__global__ __launch_bounds__(1024) void msda_fwd_win_kernel(
+    const T* __restrict__ value, const float* __restrict__ loc, const float* __restrict__ attn,
+    T* __restrict__ out, ValueGeom g, FwdWinGeom fw, int Nq, int points) {
+  static_assert(sizeof(T) == 2, "windowed forward: bf16 only");
+  constexpr int PIXB = kCh * (int)sizeof(T);     // 64 B: one head of one pixel
+  constexpr int ROWB = kHeads * PIXB;            // 512 B: one pixel, all heads
+  constexpr int LP = 16;
+  extern __shared__ float smem[];
+  char* win = reinterpret_cast<char*>(smem);                                    // [npos + 1][PIXB]
+  const int NW = blockDim.x >> 6;
+  i32x4* s_off_all = reinterpret_cast<i32x4*>(win + (size_t)(fw.npos + 1) * PIXB);   // [NW][16 * kFwdHS]
+  f32x4* s_wt_all = reinterpret_cast<f32x4*>(s_off_all + NW * 16 * kFwdHS);
+  i32x4* s_tab = reinterpret_cast<i32x4*>(s_wt_all + NW * 16 * kFwdHS);             // [4][4] lookup rows
+  int* s_geo = reinterpret_cast<int*>(s_tab + 4 * kMaxLevels);                       // [24] region geometry
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  int vb = xcd_remap(blockIdx.x, gridDim.x);
+  const int h = vb & 7; vb >>= 3;
+  const int rx = vb % g.RX; vb /= g.RX;
+  const int ry = vb % g.RY;
+  const int b = vb / g.RY;
+
+  // Region geometry: as in msda_bwd_value_kernel (same tables, same integer arithmetic).
+  //   s_tab[4l+0] = {cum, qxa, qya, qdx}   [4l+1] = {1/qdx, start, W, H}
+  //   s_tab[4l+2] = {ww, wh, wx0, wy0}     [4l+3] = {window base, nq, 0, 0}
+  if (wave == 0) {
+    if (lane < 6 * kMaxLevels) {
+      const int l = lane / 6, kind = lane - 6 * l;   // 0,1: x begin/end  2,3: y begin/end  4,5: origin x/y
+      const bool xaxis = kind == 0 || kind == 1 || kind == 4;
+      int Sl = 1;
+#pragma unroll
+      for (int k = 0; k < kMaxLevels; ++k)
+        if (l == k) Sl = xaxis ? g.W[k] : g.H[k];
+      const int S0 = xaxis ? g.W[0] : g.H[0], E = xaxis ? g.EX : g.EY;
+      const int r = (xaxis ? rx : ry) + ((kind == 1 || kind == 3) ? 1 : 0);
+      const int q = floor_div(2 * E * r * Sl - S0 + (kind < 4 ? 2 * S0 - 1 : 0), 2 * S0);
+      s_geo[lane] = kind < 4 ? (q < 0 ? 0 : (q > Sl ? Sl : q)) : q - kMarginLo;   // region_begin | win_origin
+    }
+    wave_lds_sync();
+    int tot = 0, mine = 0;
+#pragma unroll
+    for (int k = 0; k < kMaxLevels; ++k) {
+      if (k == lane) mine = tot;
+      if (k < g.levels) tot += (s_geo[6 * k + 1] - s_geo[6 * k]) * (s_geo[6 * k + 3] - s_geo[6 * k + 2]);
+    }
+#pragma unroll
+    for (int l = 0; l < kMaxLevels; ++l)
+      if (lane == l) {
+        const int qxa = s_geo[6 * l], qya = s_geo[6 * l + 2];
+        const int qdx = l < g.levels ? s_geo[6 * l + 1] - qxa : 0;
+        s_tab[4 * l + 0] = i32x4{mine, qxa, qya, qdx};
+        s_tab[4 * l + 1] = i32x4{as_i32(1.0f / (float)(qdx > 0 ? qdx : 1)), g.start[l], g.W[l], g.H[l]};
+        s_tab[4 * l + 2] = i32x4{g.ww[l], g.wh[l], s_geo[6 * l + 4], s_geo[6 * l + 5]};
+        s_tab[4 * l + 3] = i32x4{fw.base[l], tot, 0, 0};
+      }
+  }
+  __syncthreads();
+  int cum[kMaxLevels];
+#pragma unroll
+  for (int l = 0; l < kMaxLevels; ++l) cum[l] = s_tab[4 * l].x;
+  const int nq = s_tab[3].y;
+
+  const T* vbase = value + (size_t)b * Nq * (kHeads * kCh);      // Nq == Nv
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(vbase), 0, Nq * ROWB, 0x00020000);
+  const int part = lane & 3;
+  const int hb = h * PIXB + part * 16;
+
+  // ---- window fill: 4 lanes per window pixel, 16 B each; outside the image (and the zero slot): zeros.
+  // kFill loads are in flight per lane before the first LDS store (a load -> store loop pays one
+  // memory latency per iteration: ~10 iterations here).
+  {
+    constexpr int kFill = 5;
+    const int step = blockDim.x >> 2;
+    for (int p0 = tid >> 2; p0 <= fw.npos; p0 += kFill * step) {
+      u32x4 v[kFill];
+#pragma unroll
+      for (int u = 0; u < kFill; ++u) {
+        const int p = p0 + u * step;
+        int l = 0;
+#pragma unroll
+        for (int k = 1; k < kMaxLevels; ++k) l += (p >= fw.base[k]) ? 1 : 0;
+        const i32x4 lb = s_tab[4 * l + 1], lc = s_tab[4 * l + 2];
+        const int rel = p - s_tab[4 * l + 3].x;
+        const int wwl = lc.x;
+        const int wy = (int)(((float)rel + 0.5f) / (float)wwl), wx = rel - wy * wwl;
+        const int gx = lc.z + wx, gy = lc.w + wy;
+        const bool in = p < fw.npos && gx >= 0 && gx < lb.z && gy >= 0 && gy < lb.w;
+        const int goff = in ? (lb.y + gy * lb.z + gx) * ROWB + hb : kOOB;
+        v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff, 0, 0));
+      }
+#pragma unroll
+      for (int u = 0; u < kFill; ++u) {
+        const int p = p0 + u * step;
+        if (p <= fw.npos) *reinterpret_cast<u32x4*>(win + (size_t)p * PIXB + part * 16) = v[u];
+      }
+    }
+  }
+  __syncthreads();
+
+  i32x4* s_off = s_off_all + wave * 16 * kFwdHS;
+  f32x4* s_wt = s_wt_all + wave * 16 * kFwdHS;
+  const int ql = lane >> 2;                  // query of the pass
+  const int zero_slot = fw.npos * PIXB;
+
+  // Software pipeline: the sampling locations / attention weights of the NEXT pass (this lane's point on
+  // each of the four levels) are requested before the current pass is consumed.
+  f32x2 n_xy[kMaxLevels];
+  float n_a[kMaxLevels];
+  int n_qg = -1;
+  auto fetch = [&](int qb) {
+    const int qi = qb + ql;
+    n_qg = qi < nq ? region_query(s_tab, cum, qi) : -1;
+    if (n_qg >= 0) {
+      const size_t base = (((size_t)b * Nq + n_qg) * kHeads + h) * (size_t)LP + part;
+#pragma unroll
+      for (int l = 0; l < kMaxLevels; ++l) {
+        n_xy[l] = *reinterpret_cast<const f32x2*>(loc + (base + l * points) * 2);
+        n_a[l] = attn[base + l * points];
+      }
+    }
+  };
+  fetch(wave * 16);
+
+  for (int qbase = wave * 16; qbase < nq; qbase += NW * 16) {
+    const int qg = n_qg;
+    f32x2 c_xy[kMaxLevels];
+    float c_a[kMaxLevels];
+#pragma unroll
+    for (int l = 0; l < kMaxLevels; ++l) { c_xy[l] = n_xy[l]; c_a[l] = n_a[l]; }
+    fetch(qbase + NW * 16);
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+
+#pragma unroll
+    for (int lvl = 0; lvl < kMaxLevels; ++lvl) {
+      // ---- stage the 4 points of this level: lane = (query, point)
+      bool any_fb;
+      {
+        i32x4 off = i32x4{zero_slot, zero_slot, zero_slot, zero_slot};
+        f32x4 w = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (qg >= 0) {
+          const f32x2 xy = c_xy[lvl];
+          const float a = c_a[lvl];
+          const i32x4 lb = s_tab[4 * lvl + 1], lc = s_tab[4 * lvl + 2];
+          const int H = lb.w, W = lb.z, st = lb.y;
+          const float x = xy.x * (float)W - 0.5f;
+          const float y = xy.y * (float)H - 0.5f;
+          if (x > -1.f && y > -1.f && x < (float)W && y < (float)H) {   // as point_params
+            const float xf = floorf(x), yf = floorf(y);
+            const int x0 = (int)xf, y0 = (int)yf;
+            const float lx = x - xf, ly = y - yf;
+            const float hx = 1.f - lx, hy = 1.f - ly;
+            w = f32x4{hy * hx, hy * lx, ly * hx, ly * lx} * a;
+            const int wwl = lc.x, whl = lc.y;
+            const int wx = x0 - lc.z, wy = y0 - lc.w;
+            if (wx >= 0 && wx + 1 < wwl && wy >= 0 && wy + 1 < whl) {
+              const int pb = (s_tab[4 * lvl + 3].x + wy * wwl + wx) * PIXB;
+              off = i32x4{pb, pb + PIXB, pb + wwl * PIXB, pb + wwl * PIXB + PIXB};
+            } else {      // left the window: global byte offsets, flagged by the sign bit
+              const bool vx0 = x0 >= 0, vx1 = x0 + 1 <= W - 1;
+              const bool vy0 = y0 >= 0, vy1 = y0 + 1 <= H - 1;
+              const int r00 = (st + y0 * W + x0) * ROWB;
+              off.x = ((vy0 && vx0) ? r00 : kOOB) | kFwdSign;
+              off.y = ((vy0 && vx1) ? r00 + ROWB : kOOB) | kFwdSign;
+              off.z = ((vy1 && vx0) ? r00 + W * ROWB : kOOB) | kFwdSign;
+              off.w = ((vy1 && vx1) ? r00 + W * ROWB + ROWB : kOOB) | kFwdSign;
+            }
+          }
+        }
+        s_off[ql * kFwdHS + part] = off;
+        s_wt[ql * kFwdHS + part] = w;
+        any_fb = __ballot(off.x < 0) != 0ull;
+      }
+      wave_lds_sync();
+      // ---- consume: lane = (query, 16-B part)
+      if (!any_fb) {    // wave-uniform: every sample of this step is inside the windows -> LDS only, no lane branches
+#pragma unroll 2
+        for (int sl = 0; sl < 4; ++sl) {
+          const i32x4 o = s_off[ql * kFwdHS + sl];
+          const f32x4 w = s_wt[ql * kFwdHS + sl];
+          const u32x4 r0 = *reinterpret_cast<const u32x4*>(win + o.x + part * 16);
+          const u32x4 r1 = *reinterpret_cast<const u32x4*>(win + o.y + part * 16);
+          const u32x4 r2 = *reinterpret_cast<const u32x4*>(win + o.z + part * 16);
+          const u32x4 r3 = *reinterpret_cast<const u32x4*>(win + o.w + part * 16);
+          float v0[8], v1[8], v2[8], v3[8];
+          unpack_bf16x8(r0, v0);
+          unpack_bf16x8(r1, v1);
+          unpack_bf16x8(r2, v2);
+          unpack_bf16x8(r3, v3);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            acc[i] = fmaf(w.x, v0[i], acc[i]);
+            acc[i] = fmaf(w.y, v1[i], acc[i]);
+            acc[i] = fmaf(w.z, v2[i], acc[i]);
+            acc[i] = fmaf(w.w, v3[i], acc[i]);
+          }
+        }
+      } else
+#pragma unroll 2
+      for (int sl = 0; sl < 4; ++sl) {
+        const i32x4 o = s_off[ql * kFwdHS + sl];
+        const f32x4 w = s_wt[ql * kFwdHS + sl];
+        u32x4 r0, r1, r2, r3;
+        if (o.x < 0) {
+          r0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (o.x & 0x7FFFFFFF) + hb, 0, 0));
+          r1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (o.y & 0x7FFFFFFF) + hb, 0, 0));
+          r2 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (o.z & 0x7FFFFFFF) + hb, 0, 0));
+          r3 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (o.w & 0x7FFFFFFF) + hb, 0, 0));
+        } else {
+          r0 = *reinterpret_cast<const u32x4*>(win + o.x + part * 16);
+          r1 = *reinterpret_cast<const u32x4*>(win + o.y + part * 16);
+          r2 = *reinterpret_cast<const u32x4*>(win + o.z + part * 16);
+          r3 = *reinterpret_cast<const u32x4*>(win + o.w + part * 16);
+        }
+        float v0[8], v1[8], v2[8], v3[8];
+        unpack_bf16x8(r0, v0);
+        unpack_bf16x8(r1, v1);
+        unpack_bf16x8(r2, v2);
+        unpack_bf16x8(r3, v3);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          acc[i] = fmaf(w.x, v0[i], acc[i]);
+          acc[i] = fmaf(w.y, v1[i], acc[i]);
+          acc[i] = fmaf(w.z, v2[i], acc[i]);
+          acc[i] = fmaf(w.w, v3[i], acc[i]);
+        }
+      }
+      wave_lds_sync();   // the next level's staging overwrites the slots
+    }
+
+    if (qg >= 0) {
+      T* orow = out + ((size_t)b * Nq + qg) * (kHeads * kCh) + h * kCh;
+      u32x4 p;
+      p.x = pack_bf16x2(acc[0], acc[1]);
+      p.y = pack_bf16x2(acc[2], acc[3]);
+      p.z = pack_bf16x2(acc[4], acc[5]);
+      p.w = pack_bf16x2(acc[6], acc[7]);
+      *reinterpret_cast<u32x4*>(orow + part * 8) = p;
+    }
+  }
+}
+
+// Host side: regions of <= kRegionF level-0 pixels, all four windows of one head in LDS.
+bool make_fwd_win_geom(const LevelGeom& lg, int levels, int points, int Nq, ValueGeom* g, FwdWinGeom* fw,
+                       size_t* lds_bytes) {
+  if (levels != 4 || points != 4) return false;
+  int tot = 0;
+  for (int l = 0; l < levels; ++l) tot += lg.H[l] * lg.W[l];
+  if (tot != Nq) return false;
+  for (int l = 0; l < levels; ++l)
+    if (lg.start[l] != (l == 0 ? 0 : lg.start[l - 1] + lg.H[l - 1] * lg.W[l - 1])) return false;
+  const int W0 = lg.W[0], H0 = lg.H[0];
+  g->levels = levels;
+  g->RX = (W0 + kRegionF - 1) / kRegionF;
+  g->RY = (H0 + kRegionF - 1) / kRegionF;
+  g->EX = (W0 + g->RX - 1) / g->RX;
+  g->EY = (H0 + g->RY - 1) / g->RY;
+  int npos = 0, nq_max = 0;
+  for (int l = 0; l < levels; ++l) {
+    if (lg.W[l] > W0 || lg.H[l] > H0) return false;   // level 0 must be the finest
+    g->H[l] = lg.H[l]; g->W[l] = lg.W[l]; g->start[l] = lg.start[l];
+    g->ww[l] = (g->EX * lg.W[l] + W0 - 1) / W0 + 1 + kMarginLo + kMarginHi;
+    g->wh[l] = (g->EY * lg.H[l] + H0 - 1) / H0 + 1 + kMarginLo + kMarginHi;
+    fw->base[l] = npos;
+    npos += g->ww[l] * g->wh[l];
+  }
+  fw->npos = npos;
+  // queries of the largest region (the kernel's own integer arithmetic)
+  auto edge = [](int E, int r, int Sl, int S0) {
+    const int q = floor_div(2 * E * r * Sl - S0 + 2 * S0 - 1, 2 * S0);
+    return q < 0 ? 0 : (q > Sl ? Sl : q);
+  };
+  for (int ry = 0; ry < g->RY; ++ry)
+    for (int rx = 0; rx < g->RX; ++rx) {
+      int nq = 0;
+      for (int l = 0; l < levels; ++l)
+        nq += (edge(g->EX, rx + 1, lg.W[l], W0) - edge(g->EX, rx, lg.W[l], W0)) *
+              (edge(g->EY, ry + 1, lg.H[l], H0) - edge(g->EY, ry, lg.H[l], H0));
+      if (nq > nq_max) nq_max = nq;
+    }
+  // as few rounds of 16-query wave passes as possible, then as few waves as cover them
+  const int passes = (nq_max + 15) / 16;
+  const int rounds = (passes + 15) / 16;
+  int nw = (passes + rounds - 1) / rounds;
+  if (nw < 4) nw = 4;
+  if (nw > 16) nw = 16;
+  fw->waves = nw;
+  *lds_bytes = ((size_t)(npos + 1) * (kCh * 2) + (size_t)nw * 16 * kFwdHS * 32 + 16 * 4 * kMaxLevels +
+                sizeof(int) * 6 * kMaxLevels + 15) & ~(size_t)15;
+  return *lds_bytes <= kMaxLds;
+}
+
+int launch_fwd_win(const __bf16* value, const float* loc, const float* attn, __bf16* out, const ValueGeom& g,
+                   const FwdWinGeom& fw, size_t lds, int B, int Nq, int points, hipStream_t st) {
+  auto kern = msda_fwd_win_kernel<__bf16>;
+  static const hipError_t attr = hipFuncSetAttribute(
+      (const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+  if (attr != hipSuccess) return fail(DSKD_ERR_LAUNCH, "dskd_msda_fwd: cannot reserve LDS");
+  const dim3 grid((unsigned)(B * g.RY * g.RX * kHeads)), block(fw.waves * 64);
+  hipLaunchKernelGGL(kern, grid, block, lds, st, value, loc, attn, out, g, fw, Nq, points);
+  return DSKD_OK;
+}
+
 int fill_geom(const int64_t* spatial_shapes, const int64_t* level_start, int levels, int Nv,
               LevelGeom* g) {
   int64_t covered = 0;
@@ -1085,6 +1428,33 @@ extern "C" int dskd_msda_fwd(const void* value, const int64_t* spatial_shapes,
   hipLaunchKernelGGL((msda_fwd_kernel<__bf16, false, PH>), grid, block, 0, st, (const __bf16*)value, loc, attn, \
                      (const __bf16*)nullptr, (const float*)nullptr, (__bf16*)out, g, Nv, Nq, levels * points,   \
                      points, qpb, bpi)
+    // windowed forward (encoder shape, 4 levels x 4 points): DSKD_MSDA_FWD=win (A/B switch)
+    {
+      const char* fv = getenv("DSKD_MSDA_FWD");
+      ValueGeom vg;
+      FwdWinGeom fw;
+      size_t lds = 0;
+      if (fv && fv[0] == 'w' && Nq == Nv && make_fwd_win_geom(g, levels, points, Nq, &vg, &fw, &lds)) {
+        if (int rc = launch_fwd_win((const __bf16*)value, loc, attn, (__bf16*)out, vg, fw, lds, B, Nq, points, st))
+          return rc;
+        return check_launch("dskd_msda_fwd");
+      }
+    }
+    // layout experiment only (the caller passes value in that layout): "hm" head-major, "pair" head-major
+    // with the right neighbour duplicated
+    const char* lay = getenv("DSKD_MSDA_VALUE_LAYOUT");
+    if (lay && lay[0] == 'h' && lay[1] == 'm') {
+      hipLaunchKernelGGL((msda_fwd_kernel<__bf16, false, 1, 1>), grid, block, 0, st, (const __bf16*)value, loc,
+                         attn, (const __bf16*)nullptr, (const float*)nullptr, (__bf16*)out, g, Nv, Nq,
+                         levels * points, points, qpb, bpi);
+      return check_launch("dskd_msda_fwd");
+    }
+    if (lay && lay[0] == 'p') {
+      hipLaunchKernelGGL((msda_fwd_kernel<__bf16, false, 1, 2>), grid, block, 0, st, (const __bf16*)value, loc,
+                         attn, (const __bf16*)nullptr, (const float*)nullptr, (__bf16*)out, g, Nv, Nq,
+                         levels * points, points, qpb, bpi);
+      return check_launch("dskd_msda_fwd");
+    }
     switch (pick_phases(levels * points, dtype, 4)) {
       case 4: DSKD_FWD_BF16(4); break;
       case 2: DSKD_FWD_BF16(2); break;

@@ -84,6 +84,11 @@ int dskd_device_count(void);
  * attn           device, [B, Nq, heads, levels, points]    f32
  * out            device, [B, Nq, heads*ch]    same dtype as value
  * Supported: heads == 8, ch == 32, levels <= 4, levels*points <= 16.
+ * Diagnostic environment switches (A/B measurements; never needed for correct results, every
+ * variant is bit-identical to the default): DSKD_MSDA_PHASES=1|2|4 (bf16 staging phases),
+ * DSKD_MSDA_FWD=win (windowed bf16 forward for Nq == Nv, 4 levels x 4 points),
+ * DSKD_MSDA_BWD=v1 (plain-atomics backward), DSKD_MSDA_VALUE_LAYOUT=hm|pair (layout experiment:
+ * the CALLER must then pass value in that layout -- not part of the ABI).
  * ------------------------------------------------------------------------- */
 int dskd_msda_fwd(const void* value, const int64_t* spatial_shapes,
                   const int64_t* level_start, const float* loc, const float* attn,

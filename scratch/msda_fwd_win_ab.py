@@ -1,0 +1,86 @@
+"""Windowed forward (DSKD_MSDA_FWD=win: value windows of one head staged in LDS per region) against the
+plain forward: bit-equality on small / ragged / far-offset / border cases and at the BASELINE shape
+(B=4, bf16), and HIP-event time per launch.  Writes gpurun_out/msda_fwd_win_ab.json."""
+import json
+import os
+import sys
+
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+sys.path.insert(0, R + "/tests")
+import torch  # noqa: E402
+
+from dskd_amd import native  # noqa: E402
+from test_gpu_kernels import SHAPES_FULL, _encoder_like_inputs  # noqa: E402
+
+N_ITER = int(os.environ.get("N_ITER", "20"))
+
+
+def timed(fn, n=N_ITER):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3      # us
+
+
+def both(args):
+    os.environ.pop("DSKD_MSDA_FWD", None)
+    plain = native.msda_forward_raw(*args)
+    os.environ["DSKD_MSDA_FWD"] = "win"
+    win = native.msda_forward_raw(*args)
+    os.environ.pop("DSKD_MSDA_FWD")
+    torch.cuda.synchronize()
+    return plain, win
+
+
+res = {"cases": []}
+cases = [([(25, 42), (13, 21), (7, 11), (4, 6)], 2, 2.0), ([(25, 42), (13, 21), (7, 11), (4, 6)], 2, 12.0),
+         ([(64, 96), (32, 48), (16, 24), (8, 12)], 1, 3.0), ([(40, 70), (20, 35), (10, 18), (5, 9)], 3, 6.0),
+         ([(17, 16), (9, 8), (5, 4), (3, 2)], 2, 1.0), (SHAPES_FULL, 4, 2.5)]
+for shapes, B, sigma in cases:
+    value, loc, attn, _ = _encoder_like_inputs(shapes, B, 71, sigma, torch.bfloat16)
+    loc[0, :7] = torch.tensor([-0.2, 0.0, 0.5, 1.0, 1.3, float("nan"), 0.999]).view(7, 1, 1, 1, 1)
+    args = (value.cuda(), shapes, loc.cuda(), attn.cuda())
+    plain, win = both(args)
+    eq = bool(torch.equal(plain, win))
+    diff = float((plain.float() - win.float()).abs().max())
+    nbad = int((plain != win).sum())
+    res["cases"].append({"shapes": shapes, "B": B, "sigma_px": sigma, "equal": eq, "maxdiff": diff, "n_diff": nbad,
+                         "finite": bool(torch.isfinite(win.float()).all())})
+    print(res["cases"][-1], flush=True)
+
+# the benchmark's own locations: sampling_offsets at initialisation = bias grid, head h looks along
+# direction 2*pi*h/8 (max-norm 1), point k at (k + 1) pixels of every level; no learned part
+import math  # noqa: E402
+shapes, B = SHAPES_FULL, 4
+value, loc, attn, _ = _encoder_like_inputs(shapes, B, 72, 0.05, torch.bfloat16)
+dirs = torch.tensor([[math.cos(2 * math.pi * k / 8), math.sin(2 * math.pi * k / 8)] for k in range(8)])
+dirs = dirs / dirs.abs().max(-1, keepdim=True)[0]
+grid = dirs.view(8, 1, 1, 2) * torch.arange(1, 5).view(1, 1, 4, 1)                 # [heads, 1, points, 2] pixels
+norm = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32).view(1, 4, 1, 2)
+loc = loc + (grid / norm).view(1, 1, 8, 4, 4, 2)
+gargs = (value.cuda(), shapes, loc.cuda(), attn.cuda())
+plain, win = both(gargs)
+res["grid_init_equal"] = bool(torch.equal(plain, win))
+os.environ.pop("DSKD_MSDA_FWD", None)
+res["grid_init_plain_us"] = timed(lambda: native.msda_forward_raw(*gargs))
+os.environ["DSKD_MSDA_FWD"] = "win"
+res["grid_init_win_us"] = timed(lambda: native.msda_forward_raw(*gargs))
+os.environ.pop("DSKD_MSDA_FWD")
+
+# timing at the BASELINE shape (the last case's tensors)
+os.environ.pop("DSKD_MSDA_FWD", None)
+res["plain_us"] = timed(lambda: native.msda_forward_raw(*args))
+os.environ["DSKD_MSDA_FWD"] = "win"
+res["win_us"] = timed(lambda: native.msda_forward_raw(*args))
+os.environ.pop("DSKD_MSDA_FWD")
+print(json.dumps({k: v for k, v in res.items() if k != "cases"}), flush=True)
+os.makedirs(os.path.join(R, "gpurun_out"), exist_ok=True)
+with open(os.path.join(R, "gpurun_out", "msda_fwd_win_ab.json"), "w") as f:
+    json.dump(res, f, indent=1)

@@ -262,6 +262,52 @@ def test_msda_phased_staging_is_bit_identical(monkeypatch, phases, shapes):
     torch.testing.assert_close(got[0].float().cpu(), want, atol=3e-2, rtol=2e-2)
 
 
+@pytest.mark.parametrize("shapes,B,sigma", [([(25, 42), (13, 21), (7, 11), (4, 6)], 2, 2.0),
+                                            ([(25, 42), (13, 21), (7, 11), (4, 6)], 2, 12.0),     # most samples leave the windows
+                                            ([(40, 70), (20, 35), (10, 18), (5, 9)], 3, 6.0),
+                                            ([(17, 16), (9, 8), (5, 4), (3, 2)], 2, 1.0)])
+def test_msda_windowed_forward_is_bit_identical(monkeypatch, shapes, B, sigma):
+    """Experimental windowed forward (DSKD_MSDA_FWD=win: one head's value windows of a 16x16-pixel region
+    staged in LDS, out-of-window samples through buffer loads): same weights, same sample order, same
+    FMAs as the plain kernel, so the bf16 output must be identical -- borders, rejected and far samples
+    included."""
+    value, loc, attn, _ = _encoder_like_inputs(shapes, B, 71, sigma, torch.bfloat16)
+    loc[0, :7] = torch.tensor([-0.2, 0.0, 0.5, 1.0, 1.3, float("nan"), 0.999]).view(7, 1, 1, 1, 1)
+    args = (value.to(DEV), shapes, loc.to(DEV), attn.to(DEV))
+    monkeypatch.delenv("DSKD_MSDA_FWD", raising=False)
+    plain = native.msda_forward_raw(*args)
+    monkeypatch.setenv("DSKD_MSDA_FWD", "win")
+    win = native.msda_forward_raw(*args)
+    monkeypatch.delenv("DSKD_MSDA_FWD")
+    assert torch.equal(plain, win)
+
+
+def test_msda_value_layout_experiments_are_bit_identical(monkeypatch):
+    """Experiment-only forward variants reading the value in head-major / pair-duplicated layout
+    (DSKD_MSDA_VALUE_LAYOUT, scratch/msda_layout_ab.py): identical output."""
+    shapes = [(25, 42), (13, 21), (7, 11), (4, 6)]
+    value, loc, attn, _ = _encoder_like_inputs(shapes, 2, 73, 3.0, torch.bfloat16)
+    loc[0, :7] = torch.tensor([-0.2, 0.0, 0.5, 1.0, 1.3, float("nan"), 0.999]).view(7, 1, 1, 1, 1)
+    v, ld, ad = value.to(DEV), loc.to(DEV), attn.to(DEV)
+    B, Nv = v.shape[:2]
+    monkeypatch.delenv("DSKD_MSDA_VALUE_LAYOUT", raising=False)
+    plain = native.msda_forward_raw(v, shapes, ld, ad)
+    vp = v.permute(0, 2, 1, 3)
+    hm = vp.contiguous().view(B, Nv, 8, 32)
+    big = torch.zeros(B, 8, Nv, 2, 32, dtype=v.dtype, device=DEV)
+    big[:, :, :, 0] = vp
+    big[:, :, :-1, 1] = vp[:, :, 1:]
+    pair = big.view(-1)[: B * Nv * 256].view(B, Nv, 8, 32)          # the kernel indexes the whole buffer
+    monkeypatch.setenv("DSKD_MSDA_VALUE_LAYOUT", "hm")
+    out_hm = native.msda_forward_raw(hm, shapes, ld, ad)
+    monkeypatch.setenv("DSKD_MSDA_VALUE_LAYOUT", "pair")
+    out_pair = native.msda_forward_raw(pair, shapes, ld, ad)
+    monkeypatch.delenv("DSKD_MSDA_VALUE_LAYOUT")
+    torch.cuda.synchronize()
+    assert torch.equal(out_hm, plain) and torch.equal(out_pair, plain)
+    del big
+
+
 # ----------------------------------------------------------------------------- add + dropout + LayerNorm
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("want_q", [False, True])
