@@ -12,7 +12,9 @@ takes part in the arithmetic.  What runs is the reference's code:
 ``loss_corr``, ``decode_v1``), ``GFLHungarianAssigner.assign``, ``bbox_overlaps``,
 ``Integral_average`` and the loss modules.
 
-    python tests/golden/gen_golden.py        # rewrites tests/golden/*.npz
+    python tests/golden/gen_golden.py               # rewrites tests/golden/*.npz
+    python tests/golden/gen_golden.py --variants    # loss_variants_b2_l70.npz
+    python tests/golden/gen_golden.py --datasplit   # data_split_cases.json
 """
 import importlib.util
 import os
@@ -405,8 +407,42 @@ def main():
         print(name, {k: float(v) for k, v in out.items() if k.startswith("loss/")})
 
 
+def main_datasplit():
+    """tests/golden/data_split_cases.json: the reference's class table and ``split_data_category``
+    (mmdet/datasets/data_split.py, loaded by path: it imports nothing of mmdet) on a set of protocols."""
+    import contextlib
+    import io
+    import json
+    import random
+    spec = importlib.util.spec_from_file_location("ref_data_split", os.path.join(REF, "mmdet/datasets/data_split.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cases = []
+    for split, order, valpart, catofset, seed in [((40, 40), "pingyin", "prev-cur", "train|val|fine", None),
+                                                  ((70, 10), "pingyin", "prev-only", "train|val|fine", None),
+                                                  ("40-20-20", "pingyin", "cur-only", "train|val", None),
+                                                  ((20, 20, 20, 20), "pingyin", "prev-cur", "fine", None),
+                                                  ((50, 30), "pingyin", "prev-cur", "val", None),
+                                                  ((2, 3, 1), "pingyin", "prev-only", "train", None),
+                                                  ((40, 40), "shuffle", "prev-cur", "train|val|fine", 7),
+                                                  ((60, 20), "shuffle", "cur-only", "train", 123)]:
+        if seed is not None:
+            random.seed(seed)
+        with contextlib.redirect_stdout(io.StringIO()):
+            out = mod.split_data_category(dataname="CocoDataset", split=split, order=order, catofset=catofset,
+                                          valpart=valpart)
+        groups = out if isinstance(out, tuple) else (out,)
+        cases.append({"split": split, "order": order, "valpart": valpart, "catofset": catofset, "seed": seed,
+                      "out": [[list(d.items()) for d in grp] for grp in groups]})
+    with open(os.path.join(OUT, "data_split_cases.json"), "w") as f:
+        json.dump({"coco_cats_ids": list(mod.COCO_CATS_IDS.items()), "cases": cases}, f)
+    print("data_split_cases.json:", len(cases), "cases")
+
+
 if __name__ == "__main__":
-    if "--variants" in sys.argv:
+    if "--datasplit" in sys.argv:
+        main_datasplit()
+    elif "--variants" in sys.argv:
         main_variants()
     else:
         main()

@@ -142,6 +142,47 @@ def test_step_lr_with_linear_warmup():
     assert opt.param_groups[0]["lr"] == pytest.approx(0.01)
 
 
+def test_split_data_category_matches_reference_goldens():
+    """Class table and task split (reference mmdet/datasets/data_split.py:62-80, :100-158) against the
+    outputs of the reference's own function (tests/golden/gen_golden.py --datasplit), incl. the
+    'shuffle' order under a seeded ``random`` and the string form of ``split``."""
+    import json
+    import os
+    import random
+
+    from dskd_amd.datasets import COCO_CATS_IDS, split_data_category
+    with open(os.path.join(os.path.dirname(__file__), "golden", "data_split_cases.json")) as f:
+        gold = json.load(f)
+    assert [list(kv) for kv in COCO_CATS_IDS.items()] == gold["coco_cats_ids"]
+    assert len(gold["cases"]) >= 8
+    for c in gold["cases"]:
+        if c["seed"] is not None:
+            random.seed(c["seed"])
+        split = c["split"] if isinstance(c["split"], str) else tuple(c["split"])
+        out = split_data_category(split=split, order=c["order"], catofset=c["catofset"], valpart=c["valpart"])
+        groups = out if isinstance(out, tuple) else (out,)
+        got = [[[list(kv) for kv in d.items()] for d in grp] for grp in groups]
+        assert got == c["out"], (c["split"], c["order"], c["valpart"], c["catofset"])
+    with pytest.raises(NotImplementedError):
+        split_data_category(dataname="VOCDataset", split=(10, 10), valpart="prev-cur")
+    with pytest.raises(ValueError):
+        split_data_category(split=(40, 40), order="random", valpart="prev-cur")
+    with pytest.raises(AssertionError):
+        split_data_category(split=(40, 40))             # the default valpart is a menu, not a mode (reference :101, :131)
+
+
+def test_synthetic_il_dataset_uses_protocol_classes():
+    ds = SyntheticILDataset(catsplit=(70, 10), catload=(0, 1), num_images=2, img_size=(32, 48), n_gt=2)
+    assert ds.TASK_CLASSES[0][0] == "airplane" and len(ds.TASK_CLASSES[0]) == 70
+    assert ds.TASK_CLASSES[1] == ["toilet", "toothbrush", "traffic light", "train", "truck", "tv", "umbrella", "vase",
+                                  "wine glass", "zebra"]
+    assert ds.ALL_CLASSES_IDS["person"] == 1 and ds.cat2label[ds.ALL_CLASSES_IDS["airplane"]] == 0
+    assert ds.cat2label[ds.ALL_CLASSES_IDS["zebra"]] == 79
+    assert sorted(ds.cat2label[ds.ALL_CLASSES_IDS[c]] for c in ds.LOAD_CLASSES) == list(range(70, 80))
+    model_labels = [ds.cat2label[ds.ALL_CLASSES_IDS[c]] for c in set(ds.PRED_CLASSES) - set(ds.LOAD_CLASSES)]
+    assert sorted(model_labels) == list(range(70))          # what set_datainfo turns into LableInPCNTask['prev']
+
+
 def test_synthetic_il_dataset_surface():
     ds = SyntheticILDataset(catsplit=(40, 40), catload=(0, 1), num_images=5, img_size=(64, 96), n_gt=3)
     assert len(ds.TASK_CLASSES) == 2 and len(ds.LOAD_CLASSES) == 40 and len(ds.PRED_CLASSES) == 80
