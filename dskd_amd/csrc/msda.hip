@@ -1022,6 +1022,8 @@ int launch_value(const float* loc, const float* attn, const T* grad_out, float* 
 struct FwdWinGeom {
   int base[kMaxLevels];   // first window pixel of each level
   int npos;               // window pixels over all levels (the zero slot follows)
+  int lv0;                // first level held in LDS; levels below it (the finest, with the largest windows) stay on
+                          // the buffer-load path, which then runs beside the LDS gather instead of idling
   int waves;              // workgroup size in waves (host side)
 };
 constexpr int kRegionF = 16;
@@ -1111,9 +1113,9 @@ __global__ __launch_bounds__(1024) void msda_fwd_win_kernel(
 #pragma unroll
       for (int u = 0; u < kFill; ++u) {
         const int p = p0 + u * step;
-        int l = 0;
+        int l = fw.lv0;
 #pragma unroll
-        for (int k = 1; k < kMaxLevels; ++k) l += (p >= fw.base[k]) ? 1 : 0;
+        for (int k = 1; k < kMaxLevels; ++k) l += (k > fw.lv0 && p >= fw.base[k]) ? 1 : 0;
         const i32x4 lb = s_tab[4 * l + 1], lc = s_tab[4 * l + 2];
         const int rel = p - s_tab[4 * l + 3].x;
         const int wwl = lc.x;
@@ -1189,7 +1191,7 @@ __global__ __launch_bounds__(1024) void msda_fwd_win_kernel(
             w = f32x4{hy * hx, hy * lx, ly * hx, ly * lx} * a;
             const int wwl = lc.x, whl = lc.y;
             const int wx = x0 - lc.z, wy = y0 - lc.w;
-            if (wx >= 0 && wx + 1 < wwl && wy >= 0 && wy + 1 < whl) {
+            if (lvl >= fw.lv0 && wx >= 0 && wx + 1 < wwl && wy >= 0 && wy + 1 < whl) {
               const int pb = (s_tab[4 * lvl + 3].x + wy * wwl + wx) * PIXB;
               off = i32x4{pb, pb + PIXB, pb + wwl * PIXB, pb + wwl * PIXB + PIXB};
             } else {      // left the window: global byte offsets, flagged by the sign bit
@@ -1277,8 +1279,8 @@ __global__ __launch_bounds__(1024) void msda_fwd_win_kernel(
 }
 
 // Host side: regions of <= kRegionF level-0 pixels, all four windows of one head in LDS.
-bool make_fwd_win_geom(const LevelGeom& lg, int levels, int points, int Nq, ValueGeom* g, FwdWinGeom* fw,
-                       size_t* lds_bytes) {
+bool make_fwd_win_geom(const LevelGeom& lg, int levels, int points, int Nq, int lv0, int nw_req, ValueGeom* g,
+                       FwdWinGeom* fw, size_t* lds_bytes) {
   if (levels != 4 || points != 4) return false;
   int tot = 0;
   for (int l = 0; l < levels; ++l) tot += lg.H[l] * lg.W[l];
@@ -1298,9 +1300,10 @@ bool make_fwd_win_geom(const LevelGeom& lg, int levels, int points, int Nq, Valu
     g->ww[l] = (g->EX * lg.W[l] + W0 - 1) / W0 + 1 + kMarginLo + kMarginHi;
     g->wh[l] = (g->EY * lg.H[l] + H0 - 1) / H0 + 1 + kMarginLo + kMarginHi;
     fw->base[l] = npos;
-    npos += g->ww[l] * g->wh[l];
+    if (l >= lv0) npos += g->ww[l] * g->wh[l];
   }
   fw->npos = npos;
+  fw->lv0 = lv0;
   // queries of the largest region (the kernel's own integer arithmetic)
   auto edge = [](int E, int r, int Sl, int S0) {
     const int q = floor_div(2 * E * r * Sl - S0 + 2 * S0 - 1, 2 * S0);
@@ -1318,6 +1321,7 @@ bool make_fwd_win_geom(const LevelGeom& lg, int levels, int points, int Nq, Valu
   const int passes = (nq_max + 15) / 16;
   const int rounds = (passes + 15) / 16;
   int nw = (passes + rounds - 1) / rounds;
+  if (nw_req > 0) nw = nw_req;
   if (nw < 4) nw = 4;
   if (nw > 16) nw = 16;
   fw->waves = nw;
@@ -1434,7 +1438,13 @@ extern "C" int dskd_msda_fwd(const void* value, const int64_t* spatial_shapes,
       ValueGeom vg;
       FwdWinGeom fw;
       size_t lds = 0;
-      if (fv && fv[0] == 'w' && Nq == Nv && make_fwd_win_geom(g, levels, points, Nq, &vg, &fw, &lds)) {
+      // tuning knobs of the experiment: first level held in LDS (0..3), waves per workgroup (0 = automatic)
+      const char* e_lv0 = getenv("DSKD_MSDA_FWD_LV0");
+      const char* e_nw = getenv("DSKD_MSDA_FWD_NW");
+      int lv0 = e_lv0 ? atoi(e_lv0) : 0;
+      if (lv0 < 0 || lv0 > 3) lv0 = 0;
+      const int nw_req = e_nw ? atoi(e_nw) : 0;
+      if (fv && fv[0] == 'w' && Nq == Nv && make_fwd_win_geom(g, levels, points, Nq, lv0, nw_req, &vg, &fw, &lds)) {
         if (int rc = launch_fwd_win((const __bf16*)value, loc, attn, (__bf16*)out, vg, fw, lds, B, Nq, points, st))
           return rc;
         return check_launch("dskd_msda_fwd");

@@ -86,7 +86,8 @@ int dskd_device_count(void);
  * Supported: heads == 8, ch == 32, levels <= 4, levels*points <= 16.
  * Diagnostic environment switches (A/B measurements; never needed for correct results, every
  * variant is bit-identical to the default): DSKD_MSDA_PHASES=1|2|4 (bf16 staging phases),
- * DSKD_MSDA_FWD=win (windowed bf16 forward for Nq == Nv, 4 levels x 4 points),
+ * DSKD_MSDA_FWD=win (windowed bf16 forward for Nq == Nv, 4 levels x 4 points; DSKD_MSDA_FWD_LV0=0..3
+ * first level held in LDS, DSKD_MSDA_FWD_NW=4..16 waves per workgroup),
  * DSKD_MSDA_BWD=v1 (plain-atomics backward), DSKD_MSDA_VALUE_LAYOUT=hm|pair (layout experiment:
  * the CALLER must then pass value in that layout -- not part of the ABI).
  * ------------------------------------------------------------------------- */

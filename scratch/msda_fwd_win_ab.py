@@ -66,12 +66,26 @@ grid = dirs.view(8, 1, 1, 2) * torch.arange(1, 5).view(1, 1, 4, 1)              
 norm = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32).view(1, 4, 1, 2)
 loc = loc + (grid / norm).view(1, 1, 8, 4, 4, 2)
 gargs = (value.cuda(), shapes, loc.cuda(), attn.cuda())
+plain_s = both(args)[0]                      # plain result of the sigma-2.5 case above
 plain, win = both(gargs)
 res["grid_init_equal"] = bool(torch.equal(plain, win))
 os.environ.pop("DSKD_MSDA_FWD", None)
 res["grid_init_plain_us"] = timed(lambda: native.msda_forward_raw(*gargs))
 os.environ["DSKD_MSDA_FWD"] = "win"
 res["grid_init_win_us"] = timed(lambda: native.msda_forward_raw(*gargs))
+# knobs: first level held in LDS (the finer ones stay on the buffer-load path) x waves per workgroup
+res["grid_init_knobs"] = []
+for lv0, nw in ((1, 8), (1, 5), (1, 16), (2, 8), (2, 5), (0, 16), (3, 8)):
+    os.environ["DSKD_MSDA_FWD_LV0"], os.environ["DSKD_MSDA_FWD_NW"] = str(lv0), str(nw)
+    w2 = native.msda_forward_raw(*gargs)
+    w3 = native.msda_forward_raw(*args)          # sigma 2.5 px case: some samples leave the windows
+    res["grid_init_knobs"].append({"lv0": lv0, "waves": nw, "equal": bool(torch.equal(w2, plain)),
+                                   "equal_sigma2.5": bool(torch.equal(w3, plain_s)),
+                                   "grid_us": timed(lambda: native.msda_forward_raw(*gargs)),
+                                   "sigma2.5_us": timed(lambda: native.msda_forward_raw(*args))})
+    print(res["grid_init_knobs"][-1], flush=True)
+os.environ.pop("DSKD_MSDA_FWD_LV0")
+os.environ.pop("DSKD_MSDA_FWD_NW")
 os.environ.pop("DSKD_MSDA_FWD")
 
 # timing at the BASELINE shape (the last case's tensors)
