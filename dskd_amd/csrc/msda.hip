@@ -1432,19 +1432,17 @@ extern "C" int dskd_msda_fwd(const void* value, const int64_t* spatial_shapes,
   hipLaunchKernelGGL((msda_fwd_kernel<__bf16, false, PH>), grid, block, 0, st, (const __bf16*)value, loc, attn, \
                      (const __bf16*)nullptr, (const float*)nullptr, (__bf16*)out, g, Nv, Nq, levels * points,   \
                      points, qpb, bpi)
-    // windowed forward (encoder shape, 4 levels x 4 points): DSKD_MSDA_FWD=win (A/B switch)
-    {
-      const char* fv = getenv("DSKD_MSDA_FWD");
-      ValueGeom vg;
-      FwdWinGeom fw;
-      size_t lds = 0;
-      // tuning knobs of the experiment: first level held in LDS (0..3), waves per workgroup (0 = automatic)
+    // windowed forward (encoder shape, 4 levels x 4 points): DSKD_MSDA_FWD=win (A/B switch) with its knobs
+    // DSKD_MSDA_FWD_LV0 (first level held in LDS, 0..3) and DSKD_MSDA_FWD_NW (waves per workgroup, 0 = automatic)
+    if (const char* fv = getenv("DSKD_MSDA_FWD"); fv && fv[0] == 'w' && Nq == Nv) {
       const char* e_lv0 = getenv("DSKD_MSDA_FWD_LV0");
       const char* e_nw = getenv("DSKD_MSDA_FWD_NW");
       int lv0 = e_lv0 ? atoi(e_lv0) : 0;
       if (lv0 < 0 || lv0 > 3) lv0 = 0;
-      const int nw_req = e_nw ? atoi(e_nw) : 0;
-      if (fv && fv[0] == 'w' && Nq == Nv && make_fwd_win_geom(g, levels, points, Nq, lv0, nw_req, &vg, &fw, &lds)) {
+      ValueGeom vg;
+      FwdWinGeom fw;
+      size_t lds = 0;
+      if (make_fwd_win_geom(g, levels, points, Nq, lv0, e_nw ? atoi(e_nw) : 0, &vg, &fw, &lds)) {
         if (int rc = launch_fwd_win((const __bf16*)value, loc, attn, (__bf16*)out, vg, fw, lds, B, Nq, points, st))
           return rc;
         return check_launch("dskd_msda_fwd");
