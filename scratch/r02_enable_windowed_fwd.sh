@@ -1,0 +1,23 @@
+#!/usr/bin/env bash
+# First GPU call of the next round: the mixed-mode windowed forward
+# (levels 2+3 in LDS, 8 waves) was measured 13-15 % faster than the plain kernel and bit-identical at
+# B=4 with the last GPU minutes of round 1 -- after the parity suite had run.  This runs the MSDA and
+# model parity tests and a short bench with it switched on, next to the default, so that it can be made
+# the encoder default (kernel-side: the DSKD_MSDA_FWD branch of dskd_msda_fwd in dskd_amd/csrc/msda.hip).
+#   gpurun --timeout 600 -- 'bash scratch/r02_enable_windowed_fwd.sh'
+set -euo pipefail
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+mkdir -p gpurun_out
+export DSKD_MSDA_FWD=win DSKD_MSDA_FWD_LV0=2 DSKD_MSDA_FWD_NW=8
+timeout -k 10 200 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_model.py -x -q -m gpu > gpurun_out/r02_win_tests.log 2>&1
+tail -3 gpurun_out/r02_win_tests.log
+timeout -k 10 170 python bench.py --steps 20 --no-cpu-baseline > gpurun_out/r02_bench_win.json 2> gpurun_out/r02_bench_win.err
+unset DSKD_MSDA_FWD DSKD_MSDA_FWD_LV0 DSKD_MSDA_FWD_NW
+timeout -k 10 170 python bench.py --steps 20 --no-cpu-baseline > gpurun_out/r02_bench_plain.json 2> gpurun_out/r02_bench_plain.err
+python - <<'PY'
+import json
+for tag in ("win", "plain"):
+    d = json.loads(open(f"gpurun_out/r02_bench_{tag}.json").read().strip().splitlines()[-1])
+    k = d["roofline"]["kernels"]
+    print(tag, d["value"], "img/s", d["ms_per_step"], "ms/step", {n: k[n]["avg_us"] for n in k})
+PY
