@@ -1016,6 +1016,11 @@ int launch_value(const float* loc, const float* attn, const T* grad_out, float* 
 // that leaves the window takes the plain buffer-load path, so the result is exact for ANY location;
 // a rejected sample reads a zero slot.  Same weights, same order of the 16 samples, same FMAs as the
 // plain kernel: bit-identical output.
+// Measured at B=4, 100x167 (profiles/r01_msda_fwd_windowed_ab.json): with ALL four levels in LDS the 104-KB
+// window leaves one workgroup per CU and the kernel is slower than the plain one (177-219 vs 162 us);
+// holding only the coarse levels (lv0 = 2: levels 2+3, 31 KB) and leaving the fine ones on the
+// buffer-load path lets two 8-wave workgroups share a CU and the texture path and the LDS work side by
+// side: 138 us, -15 %.  Experimental (DSKD_MSDA_FWD=win); not the default yet.
 //   lane = (query of the pass, 16-B part of the head's 64-B line): 16 queries per wave pass;
 //   the 16 samples are staged level by level (4 points per query: one per lane), so the level
 //   geometry of a staging step is wave-uniform.
