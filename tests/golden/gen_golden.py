@@ -15,6 +15,8 @@ takes part in the arithmetic.  What runs is the reference's code:
     python tests/golden/gen_golden.py               # rewrites tests/golden/*.npz
     python tests/golden/gen_golden.py --variants    # loss_variants_b2_l70.npz
     python tests/golden/gen_golden.py --datasplit   # data_split_cases.json
+    python tests/golden/gen_golden.py --decode      # decode_cases.npz
+    python tests/golden/gen_golden.py --head-forward  # head_forward_cases.npz
 """
 import importlib.util
 import os
@@ -407,6 +409,108 @@ def main():
         print(name, {k: float(v) for k, v in out.items() if k.startswith("loss/")})
 
 
+def main_decode():
+    """tests/golden/decode_cases.npz: the reference's teacher decode ``get_bboxes`` -> ``_get_bboxes_single``
+    (gfl_deformable_detr_head_il.py:1535-1668) -> ``filter_scores_and_topk`` (core/utils/misc.py:119-165) on
+    seeded head outputs: many candidates (top-100 cut, queries kept twice), a few, none, and rescale."""
+    ref = load_reference()
+    H = ref["head"]
+    cls_ = H.GFLDeformableDETRHead_il
+    self = types.SimpleNamespace()
+    self.num_query, self.num_classes = 300, 80
+    self.test_cfg = dict(max_per_img=100, score_thr=0.3)
+    self.loss_cls = ref["losses"]["gfocal_loss"].QualityFocalLoss(use_sigmoid=True, beta=2.0, loss_weight=2.0)
+    self.integral_average = H.Integral_average(16)
+    for name in ("get_bboxes", "_get_bboxes_single"):
+        setattr(self, name, types.MethodType(getattr(cls_, name), self))
+    flat = {}
+    g = torch.Generator().manual_seed(404)
+    for tag, shift, rescale, cfg in (("many", -3.0, False, None), ("few", -6.5, False, None), ("none", -12.0, False, None),
+                                     ("rescale", -4.0, True, None), ("cfg", -3.0, False, dict(max_per_img=17, score_thr=0.45))):
+        B = 2
+        cls = torch.randn(1, B, 300, 80, generator=g) * 2 + shift       # get_bboxes reads the last layer only
+        box = torch.rand(1, B, 300, 70, generator=g) * 0.9 + 0.05
+        metas = [dict(img_shape=(72, 112, 3), scale_factor=np.array([1.25, 1.5, 1.25, 1.5], dtype=np.float32)),
+                 dict(img_shape=(640, 427, 3), scale_factor=np.array([0.8, 0.8, 0.8, 0.8], dtype=np.float32))]
+        with torch.no_grad():
+            out = self.get_bboxes(cls, box, None, None, img_metas=metas, rescale=rescale, cfg=cfg, need_logits=True)
+        flat[f"{tag}/cls"], flat[f"{tag}/box"] = cls.numpy(), box.numpy()
+        flat[f"{tag}/rescale"] = np.array(int(rescale))
+        flat[f"{tag}/cfg"] = np.array([cfg["max_per_img"], cfg["score_thr"]] if cfg else [100, 0.3], dtype=np.float64)
+        for i, (db, dl, dlog, keep) in enumerate(out):
+            flat[f"{tag}/{i}/bboxes"], flat[f"{tag}/{i}/labels"] = db.numpy(), dl.numpy()
+            flat[f"{tag}/{i}/logits"], flat[f"{tag}/{i}/keepid"] = dlog.numpy(), keep.numpy()
+            flat[f"{tag}/{i}/img_shape"] = np.array(metas[i]["img_shape"])
+            flat[f"{tag}/{i}/scale_factor"] = metas[i]["scale_factor"]
+        print(tag, [tuple(o[0].shape) for o in out], "queries kept twice:",
+              [int(len(o[3]) - len(torch.unique(o[3]))) for o in out])
+    np.savez_compressed(os.path.join(OUT, "decode_cases.npz"), **flat)
+
+
+def main_head_forward():
+    """tests/golden/head_forward_cases.npz: the reference's ``GFLDeformableDETRHead_il.forward``
+    (gfl_deformable_detr_head_il.py:196-281) with its own ``SinePositionalEncoding``
+    (models/utils/positional_encoding.py:11-100) around a STUB transformer that returns seeded tensors
+    and records what it was handed: padding masks (nearest interpolation of the image mask), sine
+    encodings, query embedding; and the per-layer class / box branches with the reference-point
+    shift on the first two box channels and the sigmoid on all of them."""
+    ref = load_reference()
+    _mod("mmcv.cnn.bricks", )
+    _mod("mmcv.cnn.bricks.transformer", POSITIONAL_ENCODING=_Registry("pe"))
+    pe_mod = _load("mmdet.models.utils.positional_encoding", "mmdet/models/utils/positional_encoding.py")
+    H = ref["head"]
+    D, Q, nl, C, RC = 32, 40, 6, 80, 70          # the arithmetic does not depend on 300 queries; keeps the fixture small
+    flat = {}
+    for tag, B, bis, shapes_img, feat_hw in (("full", 2, (64, 96), [(64, 96), (64, 96)], [(8, 12), (4, 6), (2, 3)]),
+                                             ("padded", 3, (72, 112), [(72, 112), (50, 112), (72, 61)], [(9, 14), (5, 7), (3, 4)])):
+        g = torch.Generator().manual_seed({"full": 31, "padded": 32}[tag])
+        cls_b = nn.Linear(D, C)
+        reg_b = nn.Sequential(nn.Linear(D, D), nn.ReLU(), nn.Linear(D, D), nn.ReLU(), nn.Linear(D, RC))
+        with torch.no_grad():
+            for prm in list(cls_b.parameters()) + list(reg_b.parameters()):
+                prm.copy_(torch.randn(prm.shape, generator=g) * 0.3)
+        emb = nn.Embedding(Q, 2 * D)
+        with torch.no_grad():
+            emb.weight.copy_(torch.randn(Q, 2 * D, generator=g))
+        N = sum(h * w for h, w in feat_hw)
+        ret = dict(hs=torch.randn(nl, Q, B, D, generator=g), init=torch.rand(B, Q, 2, generator=g) * 0.98 + 0.01,
+                   memory=torch.randn(N, B, D, generator=g))
+        # without box refinement the decoder hands back the SAME reference points for every layer
+        # (models/utils/transformer.py:686-703: they only move when reg_branches is given)
+        ret["inter"] = ret["init"].unsqueeze(0).expand(nl, -1, -1, -1).clone()
+        seen = {}
+
+        def transformer(mlvl_feats, mlvl_masks, query_embeds, mlvl_pos, reg_branches=None, cls_branches=None, **kw):
+            seen.update(masks=mlvl_masks, pos=mlvl_pos, query=query_embeds, reg=reg_branches, cls=cls_branches)
+            return ret["hs"], ret["init"], ret["inter"], ret["memory"], None, None
+
+        self = types.SimpleNamespace(as_two_stage=False, with_box_refine=False, transformer=transformer,
+                                     positional_encoding=pe_mod.SinePositionalEncoding(num_feats=D // 2, normalize=True, offset=-0.5),
+                                     query_embedding=emb, cls_branches=nn.ModuleList([cls_b] * nl),
+                                     reg_branches=nn.ModuleList([reg_b] * nl))
+        feats = [torch.randn(B, D, h, w, generator=g) for h, w in feat_hw]
+        metas = [dict(img_shape=(h, w, 3), batch_input_shape=bis) for h, w in shapes_img]
+        with torch.no_grad():
+            out = H.GFLDeformableDETRHead_il.forward(self, feats, metas)
+        assert seen["reg"] is None and seen["cls"] is None and seen["query"] is emb.weight
+        flat[f"{tag}/batch_input_shape"] = np.array(bis)
+        flat[f"{tag}/img_shapes"] = np.array(shapes_img)
+        flat[f"{tag}/feat_hw"] = np.array(feat_hw)
+        for k, v in ret.items():
+            flat[f"{tag}/ret/{k}"] = v.numpy()
+        for k, v in list(cls_b.state_dict().items()):
+            flat[f"{tag}/cls_branch/{k}"] = v.numpy()
+        for k, v in list(reg_b.state_dict().items()):
+            flat[f"{tag}/reg_branch/{k}"] = v.numpy()
+        flat[f"{tag}/query_embedding"] = emb.weight.detach().numpy()
+        for i, (m, pe) in enumerate(zip(seen["masks"], seen["pos"])):
+            flat[f"{tag}/mask{i}"], flat[f"{tag}/pos{i}"] = m.numpy(), pe.numpy()
+        flat[f"{tag}/out/cls"], flat[f"{tag}/out/box"] = out[0].numpy(), out[1].numpy()
+        assert torch.equal(out[3], ret["hs"].permute(0, 2, 1, 3)) and out[2] is ret["memory"]   # 4th output: hs, batch-first
+        print(tag, tuple(out[0].shape), tuple(out[1].shape), [int(m.sum()) for m in seen["masks"]])
+    np.savez_compressed(os.path.join(OUT, "head_forward_cases.npz"), **flat)
+
+
 def main_datasplit():
     """tests/golden/data_split_cases.json: the reference's class table and ``split_data_category``
     (mmdet/datasets/data_split.py, loaded by path: it imports nothing of mmdet) on a set of protocols."""
@@ -442,6 +546,10 @@ def main_datasplit():
 if __name__ == "__main__":
     if "--datasplit" in sys.argv:
         main_datasplit()
+    elif "--decode" in sys.argv:
+        main_decode()
+    elif "--head-forward" in sys.argv:
+        main_head_forward()
     elif "--variants" in sys.argv:
         main_variants()
     else:

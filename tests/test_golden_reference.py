@@ -253,3 +253,97 @@ def test_logit_and_localisation_distillation_vs_reference(tag, cates_distill, lo
             assert float(g[0][:-1].abs().max()) == 0.0
         if f"{tag}/grad_box_last/{key}" in v.files:
             torch.testing.assert_close(g[1][-1], t(v[f"{tag}/grad_box_last/{key}"]), rtol=1e-3, atol=1e-9)
+
+
+@pytest.mark.parametrize("tag", ["many", "few", "none", "rescale", "cfg"])
+def test_teacher_decode_vs_reference(tag):
+    """``get_bboxes`` -> ``_get_bboxes_single`` -> ``filter_scores_and_topk`` of our head
+    against the outputs of the reference's own methods (gfl_deformable_detr_head_il.py:1535-1668,
+    core/utils/misc.py:119-165; tests/golden/gen_golden.py --decode): sigmoid scores > thr, sorted
+    descending, top-k (query, class) PAIRS -- a query can be kept twice --, boxes from the integral of
+    the 4 x 17 bins, clamped to the un-padded image, optionally rescaled; logits = the sigmoid rows;
+    keepid = the query index.  Integer outputs must be equal."""
+    import types
+
+    from dskd_amd.gfl_deformable_detr_head_il import GFLDeformableDETRHead_il, Integral_average
+    z = np.load(os.path.join(G, "decode_cases.npz"))
+    head = types.SimpleNamespace(num_query=300, num_classes=80, test_cfg=dict(max_per_img=100, score_thr=0.3),
+                                 loss_cls=plosses.QualityFocalLoss(use_sigmoid=True, beta=2.0, loss_weight=2.0),
+                                 integral_average=Integral_average(16))
+    for name in ("get_bboxes", "_get_bboxes_single"):
+        setattr(head, name, types.MethodType(getattr(GFLDeformableDETRHead_il, name), head))
+    cls, box = t(z[f"{tag}/cls"]), t(z[f"{tag}/box"])
+    B = cls.shape[1]
+    metas = [dict(img_shape=tuple(int(v) for v in z[f"{tag}/{i}/img_shape"]), scale_factor=z[f"{tag}/{i}/scale_factor"])
+             for i in range(B)]
+    mp, thr = z[f"{tag}/cfg"]
+    cfg = None if (int(mp), float(thr)) == (100, 0.3) else dict(max_per_img=int(mp), score_thr=float(thr))
+    out = head.get_bboxes(cls, box, None, None, img_metas=metas, rescale=bool(z[f"{tag}/rescale"]), cfg=cfg,
+                          need_logits=True)
+    assert len(out) == B
+    twice = 0
+    for i, (bboxes, labels, logits, keepid) in enumerate(out):
+        assert torch.equal(labels, t(z[f"{tag}/{i}/labels"])) and torch.equal(keepid, t(z[f"{tag}/{i}/keepid"]))
+        torch.testing.assert_close(bboxes, t(z[f"{tag}/{i}/bboxes"]), rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(logits, t(z[f"{tag}/{i}/logits"]), rtol=1e-6, atol=1e-7)
+        assert bboxes.shape == (len(labels), 5) and logits.shape == (len(labels), 80)
+        twice += len(keepid) - len(torch.unique(keepid))
+    if tag == "many":
+        assert twice > 0 and all(len(o[1]) == 100 for o in out)      # the fixture does exercise both properties
+    if tag == "none":
+        assert all(len(o[1]) == 0 for o in out)
+    # two-tuple form without need_logits
+    two = head.get_bboxes(cls, box, None, None, img_metas=metas, rescale=bool(z[f"{tag}/rescale"]), cfg=cfg)
+    assert len(two[0]) == 2 and torch.equal(two[0][1], out[0][1])
+
+
+@pytest.mark.parametrize("tag", ["full", "padded"])
+def test_head_forward_vs_reference(tag):
+    """SURVEY.md 8a rows A2 + A5: our head's ``forward`` around a stub transformer against the reference's
+    own ``forward`` + ``SinePositionalEncoding`` run the same way (tests/golden/gen_golden.py --head-forward):
+    padding masks per level (nearest interpolation of the image mask), sine encodings, what the transformer
+    is handed, and the class / box branches -- ours runs the six shared per-layer heads as ONE batched call
+    -- with ``inverse_sigmoid(reference)`` added to the first two box channels and the sigmoid on all 70.
+    'padded': images smaller than the batch canvas; 'full': the un-padded fast path (cached encodings)."""
+    import types
+
+    import torch.nn as nn
+
+    from dskd_amd.gfl_deformable_detr_head_il import GFLDeformableDETRHead_il
+    from dskd_amd.transformer import SinePositionalEncoding
+    z = np.load(os.path.join(G, "head_forward_cases.npz"))
+    D, nl = 32, 6
+    cls_b = nn.Linear(D, 80)
+    reg_b = nn.Sequential(nn.Linear(D, D), nn.ReLU(), nn.Linear(D, D), nn.ReLU(), nn.Linear(D, 70))
+    cls_b.load_state_dict({k.split("/")[-1]: t(z[k]) for k in z.files if k.startswith(f"{tag}/cls_branch/")})
+    reg_b.load_state_dict({k.split("/")[-1]: t(z[k]) for k in z.files if k.startswith(f"{tag}/reg_branch/")})
+    emb = nn.Embedding(*z[f"{tag}/query_embedding"].shape)
+    emb.weight.data.copy_(t(z[f"{tag}/query_embedding"]))
+    ret = {k: t(z[f"{tag}/ret/{k}"]) for k in ("hs", "init", "inter", "memory")}
+    seen = {}
+
+    def transformer(mlvl_feats, mlvl_masks, query_embeds, mlvl_pos, reg_branches=None, cls_branches=None, **kw):
+        seen.update(masks=mlvl_masks, pos=mlvl_pos, query=query_embeds, reg=reg_branches, cls=cls_branches, kw=kw)
+        return ret["hs"], ret["init"], ret["inter"], ret["memory"], None, None
+
+    head = types.SimpleNamespace(as_two_stage=False, with_box_refine=False, transformer=transformer, query_embedding=emb,
+                                 positional_encoding=SinePositionalEncoding(num_feats=D // 2, normalize=True, offset=-0.5),
+                                 cls_branches=nn.ModuleList([cls_b] * nl), reg_branches=nn.ModuleList([reg_b] * nl))
+    head._forward = types.MethodType(GFLDeformableDETRHead_il._forward, head)
+    bis = tuple(int(v) for v in z[f"{tag}/batch_input_shape"])
+    metas = [dict(img_shape=(int(h), int(w), 3), batch_input_shape=bis) for h, w in z[f"{tag}/img_shapes"]]
+    B = len(metas)
+    feats = [torch.zeros(B, D, int(h), int(w)) for h, w in z[f"{tag}/feat_hw"]]
+    for rep in range(2):                                  # second call: the cached encodings of the un-padded path
+        with torch.no_grad():
+            cls, box, memory, hs = GFLDeformableDETRHead_il.forward(head, feats, metas)
+        assert seen["reg"] is None and seen["cls"] is None and seen["query"] is emb.weight
+        assert seen["kw"].get("all_valid", False) == (tag == "full")
+        for i in range(len(feats)):
+            assert torch.equal(seen["masks"][i], t(z[f"{tag}/mask{i}"]))
+            torch.testing.assert_close(seen["pos"][i], t(z[f"{tag}/pos{i}"]), rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(cls, t(z[f"{tag}/out/cls"]), rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(box, t(z[f"{tag}/out/box"]), rtol=1e-5, atol=1e-6)
+        assert torch.equal(hs, ret["hs"].permute(0, 2, 1, 3)) and memory is ret["memory"]
+    if tag == "padded":
+        assert sum(int(m.sum()) for m in seen["masks"]) > 0
