@@ -17,6 +17,7 @@ takes part in the arithmetic.  What runs is the reference's code:
     python tests/golden/gen_golden.py --datasplit   # data_split_cases.json
     python tests/golden/gen_golden.py --decode      # decode_cases.npz
     python tests/golden/gen_golden.py --head-forward  # head_forward_cases.npz
+    python tests/golden/gen_golden.py --transformer-forward  # transformer_forward_cases.npz
 """
 import importlib.util
 import os
@@ -511,6 +512,95 @@ def main_head_forward():
     np.savez_compressed(os.path.join(OUT, "head_forward_cases.npz"), **flat)
 
 
+def load_reference_transformer():
+    """The reference's mmdet/models/utils/transformer.py, loaded with dummy classes for the ext-mmcv names
+    it imports (layers, attention op: none of them is run here -- encoder / decoder are stubbed)."""
+    class _Dummy(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+    if "mmcv" not in sys.modules:
+        load_reference()
+    cnn = sys.modules["mmcv.cnn"]
+    for k in ("build_activation_layer", "build_conv_layer", "build_norm_layer", "xavier_init"):
+        setattr(cnn, k, None)
+    _mod("mmcv.cnn.bricks")
+    _mod("mmcv.cnn.bricks.registry", TRANSFORMER_LAYER=_Registry("tl"), TRANSFORMER_LAYER_SEQUENCE=_Registry("tls"))
+    _mod("mmcv.cnn.bricks.transformer", BaseTransformerLayer=_Dummy, TransformerLayerSequence=_Dummy,
+         build_transformer_layer_sequence=None, POSITIONAL_ENCODING=_Registry("pe"))
+    _mod("mmcv.runner.base_module", BaseModule=_Dummy)
+    sys.modules["mmcv.utils"].to_2tuple = lambda x: (x, x)
+    _mod("mmcv.ops.multi_scale_deform_attn", MultiScaleDeformableAttention=_Dummy)
+    _load("mmdet.models.utils.builder", "mmdet/models/utils/builder.py")
+    return _load("mmdet.models.utils.ref_transformer", "mmdet/models/utils/transformer.py")
+
+
+def main_transformer_forward():
+    """tests/golden/transformer_forward_cases.npz: the reference's ``DeformableDetrTransformer.forward``
+    (models/utils/transformer.py:875-1055, with its ``get_valid_ratio`` :865-873 and
+    ``get_reference_points`` :830-863) around STUB encoder / decoder that return seeded tensors and record
+    what they are handed: flattened features, level-embedded positional encodings, padding mask, valid
+    ratios, encoder reference points, level start indices; query / query_pos split, decoder reference
+    points ``sigmoid(Linear(query_pos))``."""
+    tr = load_reference_transformer()
+    cls_ = tr.DeformableDetrTransformer
+    D, Q, nl = 32, 20, 6
+    flat = {}
+    for tag, B, canvas, img_hw, feat_hw in (("full", 2, (64, 96), [(64, 96), (64, 96)], [(8, 12), (4, 6), (2, 3), (1, 2)]),
+                                            ("padded", 3, (72, 112), [(72, 112), (50, 112), (72, 61)],
+                                             [(9, 14), (5, 7), (3, 4), (2, 2)])):
+        g = torch.Generator().manual_seed({"full": 41, "padded": 42}[tag])
+        N = sum(h * w for h, w in feat_hw)
+        feats = [torch.randn(B, D, h, w, generator=g) for h, w in feat_hw]
+        img_mask = torch.ones(B, *canvas)
+        for i, (h, w) in enumerate(img_hw):
+            img_mask[i, :h, :w] = 0
+        masks = [torch.nn.functional.interpolate(img_mask[None], size=hw).to(torch.bool).squeeze(0) for hw in feat_hw]
+        pos = [torch.randn(B, D, h, w, generator=g) for h, w in feat_hw]
+        query_embed = torch.randn(Q, 2 * D, generator=g)
+        ref_lin = nn.Linear(D, 2)
+        with torch.no_grad():
+            ref_lin.weight.copy_(torch.randn(2, D, generator=g) * 0.3)
+            ref_lin.bias.copy_(torch.randn(2, generator=g) * 0.3)
+        level_embeds = torch.randn(len(feat_hw), D, generator=g)
+        enc_ret = torch.randn(N, B, D, generator=g)
+        dec_ret = (torch.randn(nl, Q, B, D, generator=g), torch.rand(nl, B, Q, 2, generator=g))
+        seen = {}
+
+        def encoder(**kw):
+            seen["enc"] = kw
+            return enc_ret
+
+        def decoder(**kw):
+            seen["dec"] = kw
+            return dec_ret
+
+        self = types.SimpleNamespace(as_two_stage=False, encoder=encoder, decoder=decoder, level_embeds=level_embeds,
+                                     reference_points=ref_lin, get_reference_points=cls_.get_reference_points)
+        self.get_valid_ratio = types.MethodType(cls_.get_valid_ratio, self)
+        with torch.no_grad():
+            out = cls_.forward(self, feats, masks, query_embed, pos, reg_branches=None, cls_branches=None)
+        flat[f"{tag}/canvas"], flat[f"{tag}/img_hw"], flat[f"{tag}/feat_hw"] = np.array(canvas), np.array(img_hw), np.array(feat_hw)
+        for i in range(len(feat_hw)):
+            flat[f"{tag}/feat{i}"], flat[f"{tag}/mask{i}"], flat[f"{tag}/pos{i}"] = feats[i].numpy(), masks[i].numpy(), pos[i].numpy()
+        flat[f"{tag}/query_embed"], flat[f"{tag}/level_embeds"] = query_embed.numpy(), level_embeds.numpy()
+        flat[f"{tag}/ref_w"], flat[f"{tag}/ref_b"] = ref_lin.weight.detach().numpy(), ref_lin.bias.detach().numpy()
+        flat[f"{tag}/enc_ret"], flat[f"{tag}/dec_ret0"], flat[f"{tag}/dec_ret1"] = enc_ret.numpy(), dec_ret[0].numpy(), dec_ret[1].numpy()
+        e, d = seen["enc"], seen["dec"]
+        assert e["key"] is None and e["value"] is None and d["key"] is None and d["reg_branches"] is None
+        for k in ("query", "query_pos", "query_key_padding_mask", "spatial_shapes", "reference_points", "level_start_index",
+                  "valid_ratios"):
+            flat[f"{tag}/enc/{k}"] = e[k].numpy()
+        for k in ("query", "value", "query_pos", "key_padding_mask", "reference_points", "spatial_shapes", "level_start_index",
+                  "valid_ratios"):
+            flat[f"{tag}/dec/{k}"] = d[k].numpy()
+        inter_states, init_ref, inter_refs, info_all, a, b = out
+        assert a is None and b is None and inter_states is dec_ret[0] and inter_refs is dec_ret[1]
+        flat[f"{tag}/out/init_reference"] = init_ref.numpy()
+        flat[f"{tag}/out/memory"], flat[f"{tag}/out/spatial_shapes"] = info_all[0].numpy(), info_all[1].numpy()
+        print(tag, {k: tuple(v.shape) for k, v in e.items() if torch.is_tensor(v)}, float(e["valid_ratios"].min()))
+    np.savez_compressed(os.path.join(OUT, "transformer_forward_cases.npz"), **flat)
+
+
 def main_datasplit():
     """tests/golden/data_split_cases.json: the reference's class table and ``split_data_category``
     (mmdet/datasets/data_split.py, loaded by path: it imports nothing of mmdet) on a set of protocols."""
@@ -550,6 +640,8 @@ if __name__ == "__main__":
         main_decode()
     elif "--head-forward" in sys.argv:
         main_head_forward()
+    elif "--transformer-forward" in sys.argv:
+        main_transformer_forward()
     elif "--variants" in sys.argv:
         main_variants()
     else:

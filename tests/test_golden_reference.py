@@ -347,3 +347,73 @@ def test_head_forward_vs_reference(tag):
         assert torch.equal(hs, ret["hs"].permute(0, 2, 1, 3)) and memory is ret["memory"]
     if tag == "padded":
         assert sum(int(m.sum()) for m in seen["masks"]) > 0
+
+
+@pytest.mark.parametrize("tag", ["full", "padded"])
+def test_transformer_forward_vs_reference(tag):
+    """SURVEY.md 8a rows A2 (+ the decoder hand-over of A4): our ``DeformableDetrTransformer.forward`` around
+    stub encoder / decoder against the reference's own ``forward`` run the same way (models/utils/
+    transformer.py:830-873, :875-1055; tests/golden/gen_golden.py --transformer-forward).  Ours feeds
+    the encoder batch-first and skips the masks when no image is padded, so the comparison is up to
+    that layout: flattened features, level-embedded encodings, padding mask, valid ratios, encoder
+    reference points, level starts, the query / query_pos split and ``sigmoid(Linear(query_pos))``."""
+    import types
+
+    import torch.nn as nn
+
+    from dskd_amd.transformer import DeformableDetrTransformer
+    z = np.load(os.path.join(G, "transformer_forward_cases.npz"))
+    feat_hw = [tuple(int(v) for v in hw) for hw in z[f"{tag}/feat_hw"]]
+    L = len(feat_hw)
+    feats = [t(z[f"{tag}/feat{i}"]) for i in range(L)]
+    masks = [t(z[f"{tag}/mask{i}"]) for i in range(L)]
+    pos = [t(z[f"{tag}/pos{i}"]) for i in range(L)]
+    ref_lin = nn.Linear(32, 2)
+    ref_lin.weight.data.copy_(t(z[f"{tag}/ref_w"]))
+    ref_lin.bias.data.copy_(t(z[f"{tag}/ref_b"]))
+    enc_ret, dec_ret = t(z[f"{tag}/enc_ret"]), (t(z[f"{tag}/dec_ret0"]), t(z[f"{tag}/dec_ret1"]))
+    seen = {}
+
+    def encoder(**kw):
+        seen["enc"] = kw
+        assert kw.get("tokens_batch_first")
+        return enc_ret.permute(1, 0, 2)                     # ours runs [bs, sum HW, C]
+
+    def decoder(**kw):
+        seen["dec"] = kw
+        return dec_ret
+
+    tr = types.SimpleNamespace(as_two_stage=False, encoder=encoder, decoder=decoder, level_embeds=t(z[f"{tag}/level_embeds"]),
+                               reference_points=ref_lin, get_reference_points=DeformableDetrTransformer.get_reference_points)
+    tr.get_valid_ratio = types.MethodType(DeformableDetrTransformer.get_valid_ratio, tr)
+    full = tag == "full"
+    for rep in range(2):                                    # second call: cached reference points of the un-padded path
+        with torch.no_grad():
+            out = DeformableDetrTransformer.forward(tr, feats, masks, t(z[f"{tag}/query_embed"]), pos, reg_branches=None,
+                                                    cls_branches=None, all_valid=full)
+        e, d = seen["enc"], seen["dec"]
+        assert e["key"] is None and e["value"] is None and d["key"] is None and d["reg_branches"] is None
+        torch.testing.assert_close(e["query"].permute(1, 0, 2), t(z[f"{tag}/enc/query"]), rtol=0, atol=0)
+        torch.testing.assert_close(e["query_pos"].permute(1, 0, 2), t(z[f"{tag}/enc/query_pos"]), rtol=1e-6, atol=1e-6)
+        if full:
+            assert e["query_key_padding_mask"] is None and d["key_padding_mask"] is None
+            assert not bool(t(z[f"{tag}/enc/query_key_padding_mask"]).any())          # the reference's mask is all False
+        else:
+            assert torch.equal(e["query_key_padding_mask"], t(z[f"{tag}/enc/query_key_padding_mask"]))
+            assert torch.equal(d["key_padding_mask"], t(z[f"{tag}/dec/key_padding_mask"]))
+        assert [tuple(s) for s in e["spatial_shapes"]] == [tuple(int(v) for v in s) for s in z[f"{tag}/enc/spatial_shapes"]]
+        assert [int(v) for v in e["level_start_index"]] == [int(v) for v in z[f"{tag}/enc/level_start_index"]]
+        torch.testing.assert_close(e["valid_ratios"], t(z[f"{tag}/enc/valid_ratios"]), rtol=1e-6, atol=0)
+        torch.testing.assert_close(e["reference_points"], t(z[f"{tag}/enc/reference_points"]), rtol=1e-6, atol=1e-7)
+        # decoder hand-over: the reference permutes memory back to (sum HW, bs, C); ours keeps it batch-first
+        assert d.get("value_batch_first")
+        torch.testing.assert_close(d["value"].permute(1, 0, 2), t(z[f"{tag}/dec/value"]), rtol=0, atol=0)
+        torch.testing.assert_close(d["query"], t(z[f"{tag}/dec/query"]), rtol=0, atol=0)
+        torch.testing.assert_close(d["query_pos"], t(z[f"{tag}/dec/query_pos"]), rtol=0, atol=0)
+        torch.testing.assert_close(d["reference_points"], t(z[f"{tag}/dec/reference_points"]), rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(d["valid_ratios"], t(z[f"{tag}/dec/valid_ratios"]), rtol=1e-6, atol=0)
+        inter_states, init_ref, inter_refs, info_all, a, b = out
+        assert a is None and b is None and inter_states is dec_ret[0] and inter_refs is dec_ret[1]
+        torch.testing.assert_close(init_ref, t(z[f"{tag}/out/init_reference"]), rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(info_all[0], t(z[f"{tag}/out/memory"]), rtol=0, atol=0)
+        assert torch.equal(info_all[1], t(z[f"{tag}/out/spatial_shapes"]))
