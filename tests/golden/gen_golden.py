@@ -18,6 +18,7 @@ takes part in the arithmetic.  What runs is the reference's code:
     python tests/golden/gen_golden.py --decode      # decode_cases.npz
     python tests/golden/gen_golden.py --head-forward  # head_forward_cases.npz
     python tests/golden/gen_golden.py --transformer-forward  # transformer_forward_cases.npz
+    python tests/golden/gen_golden.py --decoder-loop  # decoder_loop_cases.npz
 """
 import importlib.util
 import os
@@ -601,6 +602,51 @@ def main_transformer_forward():
     np.savez_compressed(os.path.join(OUT, "transformer_forward_cases.npz"), **flat)
 
 
+def main_decoder_loop():
+    """tests/golden/decoder_loop_cases.npz: the reference's ``DeformableDetrTransformerDecoder.forward``
+    (models/utils/transformer.py:639-709) over STUB layers that return seeded tensors and record the
+    reference points they are handed (``reference_points[:, :, None] * valid_ratios[:, None]``), without
+    and with ``reg_branches`` (iterative refinement of the reference points, detached)."""
+    tr = load_reference_transformer()
+    cls_ = tr.DeformableDetrTransformerDecoder
+    D, Q, B, nl, L = 16, 12, 2, 3, 4
+    flat = {}
+    for tag, refine in (("plain", False), ("refine", True)):
+        g = torch.Generator().manual_seed({"plain": 51, "refine": 52}[tag])
+        query = torch.randn(Q, B, D, generator=g)
+        ref = torch.rand(B, Q, 2, generator=g) * 0.9 + 0.05
+        vr = torch.rand(B, L, 2, generator=g) * 0.5 + 0.5
+        outs = [torch.randn(Q, B, D, generator=g) for _ in range(nl)]
+        regs = None
+        if refine:
+            regs = nn.ModuleList([nn.Linear(D, 2) for _ in range(nl)])
+            with torch.no_grad():
+                for m in regs:
+                    m.weight.copy_(torch.randn(2, D, generator=g) * 0.3)
+                    m.bias.copy_(torch.randn(2, generator=g) * 0.3)
+        seen = []
+
+        def make_layer(i):
+            def layer(output, *a, reference_points=None, **kw):
+                seen.append(dict(inp=output, ref=reference_points, kw=kw))
+                return outs[i]
+            return layer
+        self = types.SimpleNamespace(layers=[make_layer(i) for i in range(nl)], return_intermediate=True)
+        with torch.no_grad():
+            inter, inter_ref = cls_.forward(self, query, reference_points=ref, valid_ratios=vr, reg_branches=regs,
+                                            key=None, value=None, spatial_shapes="passed-through")
+        assert all(c["kw"]["spatial_shapes"] == "passed-through" for c in seen)
+        flat[f"{tag}/query"], flat[f"{tag}/ref"], flat[f"{tag}/valid_ratios"] = query.numpy(), ref.numpy(), vr.numpy()
+        for i in range(nl):
+            flat[f"{tag}/layer_out{i}"] = outs[i].numpy()
+            flat[f"{tag}/layer_in{i}"], flat[f"{tag}/layer_ref{i}"] = seen[i]["inp"].numpy(), seen[i]["ref"].numpy()
+            if refine:
+                flat[f"{tag}/reg_w{i}"], flat[f"{tag}/reg_b{i}"] = regs[i].weight.detach().numpy(), regs[i].bias.detach().numpy()
+        flat[f"{tag}/inter"], flat[f"{tag}/inter_ref"] = inter.numpy(), inter_ref.numpy()
+        print(tag, tuple(inter.shape), tuple(inter_ref.shape))
+    np.savez_compressed(os.path.join(OUT, "decoder_loop_cases.npz"), **flat)
+
+
 def main_datasplit():
     """tests/golden/data_split_cases.json: the reference's class table and ``split_data_category``
     (mmdet/datasets/data_split.py, loaded by path: it imports nothing of mmdet) on a set of protocols."""
@@ -642,6 +688,8 @@ if __name__ == "__main__":
         main_head_forward()
     elif "--transformer-forward" in sys.argv:
         main_transformer_forward()
+    elif "--decoder-loop" in sys.argv:
+        main_decoder_loop()
     elif "--variants" in sys.argv:
         main_variants()
     else:

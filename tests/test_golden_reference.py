@@ -417,3 +417,43 @@ def test_transformer_forward_vs_reference(tag):
         torch.testing.assert_close(init_ref, t(z[f"{tag}/out/init_reference"]), rtol=1e-6, atol=1e-7)
         torch.testing.assert_close(info_all[0], t(z[f"{tag}/out/memory"]), rtol=0, atol=0)
         assert torch.equal(info_all[1], t(z[f"{tag}/out/spatial_shapes"]))
+
+
+@pytest.mark.parametrize("tag", ["plain", "refine"])
+def test_decoder_layer_loop_vs_reference(tag):
+    """``DeformableDetrTransformerDecoder.forward`` (models/utils/transformer.py:639-709) over stub layers
+    against the reference's own loop (tests/golden/gen_golden.py --decoder-loop): what every layer is
+    handed (previous output, reference points scaled by the valid ratios), the stacked intermediates,
+    and -- 'refine' -- the iterative reference-point update through ``reg_branches``."""
+    import types
+
+    import torch.nn as nn
+
+    from dskd_amd.transformer import DeformableDetrTransformerDecoder
+    z = np.load(os.path.join(G, "decoder_loop_cases.npz"))
+    nl = 3
+    outs = [t(z[f"{tag}/layer_out{i}"]) for i in range(nl)]
+    regs = None
+    if tag == "refine":
+        regs = nn.ModuleList([nn.Linear(16, 2) for _ in range(nl)])
+        for i, m in enumerate(regs):
+            m.weight.data.copy_(t(z[f"{tag}/reg_w{i}"]))
+            m.bias.data.copy_(t(z[f"{tag}/reg_b{i}"]))
+    seen = []
+
+    def make_layer(i):
+        def layer(output, *a, reference_points=None, **kw):
+            seen.append(dict(inp=output, ref=reference_points, kw=kw))
+            return outs[i]
+        return layer
+    dec = types.SimpleNamespace(layers=[make_layer(i) for i in range(nl)], return_intermediate=True)
+    with torch.no_grad():
+        inter, inter_ref = DeformableDetrTransformerDecoder.forward(
+            dec, t(z[f"{tag}/query"]), reference_points=t(z[f"{tag}/ref"]), valid_ratios=t(z[f"{tag}/valid_ratios"]),
+            reg_branches=regs, key=None, value=None, spatial_shapes="passed-through")
+    assert len(seen) == nl and all(c["kw"]["spatial_shapes"] == "passed-through" for c in seen)
+    for i in range(nl):
+        torch.testing.assert_close(seen[i]["inp"], t(z[f"{tag}/layer_in{i}"]), rtol=0, atol=0)
+        torch.testing.assert_close(seen[i]["ref"], t(z[f"{tag}/layer_ref{i}"]), rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(inter, t(z[f"{tag}/inter"]), rtol=0, atol=0)
+    torch.testing.assert_close(inter_ref, t(z[f"{tag}/inter_ref"]), rtol=1e-6, atol=1e-7)
