@@ -132,3 +132,120 @@ def test_decoder_layer_matches_transformers(cpu_ops, padded):
                       reference_points=ref, spatial_shapes=SHAPES, level_start_index=starts,
                       value_batch_first=True).permute(1, 0, 2)
     torch.testing.assert_close(got_bf, want, rtol=2e-4, atol=2e-4)
+
+
+def _layer_map(sd, src, dst, decoder):
+    out = {}
+    if decoder:
+        out[dst + "attentions.0.attn.in_proj_weight"] = torch.cat([sd[f"{src}self_attn.{n}_proj.weight"] for n in "qkv"], 0)
+        out[dst + "attentions.0.attn.in_proj_bias"] = torch.cat([sd[f"{src}self_attn.{n}_proj.bias"] for n in "qkv"], 0)
+        out[dst + "attentions.0.attn.out_proj.weight"] = sd[src + "self_attn.o_proj.weight"]
+        out[dst + "attentions.0.attn.out_proj.bias"] = sd[src + "self_attn.o_proj.bias"]
+    msda_src, msda_dst = ("encoder_attn.", "attentions.1.") if decoder else ("self_attn.", "attentions.0.")
+    for n in ("sampling_offsets", "attention_weights", "value_proj", "output_proj"):
+        for k in ("weight", "bias"):
+            out[f"{dst}{msda_dst}{n}.{k}"] = sd[f"{src}{msda_src}{n}.{k}"]
+    norms = ["self_attn_layer_norm", "encoder_attn_layer_norm", "final_layer_norm"] if decoder \
+        else ["self_attn_layer_norm", "final_layer_norm"]
+    for k in ("weight", "bias"):
+        for i, n in enumerate(norms):
+            out[f"{dst}norms.{i}.{k}"] = sd[f"{src}{n}.{k}"]
+        out[f"{dst}ffns.0.layers.0.0.{k}"], out[f"{dst}ffns.0.layers.1.{k}"] = sd[f"{src}mlp.fc1.{k}"], sd[f"{src}mlp.fc2.{k}"]
+    return out
+
+
+def test_whole_detector_trunk_matches_transformers_model(cpu_ops):
+    """End to end on a padded batch: ResNet-50 -> ChannelMapper -> padding masks + sine encodings + level embeddings
+    -> 2-layer deformable encoder -> query split, reference points -> 2-layer decoder, built from OUR config
+    schema (the reference's), against ``transformers``' ``DeformableDetrModel`` (independent code, no timm) on
+    mapped weights: encoder memory and every decoder layer's query embeddings ``hs`` must agree.  Covers
+    rows A1, A2, A4 and the transformer half of A5 in one piece, including our fused / batch-first
+    encoder path."""
+    import copy
+    import os
+
+    from test_resnet import _hf_to_ours as resnet_map
+
+    from dskd_amd.builder import build_detector
+    from dskd_amd.config import Config
+    transformers = pytest.importorskip("transformers")
+    m, _ = _hf()
+    Dm, Fm, Q, NL = 64, 128, 30, 2
+    hcfg = transformers.DeformableDetrConfig(
+        use_timm_backbone=False, use_pretrained_backbone=False,
+        backbone_config=transformers.ResNetConfig(out_features=["stage2", "stage3", "stage4"]),
+        d_model=Dm, encoder_layers=NL, decoder_layers=NL, encoder_attention_heads=8, decoder_attention_heads=8,
+        encoder_ffn_dim=Fm, decoder_ffn_dim=Fm, num_queries=Q, num_feature_levels=4, encoder_n_points=4, decoder_n_points=4,
+        dropout=0.0, activation_dropout=0.0, attention_dropout=0.0, activation_function="relu", two_stage=False,
+        with_box_refine=False)
+    torch.manual_seed(0)
+    hf = m.DeformableDetrModel(hcfg).eval()
+    g = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        for name, p in hf.named_parameters():
+            if not name.startswith("backbone"):
+                p.copy_(torch.randn(p.shape, generator=g) * (0.3 if p.dim() == 1 else 0.08))
+        for i in range(4):
+            hf.input_proj[i][0].bias.zero_()            # our 1x1 / 3x3 convolutions in front of GroupNorm carry no bias
+        for name, buf in hf.named_buffers():
+            if name.endswith("running_var"):
+                buf.copy_(torch.rand(buf.shape, generator=g) * 0.5 + 0.75)
+            elif name.endswith("running_mean"):
+                buf.copy_(torch.randn(buf.shape, generator=g) * 0.1)
+    sd = hf.state_dict()
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mc = copy.deepcopy(Config.fromfile(os.path.join(root, "configs", "dskd_gfl_deformable_detr_r50_70_10.py")).model)
+    mc["neck"]["out_channels"] = Dm
+    head = mc["bbox_head"]
+    head["num_query"] = Q
+    head["positional_encoding"]["num_feats"] = Dm // 2
+    ffn = dict(type="FFN", embed_dims=Dm, feedforward_channels=Fm, num_fcs=2, ffn_drop=0.0, act_cfg=dict(type="ReLU", inplace=True))
+    for part in ("encoder", "decoder"):
+        seq = head["transformer"][part]
+        seq["num_layers"] = NL
+        lay = seq["transformerlayers"]
+        lay.update(ffn_cfgs=ffn, feedforward_channels=Fm, ffn_dropout=0.0)
+        for a in (lay["attn_cfgs"] if isinstance(lay["attn_cfgs"], list) else [lay["attn_cfgs"]]):
+            a["embed_dims"] = Dm
+            if a["type"] == "MultiheadAttention":
+                a["dropout"] = 0.0
+    ours = build_detector(mc).eval()
+
+    bk = next(k for k in sd if k.endswith("embedder.embedder.convolution.weight"))
+    pre = bk[: -len("embedder.embedder.convolution.weight")]
+    bsd = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+    for k in [k for k in bsd if k.endswith("running_var")]:
+        bsd.setdefault(k.replace("running_var", "num_batches_tracked"), torch.zeros((), dtype=torch.long))
+    mapped = {"backbone." + k: v for k, v in resnet_map(bsd).items()}
+    for i in range(4):
+        dst = f"neck.convs.{i}." if i < 3 else "neck.extra_convs.0."
+        mapped[dst + "conv.weight"] = sd[f"input_proj.{i}.0.weight"]
+        mapped[dst + "gn.weight"], mapped[dst + "gn.bias"] = sd[f"input_proj.{i}.1.weight"], sd[f"input_proj.{i}.1.bias"]
+    t_ = "bbox_head.transformer."
+    mapped[t_ + "level_embeds"] = sd["level_embed"]
+    mapped[t_ + "reference_points.weight"], mapped[t_ + "reference_points.bias"] = sd["reference_points.weight"], sd["reference_points.bias"]
+    mapped["bbox_head.query_embedding.weight"] = sd["query_position_embeddings.weight"]
+    for i in range(NL):
+        mapped.update(_layer_map(sd, f"encoder.layers.{i}.", f"{t_}encoder.layers.{i}.", decoder=False))
+        mapped.update(_layer_map(sd, f"decoder.layers.{i}.", f"{t_}decoder.layers.{i}.", decoder=True))
+    missing, unexpected = ours.load_state_dict(mapped, strict=False)
+    assert not unexpected
+    assert all(k.startswith(("bbox_head.cls_branches", "bbox_head.reg_branches", "bbox_head.prototype")) for k in missing), missing
+
+    canvas, sizes = (96, 128), [(96, 128), (70, 100)]
+    img = torch.zeros(2, 3, *canvas)
+    pixel_mask = torch.zeros(2, *canvas, dtype=torch.long)
+    for i, (h, w) in enumerate(sizes):
+        img[i, :, :h, :w] = torch.randn(3, h, w, generator=g)
+        pixel_mask[i, :h, :w] = 1
+    metas = [dict(img_shape=(h, w, 3), batch_input_shape=canvas, scale_factor=1.0) for h, w in sizes]
+    with torch.no_grad():
+        want = hf(pixel_values=img, pixel_mask=pixel_mask)
+        feats = ours.extract_feat(img)
+        cls, box, (memory, shapes), hs = ours.bbox_head.forward(feats, metas)
+    assert [tuple(int(v) for v in s) for s in shapes] == [tuple(f.shape[-2:]) for f in feats]
+    torch.testing.assert_close(memory.permute(1, 0, 2), want.encoder_last_hidden_state, rtol=1e-4, atol=2e-5)   # measured: 1e-6
+    torch.testing.assert_close(hs.permute(1, 0, 2, 3), want.intermediate_hidden_states, rtol=1e-4, atol=2e-5)
+    # the reference points the box branch is shifted by: sigmoid(Linear(query_pos)), the same for both images
+    torch.testing.assert_close(want.init_reference_points[0], want.init_reference_points[1])
