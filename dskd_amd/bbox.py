@@ -31,6 +31,18 @@ def bbox_xyxy_to_cxcywh(bbox):
     return torch.cat([(x1 + x2) / 2, (y1 + y2) / 2, (x2 - x1), (y2 - y1)], dim=-1)
 
 
+def bbox2result(bboxes, labels, num_classes):
+    """/root/reference/mmdet/core/bbox/transforms.py:116-133 -- detections [n, 5] + labels [n] to the evaluation
+    format: one float32 numpy array [n_c, 5] per class."""
+    import numpy as np
+    if bboxes.shape[0] == 0:
+        return [np.zeros((0, 5), dtype=np.float32) for _ in range(num_classes)]
+    if isinstance(bboxes, torch.Tensor):
+        bboxes = bboxes.detach().cpu().numpy()
+        labels = labels.detach().cpu().numpy()
+    return [bboxes[labels == i, :] for i in range(num_classes)]
+
+
 def bbox_overlaps(bboxes1, bboxes2, mode="iou", is_aligned=False, eps=1e-6):
     assert mode in ["iou", "iof", "giou"], f"Unsupported mode {mode}"
     assert bboxes1.size(-1) == 4 or bboxes1.size(0) == 0

@@ -316,9 +316,26 @@ class DeformableDETR_il(nn.Module):
         return ta
 
     def forward(self, img, img_metas, return_loss=True, **kwargs):
+        """:190-208.  ``return_loss=False``: img / img_metas are double-nested (outer list = test-time
+        augmentations), as the reference's test pipeline hands them over."""
         if return_loss:
             return self.forward_train(img, img_metas, **kwargs)
-        return self.simple_test(img, img_metas, **kwargs)
+        return self.forward_test(img, img_metas, **kwargs)
+
+    def forward_test(self, imgs, img_metas, **kwargs):
+        """``BaseDetector.forward_test`` (/root/reference/mmdet/models/detectors/base.py:112-154): one augmentation
+        only (``aug_test`` of the reference raises NotImplementedError in its head too)."""
+        for var, name in [(imgs, "imgs"), (img_metas, "img_metas")]:
+            if not isinstance(var, list):
+                raise TypeError(f"{name} must be a list, but got {type(var)}")
+        if len(imgs) != len(img_metas):
+            raise ValueError(f"num of augmentations ({len(imgs)}) != num of image meta ({len(img_metas)})")
+        for img, img_meta in zip(imgs, img_metas):
+            for m in img_meta:
+                m["batch_input_shape"] = tuple(img.size()[-2:])
+        if len(imgs) != 1:
+            raise NotImplementedError("test-time augmentation is not implemented")
+        return self.simple_test(imgs[0], img_metas[0], **kwargs)
 
     def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None, teacher_info=None):
         """:255-318.  ``teacher_info`` may be injected (bench / tests: synthetic teacher
@@ -339,8 +356,11 @@ class DeformableDETR_il(nn.Module):
                                             teacher_info=teacher_info, task_labels=self.LableInPCNTask)
 
     def simple_test(self, img, img_metas, rescale=False):
+        """:365-387 -- per image a list with one [n_c, 5] numpy array per class (``bbox2result``)."""
+        from .bbox import bbox2result
         feat = self.extract_feat(img)
-        return self.bbox_head.simple_test(feat, img_metas, rescale=rescale)
+        results_list = self.bbox_head.simple_test(feat, img_metas, rescale=rescale)
+        return [bbox2result(det_bboxes, det_labels, self.bbox_head.num_classes) for det_bboxes, det_labels in results_list]
 
     # ------------------------------------------------------------------ step
     def _parse_losses(self, losses):

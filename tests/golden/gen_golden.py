@@ -19,6 +19,7 @@ takes part in the arithmetic.  What runs is the reference's code:
     python tests/golden/gen_golden.py --head-forward  # head_forward_cases.npz
     python tests/golden/gen_golden.py --transformer-forward  # transformer_forward_cases.npz
     python tests/golden/gen_golden.py --decoder-loop  # decoder_loop_cases.npz
+    python tests/golden/gen_golden.py --bbox2result   # bbox2result_cases.npz
 """
 import importlib.util
 import os
@@ -647,6 +648,23 @@ def main_decoder_loop():
     np.savez_compressed(os.path.join(OUT, "decoder_loop_cases.npz"), **flat)
 
 
+def main_bbox2result():
+    """tests/golden/bbox2result_cases.npz: the reference's ``bbox2result`` (core/bbox/transforms.py:116-133)."""
+    ref = load_reference()
+    g = torch.Generator().manual_seed(61)
+    flat = {}
+    for tag, n in (("some", 23), ("empty", 0)):
+        b = torch.rand(n, 5, generator=g) * 100
+        l = torch.randint(0, 7, (n,), generator=g)
+        out = ref["tr"].bbox2result(b, l, 7)
+        flat[f"{tag}/bboxes"], flat[f"{tag}/labels"] = b.numpy(), l.numpy()
+        for c, a in enumerate(out):
+            assert a.dtype == np.float32
+            flat[f"{tag}/out{c}"] = a
+    np.savez_compressed(os.path.join(OUT, "bbox2result_cases.npz"), **flat)
+    print("bbox2result_cases.npz")
+
+
 def main_datasplit():
     """tests/golden/data_split_cases.json: the reference's class table and ``split_data_category``
     (mmdet/datasets/data_split.py, loaded by path: it imports nothing of mmdet) on a set of protocols."""
@@ -690,6 +708,8 @@ if __name__ == "__main__":
         main_transformer_forward()
     elif "--decoder-loop" in sys.argv:
         main_decoder_loop()
+    elif "--bbox2result" in sys.argv:
+        main_bbox2result()
     elif "--variants" in sys.argv:
         main_variants()
     else:

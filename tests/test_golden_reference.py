@@ -457,3 +457,13 @@ def test_decoder_layer_loop_vs_reference(tag):
         torch.testing.assert_close(seen[i]["ref"], t(z[f"{tag}/layer_ref{i}"]), rtol=1e-6, atol=1e-7)
     torch.testing.assert_close(inter, t(z[f"{tag}/inter"]), rtol=0, atol=0)
     torch.testing.assert_close(inter_ref, t(z[f"{tag}/inter_ref"]), rtol=1e-6, atol=1e-7)
+
+
+def test_bbox2result_vs_reference():
+    """Evaluation format of the detections (core/bbox/transforms.py:116-133; gen_golden.py --bbox2result)."""
+    z = np.load(os.path.join(G, "bbox2result_cases.npz"))
+    for tag in ("some", "empty"):
+        out = pbbox.bbox2result(t(z[f"{tag}/bboxes"]), t(z[f"{tag}/labels"]), 7)
+        assert len(out) == 7
+        for c, a in enumerate(out):
+            assert a.dtype == np.float32 and a.shape == z[f"{tag}/out{c}"].shape and np.array_equal(a, z[f"{tag}/out{c}"])

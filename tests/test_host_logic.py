@@ -303,3 +303,39 @@ def test_deepcopy_drops_runtime_accelerator_state():
     for (n, a), (_, b) in zip(m.state_dict().items(), c.state_dict().items()):
         assert torch.equal(a, b) and a.data_ptr() != b.data_ptr(), n
     assert c.bbox_head is not m.bbox_head and c.bbox_head.transformer is not m.bbox_head.transformer
+
+
+def test_inference_surface_returns_the_reference_format(cpu_ops):
+    """``model(return_loss=False, img=[...], img_metas=[[...]])`` (reference ``BaseDetector.forward_test`` base.py:112-154
+    -> ``simple_test`` deformable_detr_il.py:365-387): double-nested inputs, ``batch_input_shape`` filled in,
+    per image one [n_c, 5] float32 array per class; more than one augmentation is refused."""
+    import copy
+    import os
+
+    import numpy as np
+
+    from dskd_amd.builder import build_detector
+    from dskd_amd.config import Config
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mc = copy.deepcopy(Config.fromfile(os.path.join(root, "configs", "dskd_gfl_deformable_detr_r50_70_10.py")).model)
+    for part in ("encoder", "decoder"):
+        mc["bbox_head"]["transformer"][part]["num_layers"] = 1
+    mc["bbox_head"]["num_query"] = 20
+    torch.manual_seed(0)
+    model = build_detector(mc)
+    model.init_weights()
+    model.eval()
+    img = torch.randn(2, 3, 64, 96)
+    metas = [dict(img_shape=(64, 96, 3), scale_factor=1.0), dict(img_shape=(50, 96, 3), scale_factor=1.0)]
+    with torch.no_grad():
+        res = model(return_loss=False, img=[img], img_metas=[metas], rescale=False)
+    assert metas[0]["batch_input_shape"] == (64, 96)
+    assert len(res) == 2 and all(len(r) == 80 for r in res)
+    for r in res:
+        for a in r:
+            assert isinstance(a, np.ndarray) and a.dtype == np.float32 and a.ndim == 2 and a.shape[1] == 5
+        assert sum(len(a) for a in r) <= 100                                  # test_cfg max_per_img
+    with pytest.raises(TypeError):
+        model(return_loss=False, img=img, img_metas=[metas])
+    with pytest.raises(NotImplementedError):
+        model(return_loss=False, img=[img, img], img_metas=[metas, metas])
