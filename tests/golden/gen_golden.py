@@ -20,6 +20,7 @@ takes part in the arithmetic.  What runs is the reference's code:
     python tests/golden/gen_golden.py --transformer-forward  # transformer_forward_cases.npz
     python tests/golden/gen_golden.py --decoder-loop  # decoder_loop_cases.npz
     python tests/golden/gen_golden.py --bbox2result   # bbox2result_cases.npz
+    python tests/golden/gen_golden.py --ragged        # loss_ragged_*.npz
 """
 import importlib.util
 import os
@@ -412,6 +413,35 @@ def main():
         print(name, {k: float(v) for k, v in out.items() if k.startswith("loss/")})
 
 
+def main_ragged():
+    """tests/golden/loss_ragged_*.npz: the reference's loss() on RAGGED batches -- the second image carries no
+    teacher detection, no ground truth, or neither (then its matching problems are empty) -- same format
+    as loss_b2_l70.npz, 60 queries to keep the fixtures small."""
+    ref = load_reference()
+    B, L, shapes, img_hw, n_t, Q = 2, 70, [(9, 14), (5, 7)], [(72, 112), (70, 100)], 4, 60
+    for case in ("no_teacher_boxes", "no_gt", "empty"):
+        inp = make_loss_inputs(B, L, 21, shapes, img_hw, n_t=n_t, Q=Q)
+        if case in ("no_teacher_boxes", "empty"):
+            inp["t_b"][1], inp["t_l"][1] = torch.zeros(0, 4), torch.zeros(0, dtype=torch.long)
+            inp["keep"] = inp["keep"][:n_t]
+        if case in ("no_gt", "empty"):
+            inp["gt_b"][1], inp["gt_l"][1] = torch.zeros(0, 4), torch.zeros(0, dtype=torch.long)
+        out = run_reference_loss(ref, inp, L, img_hw, shapes)
+        flat = {"B": np.array(B), "L": np.array(L), "shapes": np.array(shapes), "img_hw": np.array(img_hw),
+                "cls": inp["cls"].numpy(), "box": inp["box"].numpy(), "hs": inp["hs"].numpy(),
+                "hs_t_last": inp["hs_t"][-1].numpy(), "keep": inp["keep"].numpy()}
+        for i in range(len(shapes)):
+            flat[f"feat_s{i}"], flat[f"feat_t{i}"] = inp["feats_s"][i].numpy(), inp["feats_t"][i].numpy()
+        for b in range(B):
+            flat[f"gt_b{b}"], flat[f"gt_l{b}"] = inp["gt_b"][b].numpy(), inp["gt_l"][b].numpy()
+            flat[f"t_b{b}"], flat[f"t_l{b}"] = inp["t_b"][b].numpy(), inp["t_l"][b].numpy()
+        flat.update(out)
+        flat.pop("grad/cls")
+        flat["grad/cls_sum_abs"] = np.abs(out["grad/cls"]).sum(axis=-1)
+        np.savez_compressed(os.path.join(OUT, f"loss_ragged_{case}.npz"), **flat)
+        print(case, {k: float(v) for k, v in out.items() if k in ("loss/loss_corr", "loss/loss_fg_feature", "loss/loss_cls")})
+
+
 def main_decode():
     """tests/golden/decode_cases.npz: the reference's teacher decode ``get_bboxes`` -> ``_get_bboxes_single``
     (gfl_deformable_detr_head_il.py:1535-1668) -> ``filter_scores_and_topk`` (core/utils/misc.py:119-165) on
@@ -710,6 +740,8 @@ if __name__ == "__main__":
         main_decoder_loop()
     elif "--bbox2result" in sys.argv:
         main_bbox2result()
+    elif "--ragged" in sys.argv:
+        main_ragged()
     elif "--variants" in sys.argv:
         main_variants()
     else:

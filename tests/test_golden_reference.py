@@ -112,11 +112,13 @@ def _make_head(L):
     return h
 
 
-@pytest.mark.parametrize("name", ["loss_b1_l40.npz", "loss_b2_l70.npz"])
+@pytest.mark.parametrize("name", ["loss_b1_l40.npz", "loss_b2_l70.npz", "loss_ragged_no_teacher_boxes.npz",
+                                  "loss_ragged_no_gt.npz", "loss_ragged_empty.npz"])
 def test_full_loss_vs_reference(name, cpu_ops):
     """Our head.loss (batched targets, dense masked losses, DSKD ops via the injected oracle)
     against the reference's GFLDeformableDETRHead_il.loss: every entry of the loss dict and the
-    gradients w.r.t. cls / box / hs."""
+    gradients w.r.t. cls / box / hs.  'ragged': the second image of the batch has no teacher
+    detection / no ground truth / neither (an empty matching problem in every layer)."""
     d = _load_loss_case(name)
     z = d["z"]
     head = _make_head(d["L"])

@@ -278,3 +278,40 @@ def test_graphed_dense_losses_equal_eager():
             torch.testing.assert_close(x, y, rtol=1e-5, atol=1e-6)
     graphs = head.__dict__["_dense_graphs"]
     assert len(graphs) == 1 and all(v is not False for v in graphs.values())       # captured after two eager calls
+
+
+@pytest.mark.xfail(strict=False, reason="written after round 1's GPU minutes were spent: first executed by the round-end run; "
+                                        "the same cases pass on the CPU path (tests/test_golden_reference.py)")
+@pytest.mark.parametrize("name", ["loss_b2_l70.npz", "loss_ragged_no_teacher_boxes.npz", "loss_ragged_no_gt.npz",
+                                  "loss_ragged_empty.npz"])
+def test_head_loss_on_gpu_vs_reference_goldens(name):
+    """The head's ``loss`` on the GPU (fused cost + batched device LSAP, HIP DSKD losses) against the outputs of the
+    reference's own ``loss`` -- including RAGGED batches whose second image has no teacher detection / no ground
+    truth / neither, i.e. empty matching problems inside the batched launches."""
+    from test_golden_reference import _load_loss_case, _make_head, t
+    dev = torch.device("cuda:0")
+    d = _load_loss_case(name)
+    z = d["z"]
+    head = _make_head(d["L"])
+    cls = d["cls"].to(dev).requires_grad_(True)
+    box = d["box"].to(dev).requires_grad_(True)
+    hs = d["hs"].to(dev).requires_grad_(True)
+    fs = [f.to(dev) for f in d["feats_s"]]
+    metas = [dict(img_shape=(d["img_hw"][b][0], d["img_hw"][b][1], 3)) for b in range(d["B"])]
+    tinfo = dict(neck_feats=[f.to(dev) for f in d["feats_t"]], head_outs=(None, None, None, d["hs_t"][None].to(dev)),
+                 pred_keepid=d["keep"].to(dev), pred_labels=[x.to(dev) for x in d["t_l"]],
+                 pred_bboxes=[x.to(dev) for x in d["t_b"]])
+    losses = head.loss(cls, box, (None, torch.tensor(d["shapes"])), hs, [x.to(dev) for x in d["gt_b"]],
+                       [x.to(dev) for x in d["gt_l"]], metas, student_feat=fs, teacher_info=tinfo,
+                       task_labels={"prev": list(range(d["L"])), "curr": [], "next": []})
+    ref_keys = [k[5:] for k in z.files if k.startswith("loss/")]
+    assert sorted(losses.keys()) == sorted(ref_keys)
+    for k in ref_keys:
+        rtol = 5e-2 if k == "loss_fg_feature" else 2e-4       # decode_v1: fp32 noise of the reference itself (kernel tests)
+        torch.testing.assert_close(losses[k].detach().cpu(), t(z[f"loss/{k}"]), rtol=rtol, atol=1e-6, msg=lambda m: f"{k}: {m}")
+    sum(v for k, v in losses.items() if "loss" in k).backward()
+    torch.testing.assert_close(box.grad.cpu(), t(z["grad/box"]), rtol=2e-3, atol=1e-5)
+    torch.testing.assert_close(hs.grad.cpu(), t(z["grad/hs"]), rtol=2e-3, atol=1e-6)
+    torch.testing.assert_close(cls.grad.abs().sum(-1).cpu(), t(z["grad/cls_sum_abs"]), rtol=2e-3, atol=1e-5)
+    if head.last_lsap_status is not None:
+        native.raise_for_lsap_status(head.last_lsap_status)
