@@ -339,3 +339,33 @@ def test_inference_surface_returns_the_reference_format(cpu_ops):
         model(return_loss=False, img=img, img_metas=[metas])
     with pytest.raises(NotImplementedError):
         model(return_loss=False, img=[img, img], img_metas=[metas, metas])
+
+
+def test_gfl_hungarian_assigner_like_the_reference_test(cpu_ops):
+    """The reference's own assigner test (tests/test_utils/test_assigner.py:385-428), applied to the assigner of
+    this path (``GFLHungarianAssigner``): no ground truth -> everything background / unlabeled; with ground truth
+    every gt is matched exactly once; the plain-IoU cost mode; ``gt_bboxes_ignore`` is refused."""
+    from dskd_amd import bbox as pbbox
+    asg = pbbox.GFLHungarianAssigner(cls_cost=dict(type="QualityFocalLossCost", weight=2.0),
+                                     reg_cost=dict(type="BBoxL1Cost", weight=5.0, box_format="xywh"),
+                                     iou_cost=dict(type="IoUCost", iou_mode="giou", weight=2.0))
+    assert asg.iou_cost.iou_mode == "giou"
+    g = torch.Generator().manual_seed(0)
+    bbox_pred, cls_pred = torch.rand((10, 4), generator=g), torch.rand((10, 80), generator=g)
+    img_meta = dict(img_shape=(10, 8, 3))
+    res = asg.assign(bbox_pred, cls_pred, torch.empty((0, 4)).float(), torch.empty((0,)).long(), None, img_meta)
+    assert res.num_gts == 0 and torch.all(res.gt_inds == 0) and torch.all(res.labels == -1)
+    gt_bboxes, gt_labels = torch.FloatTensor([[0, 0, 5, 7], [3, 5, 7, 8]]), torch.LongTensor([1, 20])
+    for cfg in (dict(type="IoUCost", iou_mode="giou", weight=2.0), dict(type="IoUCost", iou_mode="iou", weight=1.0)):
+        asg = pbbox.GFLHungarianAssigner(cls_cost=dict(type="QualityFocalLossCost", weight=2.0),
+                                         reg_cost=dict(type="BBoxL1Cost", weight=5.0, box_format="xywh"), iou_cost=cfg)
+        res = asg.assign(bbox_pred, cls_pred, gt_bboxes, gt_labels, None, img_meta)
+        assert torch.all(res.gt_inds > -1)
+        assert (res.gt_inds > 0).sum() == gt_bboxes.size(0) and (res.labels > -1).sum() == gt_bboxes.size(0)
+        assert sorted(res.gt_inds[res.gt_inds > 0].tolist()) == [1, 2]
+        assert sorted(res.labels[res.labels > -1].tolist()) == [1, 20]
+    with pytest.raises(AssertionError):
+        asg.assign(bbox_pred, cls_pred, gt_bboxes, gt_labels, None, img_meta, gt_bboxes_ignore=torch.zeros(1, 4))
+    # no predictions at all
+    res = asg.assign(torch.empty((0, 4)), torch.empty((0, 80)), gt_bboxes, gt_labels, None, img_meta)
+    assert res.num_gts == 2 and len(res.gt_inds) == 0
