@@ -154,8 +154,9 @@ def _layer_map(sd, src, dst, decoder):
     return out
 
 
-def _build_trunk_pair():
-    """(HF DeformableDetrModel, our detector with its weights mapped on, padded batch) at reduced width."""
+def _build_trunk_pair(backbone="resnet"):
+    """(HF DeformableDetrModel, our detector with its weights mapped on, padded batch) at reduced width.
+    ``backbone``: 'resnet' (BASELINE configs[1]) or 'swin' (configs[3])."""
     import copy
     import os
 
@@ -167,9 +168,17 @@ def _build_trunk_pair():
     transformers = pytest.importorskip("transformers")
     m, _ = _hf()
     Dm, Fm, Q, NL = 64, 128, 30, 2
+    swin_depths, swin_heads, swin_embed = (2, 2, 2, 2), (2, 4, 8, 16), 32
+    if backbone == "resnet":
+        bcfg = transformers.ResNetConfig(out_features=["stage2", "stage3", "stage4"])
+    else:
+        bcfg = transformers.SwinConfig(image_size=224, patch_size=4, num_channels=3, embed_dim=swin_embed, depths=list(swin_depths),
+                                       num_heads=list(swin_heads), window_size=7, mlp_ratio=4.0, qkv_bias=True,
+                                       hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, drop_path_rate=0.0,
+                                       hidden_act="gelu", use_absolute_embeddings=False, layer_norm_eps=1e-5,
+                                       out_features=["stage2", "stage3", "stage4"])
     hcfg = transformers.DeformableDetrConfig(
-        use_timm_backbone=False, use_pretrained_backbone=False,
-        backbone_config=transformers.ResNetConfig(out_features=["stage2", "stage3", "stage4"]),
+        use_timm_backbone=False, use_pretrained_backbone=False, backbone_config=bcfg,
         d_model=Dm, encoder_layers=NL, decoder_layers=NL, encoder_attention_heads=8, decoder_attention_heads=8,
         encoder_ffn_dim=Fm, decoder_ffn_dim=Fm, num_queries=Q, num_feature_levels=4, encoder_n_points=4, decoder_n_points=4,
         dropout=0.0, activation_dropout=0.0, attention_dropout=0.0, activation_function="relu", two_stage=False,
@@ -191,8 +200,13 @@ def _build_trunk_pair():
     sd = hf.state_dict()
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    mc = copy.deepcopy(Config.fromfile(os.path.join(root, "configs", "dskd_gfl_deformable_detr_r50_70_10.py")).model)
+    cfg_name = "dskd_gfl_deformable_detr_r50_70_10.py" if backbone == "resnet" else "dskd_gfl_deformable_detr_swin_t_70_10.py"
+    mc = copy.deepcopy(Config.fromfile(os.path.join(root, "configs", cfg_name)).model)
     mc["neck"]["out_channels"] = Dm
+    if backbone == "swin":
+        mc["backbone"].update(embed_dims=swin_embed, depths=list(swin_depths), num_heads=list(swin_heads), drop_path_rate=0.0,
+                              convert_weights=False)
+        mc["neck"]["in_channels"] = [swin_embed * 2, swin_embed * 4, swin_embed * 8]
     head = mc["bbox_head"]
     head["num_query"] = Q
     head["positional_encoding"]["num_feats"] = Dm // 2
@@ -207,13 +221,23 @@ def _build_trunk_pair():
             a["dropout"] = 0.0                           # both attention modules drop 0.1 of their output by default
     ours = build_detector(mc).eval()
 
-    bk = next(k for k in sd if k.endswith("embedder.embedder.convolution.weight"))
-    pre = bk[: -len("embedder.embedder.convolution.weight")]
-    bsd = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
-    for k in [k for k in bsd if k.endswith("running_var")]:
-        bsd.setdefault(k.replace("running_var", "num_batches_tracked"), torch.zeros((), dtype=torch.long))
-    mapped = {"backbone." + k: v for k, v in resnet_map(bsd).items()}
-    names = {"backbone." + k: pre + hk for k, hk in _resnet_names().items()}        # ours -> HF parameter names
+    if backbone == "resnet":
+        bk = next(k for k in sd if k.endswith("embedder.embedder.convolution.weight"))
+        pre = bk[: -len("embedder.embedder.convolution.weight")]
+        bsd = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+        for k in [k for k in bsd if k.endswith("running_var")]:
+            bsd.setdefault(k.replace("running_var", "num_batches_tracked"), torch.zeros((), dtype=torch.long))
+        mapped = {"backbone." + k: v for k, v in resnet_map(bsd).items()}
+        names = {"backbone." + k: pre + hk for k, hk in _resnet_names().items()}    # ours -> HF parameter names
+    else:
+        from test_swin import _hf_to_ours as swin_map
+        bk = next(k for k in sd if k.endswith("embeddings.patch_embeddings.projection.weight"))
+        pre = bk[: -len("swin.embeddings.patch_embeddings.projection.weight")]          # 'backbone.model.'
+        bsd = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+        bsd.setdefault("hidden_states_norms.stage1.weight", torch.ones(swin_embed))   # stage 1 is not an output here
+        bsd.setdefault("hidden_states_norms.stage1.bias", torch.zeros(swin_embed))
+        mapped = {"backbone." + k: v for k, v in swin_map(bsd, swin_depths).items() if not k.startswith("norm0.")}
+        names = {}
     for i in range(4):
         dst = f"neck.convs.{i}." if i < 3 else "neck.extra_convs.0."
         mapped[dst + "conv.weight"] = sd[f"input_proj.{i}.0.weight"]
@@ -239,7 +263,8 @@ def _build_trunk_pair():
             names[f"{t_}{part}.layers.{i}.ffns.0.layers.1.bias"] = f"{part}.layers.{i}.mlp.fc2.bias"
     missing, unexpected = ours.load_state_dict(mapped, strict=False)
     assert not unexpected
-    assert all(k.startswith(("bbox_head.cls_branches", "bbox_head.reg_branches", "bbox_head.prototype")) for k in missing), missing
+    assert all(k.startswith(("bbox_head.cls_branches", "bbox_head.reg_branches", "bbox_head.prototype")) or
+               "relative_position_index" in k for k in missing), missing
 
     canvas, sizes = (96, 128), [(96, 128), (70, 100)]
     img = torch.zeros(2, 3, *canvas)
@@ -308,3 +333,17 @@ def test_whole_detector_trunk_gradients_match_transformers_model(cpu_ops):
         checked += 1
     assert checked >= 60
     assert ours_params["backbone.conv1.weight"].grad is None and ours_params["backbone.layer1.0.conv1.weight"].grad is None
+
+
+def test_whole_swin_detector_trunk_matches_transformers_model(cpu_ops):
+    """The same end-to-end comparison with the Swin backbone (BASELINE configs[3]; the reference has no Swin +
+    Deformable-DETR config, ours composes the two): window attention with shift masks and padding to the
+    window / patch sizes on a padded batch -> ChannelMapper -> encoder -> decoder against ``transformers``'
+    ``DeformableDetrModel`` built on its own ``SwinBackbone``."""
+    hf, ours, img, pixel_mask, metas, _ = _build_trunk_pair("swin")
+    with torch.no_grad():
+        want = hf(pixel_values=img, pixel_mask=pixel_mask)
+        feats = ours.extract_feat(img)
+        cls, box, (memory, shapes), hs = ours.bbox_head.forward(feats, metas)
+    torch.testing.assert_close(memory.permute(1, 0, 2), want.encoder_last_hidden_state, rtol=1e-3, atol=2e-4)
+    torch.testing.assert_close(hs.permute(1, 0, 2, 3), want.intermediate_hidden_states, rtol=1e-3, atol=2e-4)
