@@ -21,6 +21,7 @@ takes part in the arithmetic.  What runs is the reference's code:
     python tests/golden/gen_golden.py --decoder-loop  # decoder_loop_cases.npz
     python tests/golden/gen_golden.py --bbox2result   # bbox2result_cases.npz
     python tests/golden/gen_golden.py --ragged        # loss_ragged_*.npz
+    python tests/golden/gen_golden.py --two-rank      # loss_two_rank_r{0,1}.npz
 """
 import importlib.util
 import os
@@ -442,6 +443,61 @@ def main_ragged():
         print(case, {k: float(v) for k, v in out.items() if k in ("loss/loss_corr", "loss/loss_fg_feature", "loss/loss_cls")})
 
 
+def main_two_rank():
+    """tests/golden/loss_two_rank_r{0,1}.npz: the reference's loss() as TWO data-parallel ranks would evaluate it.
+    The only cross-rank coupling inside loss() is ``reduce_mean`` (core/utils/dist_utils.py:68-74) of the
+    per-layer normalisers (``num_total_pos``, ``cls_avg_factor``; gfl_deformable_detr_head_il.py
+    ``loss_single_split``).  Pass 1 runs each rank's batch with a recording ``reduce_mean``; pass 2 replays
+    both with ``reduce_mean`` returning the mean over the two ranks at the same call position -- exactly what
+    the all-reduce delivers -- and stores each rank's losses and gradients."""
+    ref = load_reference()
+    H = ref["head"]
+    B, L, shapes, img_hw, Q = 2, 70, [(9, 14), (5, 7)], [(72, 112), (70, 100)], 60
+    inputs = [make_loss_inputs(B, L, 31, shapes, img_hw, n_t=4, n_gt=3, Q=Q),
+              make_loss_inputs(B, L, 32, shapes, img_hw, n_t=2, n_gt=6, Q=Q)]
+    recorded = []
+    for inp in inputs:
+        calls = []
+
+        def rec(tns, calls=calls):
+            calls.append(tns.clone())
+            return tns
+        H.reduce_mean = rec
+        run_reference_loss(ref, inp, L, img_hw, shapes)
+        recorded.append(calls)
+    n = len(recorded[0]) // 3                     # run_reference_loss evaluates loss() three times
+    assert len(recorded[0]) == len(recorded[1]) == 3 * n and n > 0
+    means = [(a + b) / 2 for a, b in zip(recorded[0][:n], recorded[1][:n])]
+    assert any(float((a - b).abs().max()) > 0 for a, b in zip(recorded[0][:n], recorded[1][:n]))   # the ranks do differ
+    for r, inp in enumerate(inputs):
+        pos = [0]
+
+        def feed(tns, pos=pos):
+            m = means[pos[0] % n]
+            pos[0] += 1
+            assert m.shape == tns.shape
+            return m.to(tns.dtype)
+        H.reduce_mean = feed
+        out = run_reference_loss(ref, inp, L, img_hw, shapes)
+        flat = {"B": np.array(B), "L": np.array(L), "shapes": np.array(shapes), "img_hw": np.array(img_hw),
+                "cls": inp["cls"].numpy(), "box": inp["box"].numpy(), "hs": inp["hs"].numpy(),
+                "hs_t_last": inp["hs_t"][-1].numpy(), "keep": inp["keep"].numpy(),
+                "reduce_mean_local": np.array([float(x.reshape(-1)[0]) for x in recorded[r][:n]]),
+                "reduce_mean_global": np.array([float(x.reshape(-1)[0]) for x in means])}
+        for i in range(len(shapes)):
+            flat[f"feat_s{i}"], flat[f"feat_t{i}"] = inp["feats_s"][i].numpy(), inp["feats_t"][i].numpy()
+        for b in range(B):
+            flat[f"gt_b{b}"], flat[f"gt_l{b}"] = inp["gt_b"][b].numpy(), inp["gt_l"][b].numpy()
+            flat[f"t_b{b}"], flat[f"t_l{b}"] = inp["t_b"][b].numpy(), inp["t_l"][b].numpy()
+        flat.update(out)
+        flat.pop("grad/cls")
+        flat["grad/cls_sum_abs"] = np.abs(out["grad/cls"]).sum(axis=-1)
+        np.savez_compressed(os.path.join(OUT, f"loss_two_rank_r{r}.npz"), **flat)
+        print("rank", r, "calls per loss()", n, "local", flat["reduce_mean_local"][:4], "global", flat["reduce_mean_global"][:4],
+              {k: float(v) for k, v in out.items() if k in ("loss/loss_cls", "loss/loss_corr")})
+    H.reduce_mean = lambda t: t
+
+
 def main_decode():
     """tests/golden/decode_cases.npz: the reference's teacher decode ``get_bboxes`` -> ``_get_bboxes_single``
     (gfl_deformable_detr_head_il.py:1535-1668) -> ``filter_scores_and_topk`` (core/utils/misc.py:119-165) on
@@ -742,6 +798,8 @@ if __name__ == "__main__":
         main_bbox2result()
     elif "--ragged" in sys.argv:
         main_ragged()
+    elif "--two-rank" in sys.argv:
+        main_two_rank()
     elif "--variants" in sys.argv:
         main_variants()
     else:
