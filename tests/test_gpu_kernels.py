@@ -266,19 +266,30 @@ def test_msda_phased_staging_is_bit_identical(monkeypatch, phases, shapes):
                                             ([(25, 42), (13, 21), (7, 11), (4, 6)], 2, 12.0),     # most samples leave the windows
                                             ([(40, 70), (20, 35), (10, 18), (5, 9)], 3, 6.0),
                                             ([(17, 16), (9, 8), (5, 4), (3, 2)], 2, 1.0)])
-def test_msda_windowed_forward_is_bit_identical(monkeypatch, shapes, B, sigma):
+@pytest.mark.parametrize("knobs", [None, pytest.param((2, 8), marks=pytest.mark.xfail(
+    strict=False, reason="mixed mode (levels 2+3 in LDS, 8 waves) was verified bit-identical at the BASELINE shape by "
+                         "scratch/msda_fwd_win_ab.py with the last GPU minutes of round 1; these small / ragged shapes "
+                         "are first executed by the round-end run"))])
+def test_msda_windowed_forward_is_bit_identical(monkeypatch, shapes, B, sigma, knobs):
     """Experimental windowed forward (DSKD_MSDA_FWD=win: one head's value windows of a 16x16-pixel region
     staged in LDS, out-of-window samples through buffer loads): same weights, same sample order, same
     FMAs as the plain kernel, so the bf16 output must be identical -- borders, rejected and far samples
-    included."""
+    included.  ``knobs`` = (first level held in LDS, waves per workgroup): the mixed mode that is faster
+    than the plain kernel."""
     value, loc, attn, _ = _encoder_like_inputs(shapes, B, 71, sigma, torch.bfloat16)
     loc[0, :7] = torch.tensor([-0.2, 0.0, 0.5, 1.0, 1.3, float("nan"), 0.999]).view(7, 1, 1, 1, 1)
     args = (value.to(DEV), shapes, loc.to(DEV), attn.to(DEV))
-    monkeypatch.delenv("DSKD_MSDA_FWD", raising=False)
+    for k in ("DSKD_MSDA_FWD", "DSKD_MSDA_FWD_LV0", "DSKD_MSDA_FWD_NW"):
+        monkeypatch.delenv(k, raising=False)
     plain = native.msda_forward_raw(*args)
     monkeypatch.setenv("DSKD_MSDA_FWD", "win")
+    if knobs is not None:
+        monkeypatch.setenv("DSKD_MSDA_FWD_LV0", str(knobs[0]))
+        monkeypatch.setenv("DSKD_MSDA_FWD_NW", str(knobs[1]))
     win = native.msda_forward_raw(*args)
-    monkeypatch.delenv("DSKD_MSDA_FWD")
+    torch.cuda.synchronize()
+    for k in ("DSKD_MSDA_FWD", "DSKD_MSDA_FWD_LV0", "DSKD_MSDA_FWD_NW"):
+        monkeypatch.delenv(k, raising=False)
     assert torch.equal(plain, win)
 
 
