@@ -8,6 +8,14 @@
 set -euo pipefail
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 mkdir -p gpurun_out
+# (0) two LDS-atomic rates that decide the next step of the grad_value kernels:
+#     ds_add_u64 (two exact fixed-point channels per atomic) and the packed half-precision adds
+./scratch/ubench/lds_atomics > gpurun_out/r02_lds_atomics.log 2>&1 || true
+tail -20 gpurun_out/r02_lds_atomics.log
+# (1) the GPU tests written after round 1's GPU minutes were spent (non-strict xfail): ragged batches through the
+#     HIP loss path, mixed-mode windowed forward on small shapes -- look for XPASS / xfail in the summary
+timeout -k 10 120 python -m pytest tests -q -m gpu -rxX -k "reference_goldens or windowed_forward" > gpurun_out/r02_new_gpu_tests.log 2>&1 || true
+tail -15 gpurun_out/r02_new_gpu_tests.log
 export DSKD_MSDA_FWD=win DSKD_MSDA_FWD_LV0=2 DSKD_MSDA_FWD_NW=8
 timeout -k 10 200 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_model.py -x -q -m gpu > gpurun_out/r02_win_tests.log 2>&1
 tail -3 gpurun_out/r02_win_tests.log
