@@ -10,6 +10,7 @@ cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 mkdir -p gpurun_out
 # (0) two LDS-atomic rates that decide the next step of the grad_value kernels:
 #     ds_add_u64 (two exact fixed-point channels per atomic) and the packed half-precision adds
+[ -x scratch/ubench/lds_atomics ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value scratch/ubench/lds_atomics.hip -o scratch/ubench/lds_atomics
 ./scratch/ubench/lds_atomics > gpurun_out/r02_lds_atomics.log 2>&1 || true
 tail -20 gpurun_out/r02_lds_atomics.log
 # (1) the GPU tests written after round 1's GPU minutes were spent (non-strict xfail): ragged batches through the
