@@ -91,7 +91,12 @@ struct Drop {
   unsigned thresh;          // drop when the element's 16-bit random field < thresh  (thresh = p * 2^16)
   float scale;              // 1 / (1 - p)
   unsigned long long seed, offset;
+  const unsigned long long* epoch;   // device word added to `offset` (or NULL): the per-step part of the key, so that a
+                                     // launch captured into a hipGraph draws a new mask on every replay
 };
+__device__ __forceinline__ unsigned long long drop_offset(const Drop& dr) {
+  return dr.offset + (dr.epoch ? *dr.epoch : 0ull);
+}
 
 // element i (< 8) of a lane is dropped when its 16-bit field is below the threshold
 __device__ __forceinline__ bool dropped(const u32x4& rnd, int i, unsigned thresh) {
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void add_ln_fwd_kernel(
     load_vec(h + rr * kD + c, hv);
     load_vec(res + rr * kD + c, zv);
     if (dr.thresh) {
-      const u32x4 rnd = philox((unsigned long long)rr, (unsigned)rl, dr.seed, dr.offset);
+      const u32x4 rnd = philox((unsigned long long)rr, (unsigned)rl, dr.seed, drop_offset(dr));
 #pragma unroll
       for (int i = 0; i < E; ++i) hv[i] = dropped(rnd, i, dr.thresh) ? 0.f : hv[i] * dr.scale;
     }
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void add_ln_bwd_kernel(
     }
     if (dh) {
       float dv[E];
-      const u32x4 rnd = philox((unsigned long long)row, (unsigned)rl, dr.seed, dr.offset);
+      const u32x4 rnd = philox((unsigned long long)row, (unsigned)rl, dr.seed, drop_offset(dr));
 #pragma unroll
       for (int i = 0; i < E; ++i) dv[i] = dropped(rnd, i, dr.thresh) ? 0.f : dz[i] * dr.scale;
       store_vec(dh + row * kD + c, dv);
@@ -252,13 +257,14 @@ inline int grid_for(long long rows, int rows_per_wave) {
   return (int)(blocks < 2048 ? blocks : 2048);     // 8 workgroups per CU, grid-stride over rows
 }
 
-inline bool make_drop(float p, unsigned long long seed, unsigned long long offset, Drop* d) {
+inline bool make_drop(float p, unsigned long long seed, unsigned long long offset, const uint64_t* epoch, Drop* d) {
   if (!(p >= 0.f) || p >= 1.f) return false;
   const double t = (double)p * 65536.0 + 0.5;
   d->thresh = p > 0.f ? (unsigned)(t < 1.0 ? 1.0 : t) : 0u;
   d->scale = 1.0f / (1.0f - p);
   d->seed = seed;
   d->offset = offset;
+  d->epoch = reinterpret_cast<const unsigned long long*>(epoch);
   return true;
 }
 
@@ -272,7 +278,7 @@ using namespace dskd;
 extern "C" int dskd_add_ln_fwd(const void* h, const void* res, const float* pos, int64_t pos_rows,
                                const float* gamma, const float* beta, void* y, void* q, void* z,
                                float* stats, int64_t rows, int D, float eps, float drop_p,
-                               uint64_t seed, uint64_t offset, int dtype, void* stream) {
+                               uint64_t seed, uint64_t offset, const uint64_t* epoch, int dtype, void* stream) {
   if (D != kD) return fail(DSKD_ERR_INVALID_ARG, "dskd_add_ln_fwd: only D=256 supported (got %d)", D);
   if (dtype != DSKD_DTYPE_F32 && dtype != DSKD_DTYPE_BF16)
     return fail(DSKD_ERR_INVALID_ARG, "dskd_add_ln_fwd: unknown dtype %d", dtype);
@@ -286,7 +292,7 @@ extern "C" int dskd_add_ln_fwd(const void* h, const void* res, const float* pos,
       !aligned16(gamma) || !aligned16(beta) || !aligned16(stats))
     return fail(DSKD_ERR_INVALID_ARG, "dskd_add_ln_fwd: pointers must be 16-byte aligned");
   Drop dr;
-  if (!make_drop(drop_p, seed, offset, &dr)) return fail(DSKD_ERR_INVALID_ARG, "dskd_add_ln_fwd: drop_p=%f", drop_p);
+  if (!make_drop(drop_p, seed, offset, epoch, &dr)) return fail(DSKD_ERR_INVALID_ARG, "dskd_add_ln_fwd: drop_p=%f", drop_p);
   if (rows == 0) return DSKD_OK;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(grid_for(rows, dtype == DSKD_DTYPE_F32 ? 1 : 2)), block(kRowsPerBlock * 64);
@@ -304,7 +310,7 @@ extern "C" int dskd_add_ln_fwd(const void* h, const void* res, const float* pos,
 extern "C" int dskd_add_ln_bwd(const void* dy, const void* dq, const void* z, const float* stats,
                                const float* gamma, void* dres, void* dh, float* dgamma, float* dbeta,
                                int copies, int64_t rows, int D, float drop_p, uint64_t seed,
-                               uint64_t offset, int dtype, void* stream) {
+                               uint64_t offset, const uint64_t* epoch, int dtype, void* stream) {
   if (D != kD) return fail(DSKD_ERR_INVALID_ARG, "dskd_add_ln_bwd: only D=256 supported (got %d)", D);
   if (dtype != DSKD_DTYPE_F32 && dtype != DSKD_DTYPE_BF16)
     return fail(DSKD_ERR_INVALID_ARG, "dskd_add_ln_bwd: unknown dtype %d", dtype);
@@ -314,7 +320,7 @@ extern "C" int dskd_add_ln_bwd(const void* dy, const void* dq, const void* z, co
       !aligned16(dres) || !aligned16(dh))
     return fail(DSKD_ERR_INVALID_ARG, "dskd_add_ln_bwd: pointers must be 16-byte aligned");
   Drop dr;
-  if (!make_drop(drop_p, seed, offset, &dr)) return fail(DSKD_ERR_INVALID_ARG, "dskd_add_ln_bwd: drop_p=%f", drop_p);
+  if (!make_drop(drop_p, seed, offset, epoch, &dr)) return fail(DSKD_ERR_INVALID_ARG, "dskd_add_ln_bwd: drop_p=%f", drop_p);
   if ((dr.thresh != 0) != (dh != nullptr))
     return fail(DSKD_ERR_INVALID_ARG, "dskd_add_ln_bwd: dh is written exactly when drop_p > 0 (else d(h) == d(res))");
   if (rows == 0) return DSKD_OK;

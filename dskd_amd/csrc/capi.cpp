@@ -19,7 +19,7 @@ int fail(int code, const char* fmt, ...) {
 
 }  // namespace dskd
 
-extern "C" int dskd_abi_version(void) { return 1; }
+extern "C" int dskd_abi_version(void) { return 2; }
 
 extern "C" const char* dskd_last_error(void) { return dskd::err_buf(); }
 

@@ -41,7 +41,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // y: [n] bf16, n % 8 == 0.  One 16-bit random field per element: drop when field < thresh16.
 __global__ __launch_bounds__(256) void dropout_fwd_kernel(__bf16* __restrict__ y, long long nvec, unsigned thresh16,
                                                           float scale, unsigned long long seed,
-                                                          unsigned long long offset) {
+                                                          unsigned long long offset0,
+                                                          const unsigned long long* __restrict__ epoch) {
+  const unsigned long long offset = offset0 + (epoch ? *epoch : 0ull);   // per-step part of the key: graph-replay safe
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
        i += (long long)gridDim.x * blockDim.x) {
     float f[8];
@@ -174,8 +176,8 @@ extern "C" int dskd_colsum(const void* x, float* colsum, int copies, int64_t row
   return check_launch("dskd_colsum");
 }
 
-extern "C" int dskd_dropout_fwd(void* y, int64_t n, float p, uint64_t seed, uint64_t offset, int dtype,
-                                void* stream) {
+extern "C" int dskd_dropout_fwd(void* y, int64_t n, float p, uint64_t seed, uint64_t offset,
+                                const uint64_t* epoch, int dtype, void* stream) {
   if (dtype != DSKD_DTYPE_BF16) return fail(DSKD_ERR_INVALID_ARG, "dskd_dropout_fwd: bf16 only");
   if (!y || n < 0 || n % 8 != 0 || (reinterpret_cast<uintptr_t>(y) & 15))
     return fail(DSKD_ERR_INVALID_ARG, "dskd_dropout_fwd: need a 16-byte aligned buffer of n %% 8 == 0 elements");
@@ -185,7 +187,8 @@ extern "C" int dskd_dropout_fwd(void* y, int64_t n, float p, uint64_t seed, uint
   const long long nvec = n / 8, want = (nvec + 255) / 256;
   hipLaunchKernelGGL(dropout_fwd_kernel, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0,
                      (hipStream_t)stream, (__bf16*)y, nvec, t < 1 ? 1u : t, 1.0f / (1.0f - p),
-                     (unsigned long long)seed, (unsigned long long)offset);
+                     (unsigned long long)seed, (unsigned long long)offset,
+                     reinterpret_cast<const unsigned long long*>(epoch));
   return check_launch("dskd_dropout_fwd");
 }
 

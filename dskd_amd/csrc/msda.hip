@@ -84,10 +84,7 @@ __device__ __forceinline__ void fill_level_table(i32x4* tab, const LevelGeom& g)
     if (threadIdx.x == l) tab[l] = i32x4{g.H[l], g.W[l], g.start[l], 0};
 }
 
-// PAIR (layout experiment): a pixel's block holds (pixel, right neighbour), ROWB = 2 x head line, so
-// the corners (x0, x0+1) of a row are ONE aligned line; with x0 == -1 the right corner is the
-// first half of the next block.
-template <int ROWB, bool PAIR = false>
+template <int ROWB>
 __device__ __forceinline__ void point_params(float lx_n, float ly_n, float a, int lvl,
                                              const i32x4* tab, i32x4& off, f32x4& w,
                                              f32x4& aux) {
@@ -108,10 +105,9 @@ __device__ __forceinline__ void point_params(float lx_n, float ly_n, float a, in
     const bool vy0 = y0 >= 0, vy1 = y0 + 1 <= H - 1;
     const int r00 = (st + y0 * W + x0) * ROWB;
     off.x = (vy0 && vx0) ? r00 : kOOB;
-    const int right = PAIR ? (vx0 ? ROWB / 2 : ROWB) : ROWB;
-    off.y = (vy0 && vx1) ? r00 + right : kOOB;
+    off.y = (vy0 && vx1) ? r00 + ROWB : kOOB;
     off.z = (vy1 && vx0) ? r00 + W * ROWB : kOOB;
-    off.w = (vy1 && vx1) ? r00 + W * ROWB + right : kOOB;
+    off.w = (vy1 && vx1) ? r00 + W * ROWB + ROWB : kOOB;
     w = f32x4{hy * hx, hy * lx, ly * hx, ly * lx};
     aux.x = lx;
     aux.y = ly;
@@ -171,7 +167,7 @@ struct Phased {
   static constexpr int HS = kMaxLP / PH + 1;
 };
 
-template <typename T, bool WITH_AUX, int PH, bool KEEP_WT, int ROWB = Traits<T>::ROWB, bool PAIR = false>
+template <typename T, bool WITH_AUX, int PH, bool KEEP_WT>
 __device__ __forceinline__ void stage_points(const float* __restrict__ loc,
                                              const float* __restrict__ attn,
                                              const i32x4* g, int b, int Nq, int q0,
@@ -195,7 +191,7 @@ __device__ __forceinline__ void stage_points(const float* __restrict__ loc,
       const size_t base = ((size_t)b * Nq + q) * (size_t)(kHeads * LP) + h * LP + s;
       const f32x2 xy = *reinterpret_cast<const f32x2*>(loc + base * 2);
       const float a = attn[base];
-      point_params<ROWB, PAIR>(xy.x, xy.y, a, s / points, g, off, w, aux);
+      point_params<TR::ROWB>(xy.x, xy.y, a, s / points, g, off, w, aux);
     }
     const int slot = (qs * kHeads + h) * HS + sl;
     s_off[slot] = off;
@@ -263,11 +259,7 @@ __device__ __forceinline__ void stage_points_fused(const T* __restrict__ both, c
 }
 
 // ------------------------------------------------------------------ forward
-// LAY (experiment, scratch/msda_layout_ab.py): 0 = [B, Nv, heads, ch] (the product layout);
-// 1 = head-major [B, heads, Nv, ch]: the two horizontally adjacent corners of a sample are contiguous
-// (one 128-B line when x0 is even, bf16); 2 = head-major with every pixel followed by a copy of its
-// right neighbour [B, heads, Nv, 2, ch]: the corner pair of a row is always one aligned 128-B line.
-template <typename T, bool FUSED, int PH, int LAY = 0>
+template <typename T, bool FUSED, int PH>
 __global__ __launch_bounds__(kWaves * 64) void msda_fwd_kernel(
     const T* __restrict__ value, const float* __restrict__ loc,
     const float* __restrict__ attn, const T* __restrict__ both, const float* __restrict__ ref,
@@ -294,16 +286,14 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_kernel(
   const int q_end = min(q_begin + qpb, Nq);
 
   const T* vbase = value + (size_t)b * Nv * (kHeads * kCh);
-  constexpr int ROWB = LAY == 0 ? TR::ROWB : LAY * kCh * (int)sizeof(T);     // bytes between neighbouring pixels
-  const T* vimg = LAY == 2 ? value + (size_t)b * Nv * (2 * kHeads * kCh) : vbase;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<T*>(vimg), 0, Nv * (LAY == 2 ? 2 : 1) * TR::ROWB, 0x00020000);
+      const_cast<T*>(vbase), 0, Nv * TR::ROWB, 0x00020000);
 
   // lane -> (query slot, head, 16-byte part of the head's line)
   const int qs = lane / (kHeads * TR::LPH);
   const int h = (lane / TR::LPH) & (kHeads - 1);
   const int part = lane & (TR::LPH - 1);
-  const int hb = (LAY ? h * Nv * ROWB : h * (kCh * (int)sizeof(T))) + part * 16;
+  const int hb = h * (kCh * (int)sizeof(T)) + part * 16;
   const i32x4* my_off = s_off + (qs * kHeads + h) * HS;
   const f32x4* my_wt = s_wt + (qs * kHeads + h) * HS;
   const int LPS = LP / PH;      // samples per head and phase
@@ -318,8 +308,8 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_kernel(
       if constexpr (FUSED)
         stage_points_fused<T, PH>(both, ref, s_lvl, b, Nq, q0, q_end, LP / points, points, ph, lane, s_off, s_wt);
       else
-        stage_points<T, false, PH, true, ROWB, LAY == 2>(loc, attn, s_lvl, b, Nq, q0, q_end, LP, points, ph, lane,
-                                                         s_off, s_wt, nullptr);
+        stage_points<T, false, PH, true>(loc, attn, s_lvl, b, Nq, q0, q_end, LP, points, ph, lane, s_off, s_wt,
+                                         nullptr);
       wave_lds_sync();
 
 #pragma unroll 4
@@ -1437,36 +1427,25 @@ extern "C" int dskd_msda_fwd(const void* value, const int64_t* spatial_shapes,
   hipLaunchKernelGGL((msda_fwd_kernel<__bf16, false, PH>), grid, block, 0, st, (const __bf16*)value, loc, attn, \
                      (const __bf16*)nullptr, (const float*)nullptr, (__bf16*)out, g, Nv, Nq, levels * points,   \
                      points, qpb, bpi)
-    // windowed forward (encoder shape, 4 levels x 4 points): DSKD_MSDA_FWD=win (A/B switch) with its knobs
-    // DSKD_MSDA_FWD_LV0 (first level held in LDS, 0..3) and DSKD_MSDA_FWD_NW (waves per workgroup, 0 = automatic)
-    if (const char* fv = getenv("DSKD_MSDA_FWD"); fv && fv[0] == 'w' && Nq == Nv) {
+    // Encoder shape (queries == pixels, 4 levels x 4 points): windowed forward in MIXED mode -- the coarse levels
+    // 2+3 of one head in LDS, the fine levels on the buffer-load path, 8 waves per workgroup (two workgroups per
+    // CU): bit-identical to the plain kernel and 13-15 % faster.  DSKD_MSDA_FWD=plain forces the
+    // plain kernel; DSKD_MSDA_FWD_LV0 (first level held in LDS, 0..3) / DSKD_MSDA_FWD_NW (waves, 0 = automatic)
+    // are A/B knobs.
+    const char* fv = getenv("DSKD_MSDA_FWD");
+    if (!(fv && fv[0] == 'p') && Nq == Nv) {
       const char* e_lv0 = getenv("DSKD_MSDA_FWD_LV0");
       const char* e_nw = getenv("DSKD_MSDA_FWD_NW");
-      int lv0 = e_lv0 ? atoi(e_lv0) : 0;
-      if (lv0 < 0 || lv0 > 3) lv0 = 0;
+      int lv0 = e_lv0 ? atoi(e_lv0) : 2;
+      if (lv0 < 0 || lv0 > 3) lv0 = 2;
       ValueGeom vg;
       FwdWinGeom fw;
       size_t lds = 0;
-      if (make_fwd_win_geom(g, levels, points, Nq, lv0, e_nw ? atoi(e_nw) : 0, &vg, &fw, &lds)) {
+      if (make_fwd_win_geom(g, levels, points, Nq, lv0, e_nw ? atoi(e_nw) : 8, &vg, &fw, &lds)) {
         if (int rc = launch_fwd_win((const __bf16*)value, loc, attn, (__bf16*)out, vg, fw, lds, B, Nq, points, st))
           return rc;
         return check_launch("dskd_msda_fwd");
       }
-    }
-    // layout experiment only (the caller passes value in that layout): "hm" head-major, "pair" head-major
-    // with the right neighbour duplicated
-    const char* lay = getenv("DSKD_MSDA_VALUE_LAYOUT");
-    if (lay && lay[0] == 'h' && lay[1] == 'm') {
-      hipLaunchKernelGGL((msda_fwd_kernel<__bf16, false, 1, 1>), grid, block, 0, st, (const __bf16*)value, loc,
-                         attn, (const __bf16*)nullptr, (const float*)nullptr, (__bf16*)out, g, Nv, Nq,
-                         levels * points, points, qpb, bpi);
-      return check_launch("dskd_msda_fwd");
-    }
-    if (lay && lay[0] == 'p') {
-      hipLaunchKernelGGL((msda_fwd_kernel<__bf16, false, 1, 2>), grid, block, 0, st, (const __bf16*)value, loc,
-                         attn, (const __bf16*)nullptr, (const float*)nullptr, (__bf16*)out, g, Nv, Nq,
-                         levels * points, points, qpb, bpi);
-      return check_launch("dskd_msda_fwd");
     }
     switch (pick_phases(levels * points, dtype, 4)) {
       case 4: DSKD_FWD_BF16(4); break;

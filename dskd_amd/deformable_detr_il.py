@@ -134,18 +134,52 @@ class TeacherAhead:
                 feats, outs = e["feats"], e["outs"]
             else:
                 feats, outs = self._forward(img, img_metas, amp_dtype)
-        self.pending = ("ahead", feats, outs, img_metas)
+        self.pending = ("ahead", feats, outs, img_metas, img)
+
+    def invalidate(self):
+        """Drop the captured graphs, the seen-signature counters and any pending batch (the teacher they
+        were made with is gone, or the detector moved)."""
+        if self.stream is not None:
+            self.stream.synchronize()        # nothing of the old teacher is still being replayed
+        self.pending = None
+        self._graphs, self._seen, self._flip = {}, {}, 0
+
+    def discard(self):
+        """Forget a launched batch that will not be consumed (end of an epoch cut short, end of a task)."""
+        self.pending = None
+
+    @staticmethod
+    def _same_batch(pend_img, pend_metas, img, img_metas):
+        """Does the pending entry belong to the batch the caller is about to train on?  The same tensor
+        (identity or storage + shape) and the same per-image shapes."""
+        if img is None:
+            return True                      # caller did not say: it consumes what it launched
+        if pend_img is not img and (pend_img.data_ptr() != img.data_ptr() or pend_img.shape != img.shape
+                                    or pend_img.dtype != img.dtype):
+            return False
+        if img_metas is not None and pend_metas is not img_metas:
+            if len(pend_metas) != len(img_metas):
+                return False
+            for a, b in zip(pend_metas, img_metas):
+                if tuple(a.get("img_shape", ())) != tuple(b.get("img_shape", ())):
+                    return False
+        return True
 
     def finish(self, img=None, img_metas=None):
-        """teacher_info of the launched batch (same dict as ``forward_train`` builds)."""
+        """teacher_info of the launched batch (same dict as ``forward_train`` builds).  With ``img`` given, a
+        pending entry launched for ANOTHER batch (a loop that broke after launching, a new epoch / task) is
+        discarded and the teacher runs inline on ``img``."""
         det = self.det
         pend, self.pending = self.pending, None
+        if pend is not None and not self._same_batch(pend[-1] if pend[0] == "ahead" else pend[1],
+                                                     pend[3] if pend[0] == "ahead" else pend[2], img, img_metas):
+            pend = None
         if pend is None or pend[0] == "inline":
             if pend is not None:
                 img, img_metas = pend[1], pend[2]
             feats, outs, keepid, logits, labels, scores, bboxes = det.out_teacher(img, img_metas, cat_keepid=True)
         else:
-            _, feats, outs, img_metas = pend
+            _, feats, outs, img_metas, _ = pend
             main = torch.cuda.current_stream(feats[0].device)
             with torch.cuda.stream(self.stream), torch.no_grad():
                 cfg = det.teacher_test_cfg if det.teacher_test_cfg is not None else det.test_cfg
@@ -184,10 +218,9 @@ class DeformableDETR_il(nn.Module):
         self.LableInPCNTask = {"prev": [], "curr": [], "next": []}
         self.eval_teacher = eval_teacher
         self.teacher_model = None
-        if self.has_teacher:
-            raise NotImplementedError("build the teacher with set_teacher(model=...) (config+ckpt loading is "
-                                      "the mmcv checkpoint path, SURVEY.md section 8f item 3)")
         self.lazy_log = False   # True: train_step returns device log vars (no host sync)
+        if self.has_teacher:    # :70-74 -- the teacher is built from its config and checkpoint right here
+            self.set_teacher(config=teacher_config, ckptfile=teacher_ckpt, trainval="val")
 
     @property
     def with_neck(self):
@@ -200,8 +233,17 @@ class DeformableDETR_il(nn.Module):
         self.bbox_head.init_weights()
 
     # ------------------------------------------------------------------ teacher / task state
+    def _drop_teacher_ahead(self):
+        """Forget the ahead-of-time teacher pipeline: its hipGraphs hold raw pointers into the weights and
+        activations of the teacher they were captured with, and a pending batch belongs to that teacher.
+        Called wherever the teacher (or the device / layout of the detector) changes."""
+        ta = self.__dict__.pop("_teacher_ahead", None)
+        if ta is not None:
+            ta.invalidate()
+
     def set_teacher(self, config=None, ckptfile=None, model=None, trainval="val"):
         """:79-114."""
+        self._drop_teacher_ahead()
         if (config is None or ckptfile is None) and model is None:
             self.has_teacher = False
             self.bbox_head.has_teacher = False
@@ -240,6 +282,7 @@ class DeformableDETR_il(nn.Module):
 
     def load_student(self, ckptfile):
         self.set_student(ckptfile)
+        self._drop_teacher_ahead()
         if self.teacher_model is not None:
             self.teacher_model = None
             self.has_teacher = False
@@ -265,11 +308,13 @@ class DeformableDETR_il(nn.Module):
             super().__setattr__(name, value)
 
     def cuda(self, device=None):
+        self._drop_teacher_ahead()
         if self.has_teacher and self.teacher_model is not None:
             self.teacher_model.cuda(device=device)
         return super().cuda(device=device)
 
     def to(self, *args, **kwargs):
+        self._drop_teacher_ahead()
         if self.has_teacher and self.teacher_model is not None:
             self.teacher_model.to(*args, **kwargs)
         return super().to(*args, **kwargs)

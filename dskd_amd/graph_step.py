@@ -191,6 +191,8 @@ class GraphedDistillStep:
                 return self.eager_step(data, inject)
             g = self._capture(data, inject)
             self._graphs[sig] = g
+        from . import native
+        native.advance_dropout_epoch(self.dev)  # the captured dropout launches read it: new masks on every replay
         g["T"].replay()
         self._decode(g["outs"], data)           # executed (and synchronising) as in the eager step
         self._set_avg_pos(data, inject)

@@ -32,10 +32,10 @@ _SIGNATURES = {
     "dskd_msda_prep_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_msda_prep_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_add_ln_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, _f32, _f32,
-                                   C.c_uint64, C.c_uint64, C.c_int, _vp]),
-    "dskd_add_ln_bwd": (C.c_int, [_vp] * 9 + [C.c_int, _i64, C.c_int, _f32, C.c_uint64, C.c_uint64, C.c_int, _vp]),
+                                   C.c_uint64, C.c_uint64, _vp, C.c_int, _vp]),
+    "dskd_add_ln_bwd": (C.c_int, [_vp] * 9 + [C.c_int, _i64, C.c_int, _f32, C.c_uint64, C.c_uint64, _vp, C.c_int, _vp]),
     "dskd_bias_act": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, _vp]),
-    "dskd_dropout_fwd": (C.c_int, [_vp, _i64, _f32, C.c_uint64, C.c_uint64, C.c_int, _vp]),
+    "dskd_dropout_fwd": (C.c_int, [_vp, _i64, _f32, C.c_uint64, C.c_uint64, _vp, C.c_int, _vp]),
     "dskd_relu_dropout_bwd": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _i64, C.c_int, _f32, C.c_int, _vp]),
     "dskd_colsum": (C.c_int, [_vp, _vp, C.c_int, _i64, C.c_int, C.c_int, _vp]),
     "dskd_lsap_host": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
@@ -71,7 +71,7 @@ def load() -> C.CDLL:
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        if lib.dskd_abi_version() != 1:
+        if lib.dskd_abi_version() != 2:
             raise NativeError("libdskd_hip.so ABI version mismatch")
         _lib = lib
     return _lib
@@ -320,12 +320,36 @@ def msda_prepare(both: torch.Tensor, reference_points: torch.Tensor, spatial_sha
 _drop_calls = 0
 
 
+_drop_epochs = {}
+
+
 def _next_drop_key():
     """(seed, offset) of the next dropout mask: torch's seed (so ``torch.manual_seed`` governs
     it) and a per-process call counter; no device work, no synchronisation."""
     global _drop_calls
     _drop_calls += 1
     return torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, _drop_calls
+
+
+def dropout_epoch(device) -> torch.Tensor:
+    """The device word every dropout kernel adds to its ``offset`` (one int64 per device).  (seed, offset) are
+    launch arguments: captured into a hipGraph they are frozen, and every replay would redraw the SAME masks.  The
+    kernels therefore read this word as well; whoever replays a graph that contains dropout advances it between
+    replays (:func:`advance_dropout_epoch`) -- never between a forward and its backward.  Call-site offsets advance
+    by one per launch, the epoch by 2^32 per step, so (offset + epoch) never repeats."""
+    device = torch.device(device)
+    t = _drop_epochs.get(device)
+    if t is None:
+        t = _drop_epochs[device] = torch.zeros((), dtype=torch.int64, device=device)
+    return t
+
+
+def advance_dropout_epoch(device) -> None:
+    """New dropout masks for the next replay of any captured graph (one tiny launch; not to be captured)."""
+    if torch.cuda.is_current_stream_capturing():
+        raise NativeError("advance_dropout_epoch() inside a hipGraph capture: the increment would be replayed, "
+                          "which is fine, but the captured forward / backward pair must see ONE value")
+    dropout_epoch(device).add_(1 << 32)
 
 
 class _AddLNFunction(torch.autograd.Function):
@@ -346,7 +370,8 @@ class _AddLNFunction(torch.autograd.Function):
             h.data_ptr(), res.data_ptr(), None if pos_f is None else pos_f.data_ptr(),
             0 if pos_f is None else pos_f.numel() // D, gamma_f.data_ptr(), beta_f.data_ptr(), y.data_ptr(),
             None if q is None else q.data_ptr(), None if z is None else z.data_ptr(),
-            None if stats is None else stats.data_ptr(), rows, D, eps, p, seed, offset, dt, _stream(h))
+            None if stats is None else stats.data_ptr(), rows, D, eps, p, seed, offset,
+            dropout_epoch(h.device).data_ptr() if p > 0 else None, dt, _stream(h))
         _check(rc, "dskd_add_ln_fwd")
         if train:
             ctx.save_for_backward(z, stats, gamma_f)
@@ -367,7 +392,8 @@ class _AddLNFunction(torch.autograd.Function):
         dgb = torch.zeros((2, copies, D), dtype=torch.float32, device=z.device)
         rc = load().dskd_add_ln_bwd(dy.data_ptr(), None if dq is None else dq.data_ptr(), z.data_ptr(), stats.data_ptr(),
                                     gamma_f.data_ptr(), dres.data_ptr(), None if dh is None else dh.data_ptr(),
-                                    dgb[0].data_ptr(), dgb[1].data_ptr(), copies, rows, D, p, seed, offset, dt, _stream(z))
+                                    dgb[0].data_ptr(), dgb[1].data_ptr(), copies, rows, D, p, seed, offset,
+                                    dropout_epoch(z.device).data_ptr() if p > 0 else None, dt, _stream(z))
         _check(rc, "dskd_add_ln_bwd")
         dgb = dgb.sum(1) if copies > 1 else dgb[:, 0]
         dpos = None
@@ -404,7 +430,8 @@ def dropout_(y: torch.Tensor, p: float) -> torch.Tensor:
     _need_gpu(y)
     if p > 0:
         seed, offset = _next_drop_key()
-        rc = load().dskd_dropout_fwd(y.data_ptr(), y.numel(), p, seed, offset, DTYPE_BF16, _stream(y))
+        rc = load().dskd_dropout_fwd(y.data_ptr(), y.numel(), p, seed, offset, dropout_epoch(y.device).data_ptr(),
+                                     DTYPE_BF16, _stream(y))
         _check(rc, "dskd_dropout_fwd")
     return y
 

@@ -152,6 +152,9 @@ class TaskEpochBasedRunner:
                         self.log(f"Task [{cur_task}] Epoch [{epoch + 1}][{i + 1}/{len(loader)}] "
                                  f"lr: {self.optimizer.param_groups[0]['lr']:.3e}, "
                                  + ", ".join(f"{k}: {v:.4f}" for k, v in lv.items()))
+            ta = self.module.__dict__.get("_teacher_ahead")
+            if ta is not None:
+                ta.discard()          # a batch launched before the loop ended belongs to no later iteration
             self.epoch = epoch + 1
             if rank == 0 and self.work_dir and (epoch + 1) % self.checkpoint_interval == 0:
                 self.save_checkpoint(cur_task, epoch + 1)

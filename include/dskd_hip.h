@@ -236,14 +236,17 @@ int dskd_fgkd_fwd(const float* const* feat_s, const float* const* feat_t,
  * q           device, [rows, D] dtype or NULL (requires pos)
  * z, stats    device, [rows, D] dtype and [rows, 2] f32 (mean, rstd), saved for backward; both
  *             NULL in inference.  With bf16 the statistics are those of the ROUNDED z.
- * drop_p      dropout probability in [0, 1); the mask is Philox4x32-10(seed, offset) counted by
- *             (row, lane) and is regenerated by the backward call from the same (seed, offset).
+ * drop_p      dropout probability in [0, 1); the mask is Philox4x32-10(seed, offset + *epoch) counted by
+ *             (row, lane) and is regenerated by the backward call from the same (seed, offset, epoch).
+ * epoch       device, one uint64 or NULL (= 0): the part of the key that changes from step to step.  (seed,
+ *             offset) are launch arguments and are frozen into a captured hipGraph; the caller bumps *epoch
+ *             between replays (never between a forward and its backward), so every replay draws new masks.
  * All pointers 16-byte aligned.  Supported: D == 256.
  * ------------------------------------------------------------------------- */
 int dskd_add_ln_fwd(const void* h, const void* res, const float* pos, int64_t pos_rows,
                     const float* gamma, const float* beta, void* y, void* q, void* z,
                     float* stats, int64_t rows, int D, float eps, float drop_p, uint64_t seed,
-                    uint64_t offset, int dtype, void* stream);
+                    uint64_t offset, const uint64_t* epoch, int dtype, void* stream);
 /* Backward of the above.
  * dy, dq      device, [rows, D] dtype: gradients of y and (or NULL) of q
  * dres        device, [rows, D] dtype: d loss / d res (overwritten)
@@ -256,7 +259,7 @@ int dskd_add_ln_fwd(const void* h, const void* res, const float* pos, int64_t po
 int dskd_add_ln_bwd(const void* dy, const void* dq, const void* z, const float* stats,
                     const float* gamma, void* dres, void* dh, float* dgamma, float* dbeta,
                     int copies, int64_t rows, int D, float drop_p, uint64_t seed, uint64_t offset,
-                    int dtype, void* stream);
+                    const uint64_t* epoch, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
  * In-place epilogue of a folded convolution:  x = act(x + bias[c] (+ identity))
@@ -271,15 +274,15 @@ int dskd_bias_act(void* x, const void* bias, const void* identity, int64_t n, in
 /* ---------------------------------------------------------------------------
  * FFN hidden activation (bf16 only).
  * dskd_dropout_fwd: y (device, n elements, n % 8 == 0) is overwritten with dropout_p(y); the mask
- *   is Philox4x32-10(seed, offset) and is NOT stored.
+ *   is Philox4x32-10(seed, offset + *epoch) (epoch as in dskd_add_ln_fwd) and is NOT stored.
  * dskd_relu_dropout_bwd: for y_dropped = dropout_p(relu(.)),
  *       out = g * (y_dropped != 0) / (1 - p)        (ReLU active AND kept <=> y_dropped != 0)
  *       colsum[c] += sum over rows of out[:, c]     (the bias gradient of the Linear before the
  *                                                    ReLU; NULL to skip, else zeroed by the caller)
  *   g, y_dropped, out device [rows, C]; C in {256, 512, 1024, 2048}.
  * ------------------------------------------------------------------------- */
-int dskd_dropout_fwd(void* y, int64_t n, float p, uint64_t seed, uint64_t offset, int dtype,
-                     void* stream);
+int dskd_dropout_fwd(void* y, int64_t n, float p, uint64_t seed, uint64_t offset,
+                     const uint64_t* epoch, int dtype, void* stream);
 int dskd_relu_dropout_bwd(const void* g, const void* y_dropped, void* out, float* colsum,
                           int copies, int64_t rows, int C, float p, int dtype, void* stream);
 /* colsum[c] += sum over rows of x[:, c]  -- the bias gradient of a Linear (`grad.sum(0)` in

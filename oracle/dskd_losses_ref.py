@@ -7,7 +7,7 @@ reference's gradients.
                  (mmdet/models/losses/mse_loss.py:10-13, :16-55, reduction 'mean')
   loss_fg (decode_v1)  gfl_deformable_detr_head_il.py:664-718 +
                  KnowledgeDistillationKLDivLoss (mmdet/models/losses/kd_loss.py:10-43, 'sum')
-Pinned by tests/golden/dskd_losses.npz, produced by running the reference's own
+Pinned by tests/golden/loss_b1_l40.npz / loss_b2_l70.npz, produced by running the reference's own
 ``GFLDeformableDETRHead_il.loss`` (tests/golden/gen_golden.py).
 """
 import torch

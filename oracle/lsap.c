@@ -5,7 +5,7 @@
  * calls at mmdet/core/bbox/assigners/gfl_hungarian_assigner.py:143-147 on a float32 CPU
  * tensor.  scipy's source is not in /root/reference; this file restates the published
  * algorithm and is pinned by differential tests against the installed scipy
- * (tests/test_oracle_lsap.py) and by frozen vectors (tests/golden/lsap_cases.npz).
+ * (tests/test_oracle.py) and by frozen vectors (tests/golden/lsap_cases.npz).
  *
  * Plain C, no dependencies.  Build: `make -C oracle`  ->  oracle/_build/liboracle_lsap.so
  *

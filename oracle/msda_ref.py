@@ -11,7 +11,7 @@ imports it (mmdet/models/utils/transformer.py:22-29) and calls it from the encod
     out = (stack(sampled) * attn).sum(-1)  -> [B, Nq, heads*ch]
 
 ``msda_scalar`` is the same thing written as explicit loops from the formula in SURVEY.md
-appendix A; ``tests/test_oracle_msda.py`` checks the two against each other and against the
+appendix A; ``tests/test_oracle.py`` checks the two against each other and against the
 independent implementation shipped in the installed ``transformers`` package.
 """
 import math

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(native.lib_path())
     for sym in _declared_symbols():
         assert hasattr(lib, sym), sym
-    assert native.load().dskd_abi_version() == 1
+    assert native.load().dskd_abi_version() == 2
 
 
 def test_cpu_tensors_fail_loudly_without_checker():

@@ -194,33 +194,41 @@ def test_other_distill_variants_vs_reference(tag, feats_distill, memory_distill,
     loss() -- decode_v2 (:721-772), kldv (:646-651), memory (:652-661), sg_out (:860-925), fg_only
     (:1082-1129) -- against goldens made by
     running the reference on the inputs of loss_b2_l70 (tests/golden/gen_golden.py --variants)."""
+    _distill_variant_case(tag, feats_distill, memory_distill, key, torch.device("cpu"))
+
+
+def _distill_variant_case(tag, feats_distill, memory_distill, key, dev, rtol=2e-4, grad_rtol=1e-3):
+    """Body of the variant test on ``dev`` (the -m gpu suite runs it on cuda:0 through the HIP path)."""
     d = _load_loss_case("loss_b2_l70.npz")
     v = np.load(os.path.join(G, "loss_variants_b2_l70.npz"))
     head = _make_head(d["L"])
     head.feats_distill, head.memory_distill = feats_distill, memory_distill
     head.loss_fd = plosses.KnowledgeDistillationKLDivLoss(loss_weight=1, T=2)
     head.loss_memory = plosses.KnowledgeDistillationKLDivLoss(loss_weight=1, T=2)
-    hs = d["hs"].clone().requires_grad_(True)
-    fs = [f.clone().requires_grad_(True) for f in d["feats_s"]]
-    mem_s = t(v["mem_s"]).clone().requires_grad_(True)
+    hs = d["hs"].to(dev).requires_grad_(True)
+    fs = [f.to(dev).requires_grad_(True) for f in d["feats_s"]]
+    mem_s = t(v["mem_s"]).to(dev).requires_grad_(True)
     metas = [dict(img_shape=(d["img_hw"][b][0], d["img_hw"][b][1], 3)) for b in range(d["B"])]
     spatial = torch.tensor(d["shapes"])
-    tinfo = dict(neck_feats=d["feats_t"], head_outs=(None, None, (t(v["mem_t"]), spatial), d["hs_t"][None]),
-                 pred_keepid=d["keep"], pred_labels=d["t_l"], pred_bboxes=d["t_b"])
-    losses = head.loss(d["cls"].clone(), d["box"].clone(), (mem_s, spatial), hs, d["gt_b"], d["gt_l"], metas,
-                       student_feat=fs, teacher_info=tinfo, task_labels={"prev": list(range(d["L"])), "curr": [], "next": []})
+    tinfo = dict(neck_feats=[f.to(dev) for f in d["feats_t"]],
+                 head_outs=(None, None, (t(v["mem_t"]).to(dev), spatial), d["hs_t"][None].to(dev)),
+                 pred_keepid=d["keep"].to(dev), pred_labels=[x.to(dev) for x in d["t_l"]],
+                 pred_bboxes=[x.to(dev) for x in d["t_b"]])
+    losses = head.loss(d["cls"].to(dev), d["box"].to(dev), (mem_s, spatial), hs, [x.to(dev) for x in d["gt_b"]],
+                       [x.to(dev) for x in d["gt_l"]], metas, student_feat=fs, teacher_info=tinfo,
+                       task_labels={"prev": list(range(d["L"])), "curr": [], "next": []})
     assert sorted(losses.keys()) == sorted(v[f"{tag}/keys"].tolist())
-    torch.testing.assert_close(losses[key].detach(), t(v[f"{tag}/loss/{key}"]), rtol=2e-4, atol=1e-9)
+    torch.testing.assert_close(losses[key].detach().cpu(), t(v[f"{tag}/loss/{key}"]), rtol=rtol, atol=1e-9)
     if f"{tag}/nograd/{key}" in v.files:
         assert not losses[key].requires_grad           # decode_v2: teacher features in the prediction slot
         return
     g = torch.autograd.grad(losses[key], [hs, mem_s] + fs, allow_unused=True)
     assert g[0] is None or float(g[0].abs().max()) == 0.0
     if f"{tag}/grad_mem/{key}" in v.files:
-        torch.testing.assert_close(g[1], t(v[f"{tag}/grad_mem/{key}"]), rtol=1e-3, atol=1e-10)
+        torch.testing.assert_close(g[1].cpu(), t(v[f"{tag}/grad_mem/{key}"]), rtol=grad_rtol, atol=1e-10)
     for i in range(len(fs)):
         if f"{tag}/grad_feat{i}/{key}" in v.files:
-            torch.testing.assert_close(g[2 + i], t(v[f"{tag}/grad_feat{i}/{key}"]), rtol=1e-3, atol=1e-10)
+            torch.testing.assert_close(g[2 + i].cpu(), t(v[f"{tag}/grad_feat{i}/{key}"]), rtol=grad_rtol, atol=1e-10)
 
 
 @pytest.mark.parametrize("tag,cates_distill,locat_distill,keys", [
@@ -265,6 +273,11 @@ def test_teacher_decode_vs_reference(tag):
     descending, top-k (query, class) PAIRS -- a query can be kept twice --, boxes from the integral of
     the 4 x 17 bins, clamped to the un-padded image, optionally rescaled; logits = the sigmoid rows;
     keepid = the query index.  Integer outputs must be equal."""
+    _teacher_decode_case(tag, torch.device("cpu"))
+
+
+def _teacher_decode_case(tag, dev):
+    """Body of the decode test on ``dev`` (the -m gpu suite runs it on cuda:0)."""
     import types
 
     from dskd_amd.gfl_deformable_detr_head_il import GFLDeformableDETRHead_il, Integral_average
@@ -274,7 +287,7 @@ def test_teacher_decode_vs_reference(tag):
                                  integral_average=Integral_average(16))
     for name in ("get_bboxes", "_get_bboxes_single"):
         setattr(head, name, types.MethodType(getattr(GFLDeformableDETRHead_il, name), head))
-    cls, box = t(z[f"{tag}/cls"]), t(z[f"{tag}/box"])
+    cls, box = t(z[f"{tag}/cls"]).to(dev), t(z[f"{tag}/box"]).to(dev)
     B = cls.shape[1]
     metas = [dict(img_shape=tuple(int(v) for v in z[f"{tag}/{i}/img_shape"]), scale_factor=z[f"{tag}/{i}/scale_factor"])
              for i in range(B)]
@@ -285,6 +298,8 @@ def test_teacher_decode_vs_reference(tag):
     assert len(out) == B
     twice = 0
     for i, (bboxes, labels, logits, keepid) in enumerate(out):
+        assert bboxes.device.type == dev.type
+        bboxes, labels, logits, keepid = bboxes.cpu(), labels.cpu(), logits.cpu(), keepid.cpu()
         assert torch.equal(labels, t(z[f"{tag}/{i}/labels"])) and torch.equal(keepid, t(z[f"{tag}/{i}/keepid"]))
         torch.testing.assert_close(bboxes, t(z[f"{tag}/{i}/bboxes"]), rtol=1e-6, atol=1e-6)
         torch.testing.assert_close(logits, t(z[f"{tag}/{i}/logits"]), rtol=1e-6, atol=1e-7)
@@ -297,6 +312,7 @@ def test_teacher_decode_vs_reference(tag):
     # two-tuple form without need_logits
     two = head.get_bboxes(cls, box, None, None, img_metas=metas, rescale=bool(z[f"{tag}/rescale"]), cfg=cfg)
     assert len(two[0]) == 2 and torch.equal(two[0][1], out[0][1])
+    return out
 
 
 @pytest.mark.parametrize("tag", ["full", "padded"])

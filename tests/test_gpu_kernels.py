@@ -168,6 +168,23 @@ def test_msda_bwd_windowed_matches_plain_atomics_full_size(monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_msda_bwd_full_size_vs_oracle(dtype):
+    """BASELINE size (100x167 ... 13x21, Nq = Nv = 22 223), one image: grad_value, grad_loc and grad_attn of the
+    encoder-shape backward against autograd of the oracle on ALL queries and ALL value rows (the oracle needs ~3 s
+    for this on the host)."""
+    value, loc, attn, go = _encoder_like_inputs(SHAPES_FULL, 1, 43, 2.5, dtype)
+    v = value.float().requires_grad_(True)
+    l = loc.clone().requires_grad_(True)
+    a = attn.clone().requires_grad_(True)
+    msda_ref.msda_grid_sample(v, SHAPES_FULL, l, a).backward(go.float())
+    gv, gl, ga = native.msda_backward_raw(value.to(DEV), SHAPES_FULL, loc.to(DEV), attn.to(DEV), go.to(DEV))
+    tol = dict(atol=2e-4, rtol=1e-3) if dtype == torch.float32 else dict(atol=4e-3, rtol=4e-3)
+    torch.testing.assert_close(gv.cpu(), v.grad, **tol)
+    torch.testing.assert_close(ga.cpu(), a.grad, **tol)
+    torch.testing.assert_close(gl.cpu(), l.grad, atol=tol["atol"] * 20, rtol=tol["rtol"])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_msda_prepare_vs_module_chain(dtype, oracle_checker):
     """softmax + location prologue kernel (and its backward) against the module's PyTorch chain."""
     g = torch.Generator().manual_seed(17)
@@ -266,60 +283,78 @@ def test_msda_phased_staging_is_bit_identical(monkeypatch, phases, shapes):
                                             ([(25, 42), (13, 21), (7, 11), (4, 6)], 2, 12.0),     # most samples leave the windows
                                             ([(40, 70), (20, 35), (10, 18), (5, 9)], 3, 6.0),
                                             ([(17, 16), (9, 8), (5, 4), (3, 2)], 2, 1.0)])
-@pytest.mark.parametrize("knobs", [None, pytest.param((2, 8), marks=pytest.mark.xfail(
-    strict=False, reason="mixed mode (levels 2+3 in LDS, 8 waves) was verified bit-identical at the BASELINE shape by "
-                         "scratch/msda_fwd_win_ab.py with the last GPU minutes of round 1; these small / ragged shapes "
-                         "are first executed by the round-end run"))])
+@pytest.mark.parametrize("knobs", ["default", (0, 0), (2, 8), (1, 8), (3, 4)])
 def test_msda_windowed_forward_is_bit_identical(monkeypatch, shapes, B, sigma, knobs):
-    """Experimental windowed forward (DSKD_MSDA_FWD=win: one head's value windows of a 16x16-pixel region
-    staged in LDS, out-of-window samples through buffer loads): same weights, same sample order, same
-    FMAs as the plain kernel, so the bf16 output must be identical -- borders, rejected and far samples
-    included.  ``knobs`` = (first level held in LDS, waves per workgroup): the mixed mode that is faster
-    than the plain kernel."""
+    """Windowed forward (one head's value windows of a 16x16-pixel region staged in LDS, out-of-window samples
+    through buffer loads): same weights, same sample order, same FMAs as the plain kernel, so the bf16 output must
+    be identical -- borders, rejected and far samples included.  ``knobs`` = (first level held in LDS, waves per
+    workgroup); "default" = what the encoder runs (mixed mode: levels 2+3 in LDS, 8 waves; DESIGN.md section
+    4.1), compared with ``DSKD_MSDA_FWD=plain``."""
     value, loc, attn, _ = _encoder_like_inputs(shapes, B, 71, sigma, torch.bfloat16)
     loc[0, :7] = torch.tensor([-0.2, 0.0, 0.5, 1.0, 1.3, float("nan"), 0.999]).view(7, 1, 1, 1, 1)
     args = (value.to(DEV), shapes, loc.to(DEV), attn.to(DEV))
     for k in ("DSKD_MSDA_FWD", "DSKD_MSDA_FWD_LV0", "DSKD_MSDA_FWD_NW"):
         monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("DSKD_MSDA_FWD", "plain")
     plain = native.msda_forward_raw(*args)
-    monkeypatch.setenv("DSKD_MSDA_FWD", "win")
-    if knobs is not None:
+    monkeypatch.delenv("DSKD_MSDA_FWD")
+    if knobs != "default":
         monkeypatch.setenv("DSKD_MSDA_FWD_LV0", str(knobs[0]))
         monkeypatch.setenv("DSKD_MSDA_FWD_NW", str(knobs[1]))
     win = native.msda_forward_raw(*args)
     torch.cuda.synchronize()
-    for k in ("DSKD_MSDA_FWD", "DSKD_MSDA_FWD_LV0", "DSKD_MSDA_FWD_NW"):
+    for k in ("DSKD_MSDA_FWD_LV0", "DSKD_MSDA_FWD_NW"):
         monkeypatch.delenv(k, raising=False)
     assert torch.equal(plain, win)
-
-
-def test_msda_value_layout_experiments_are_bit_identical(monkeypatch):
-    """Experiment-only forward variants reading the value in head-major / pair-duplicated layout
-    (DSKD_MSDA_VALUE_LAYOUT, scratch/msda_layout_ab.py): identical output."""
-    shapes = [(25, 42), (13, 21), (7, 11), (4, 6)]
-    value, loc, attn, _ = _encoder_like_inputs(shapes, 2, 73, 3.0, torch.bfloat16)
-    loc[0, :7] = torch.tensor([-0.2, 0.0, 0.5, 1.0, 1.3, float("nan"), 0.999]).view(7, 1, 1, 1, 1)
-    v, ld, ad = value.to(DEV), loc.to(DEV), attn.to(DEV)
-    B, Nv = v.shape[:2]
-    monkeypatch.delenv("DSKD_MSDA_VALUE_LAYOUT", raising=False)
-    plain = native.msda_forward_raw(v, shapes, ld, ad)
-    vp = v.permute(0, 2, 1, 3)
-    hm = vp.contiguous().view(B, Nv, 8, 32)
-    big = torch.zeros(B, 8, Nv, 2, 32, dtype=v.dtype, device=DEV)
-    big[:, :, :, 0] = vp
-    big[:, :, :-1, 1] = vp[:, :, 1:]
-    pair = big.view(-1)[: B * Nv * 256].view(B, Nv, 8, 32)          # the kernel indexes the whole buffer
-    monkeypatch.setenv("DSKD_MSDA_VALUE_LAYOUT", "hm")
-    out_hm = native.msda_forward_raw(hm, shapes, ld, ad)
-    monkeypatch.setenv("DSKD_MSDA_VALUE_LAYOUT", "pair")
-    out_pair = native.msda_forward_raw(pair, shapes, ld, ad)
-    monkeypatch.delenv("DSKD_MSDA_VALUE_LAYOUT")
-    torch.cuda.synchronize()
-    assert torch.equal(out_hm, plain) and torch.equal(out_pair, plain)
-    del big
+    # and the plain kernel's result is the oracle's (fp32 evaluation on the rounded inputs)
+    want = msda_ref.msda_grid_sample(value.float(), shapes, loc.nan_to_num(nan=-5.0), attn)
+    torch.testing.assert_close(win.float().cpu(), want, atol=3e-2, rtol=2e-2)
 
 
 # ----------------------------------------------------------------------------- add + dropout + LayerNorm
+def test_dropout_masks_change_between_graph_replays():
+    """(seed, offset) are launch arguments and are frozen into a captured hipGraph; the kernels also read
+    the device epoch word, so every replay draws a new mask once the host has advanced it -- for the fused add+LN
+    tail and for the FFN's in-place dropout -- and the backward inside the same replay regenerates the forward's."""
+    g = torch.Generator().manual_seed(3)
+    rows, D, p = 512, 256, 0.25
+    h = (torch.rand(rows, D, generator=g) + 1.0).to(DEV).to(torch.bfloat16).requires_grad_(True)
+    res = torch.zeros(rows, D, device=DEV, dtype=torch.bfloat16)
+    norm = torch.nn.LayerNorm(D).to(DEV)
+    y_ffn = (torch.rand(rows, 1024, generator=g) + 1.0).to(DEV).to(torch.bfloat16)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+
+    def region():
+        y, _ = native.add_layer_norm(h, res, norm, p)
+        (gh,) = torch.autograd.grad(y.float().sum() + (y.float() ** 2).sum(), h)
+        d = native.dropout_(y_ffn.clone(), p)
+        return y, gh, d
+    with torch.cuda.stream(side):
+        region()                                             # warm-up outside capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        y, gh, d = region()
+    seen = []
+    for _ in range(3):
+        native.advance_dropout_epoch(DEV)
+        graph.replay()
+        torch.cuda.synchronize()
+        keep_ffn = d != 0
+        keep_ln = gh != 0                                    # d(h) is zero exactly where h was dropped
+        frac = keep_ln.float().mean().item()
+        assert abs(frac - (1 - p)) < 0.02, frac
+        seen.append((keep_ln.clone(), keep_ffn.clone()))
+    for i in range(3):
+        for j in range(i):
+            assert not torch.equal(seen[i][0], seen[j][0]) and not torch.equal(seen[i][1], seen[j][1])
+    # without advancing, a replay repeats its masks (that is the failure mode the epoch word removes)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(gh != 0, seen[-1][0]) and torch.equal(d != 0, seen[-1][1])
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("want_q", [False, True])
 def test_add_layer_norm_vs_module_chain(dtype, want_q, oracle_checker):
@@ -376,11 +411,11 @@ def test_add_layer_norm_dropout_mask_through_abi():
     gamma, beta = torch.ones(D, device=DEV), torch.zeros(D, device=DEV)
     st = torch.cuda.current_stream().cuda_stream
 
-    def fwd(seed, offset):
+    def fwd(seed, offset, epoch=None):
         y, z = torch.empty_like(h), torch.empty_like(h)
         stats = torch.empty(rows, 2, device=DEV)
         rc = lib.dskd_add_ln_fwd(h.data_ptr(), res.data_ptr(), None, 0, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
-                                 None, z.data_ptr(), stats.data_ptr(), rows, D, 1e-5, p, seed, offset, native.DTYPE_F32, st)
+                                 None, z.data_ptr(), stats.data_ptr(), rows, D, 1e-5, p, seed, offset, epoch, native.DTYPE_F32, st)
         assert rc == 0, lib.dskd_last_error()
         return y, z, stats
     y, z, stats = fwd(1234, 7)
@@ -394,6 +429,11 @@ def test_add_layer_norm_dropout_mask_through_abi():
     assert torch.equal(z, z2)
     _, z3, _ = fwd(1234, 8)
     assert not torch.equal(z3 != 0, keep)
+    # the device epoch word is added to the offset: (7, epoch 1) == (8, no epoch), (7, epoch 0) == (7, no epoch)
+    ep = torch.zeros((), dtype=torch.int64, device=DEV)
+    assert torch.equal(fwd(1234, 7, ep.data_ptr())[1], z)
+    ep.add_(1)
+    assert torch.equal(fwd(1234, 7, ep.data_ptr())[1], z3)
     # statistics of z
     torch.testing.assert_close(stats[:, 0], z.mean(1), rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(stats[:, 1], (z.var(1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-4, atol=1e-5)
@@ -402,20 +442,20 @@ def test_add_layer_norm_dropout_mask_through_abi():
     dres, dh = torch.empty_like(h), torch.empty_like(h)
     dg, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
     rc = lib.dskd_add_ln_bwd(dy.data_ptr(), None, z.data_ptr(), stats.data_ptr(), gamma.data_ptr(), dres.data_ptr(),
-                             dh.data_ptr(), dg.data_ptr(), db.data_ptr(), 1, rows, D, p, 1234, 7, native.DTYPE_F32, st)
+                             dh.data_ptr(), dg.data_ptr(), db.data_ptr(), 1, rows, D, p, 1234, 7, None, native.DTYPE_F32, st)
     assert rc == 0, lib.dskd_last_error()
     assert torch.equal(dh != 0, keep & (dres != 0))
     torch.testing.assert_close(dh[keep], (dres / (1 - p))[keep], rtol=1e-6, atol=0)
     torch.testing.assert_close(db, dy.sum(0), rtol=1e-4, atol=1e-3)
     # argument checks of the ABI
     assert lib.dskd_add_ln_fwd(h.data_ptr(), res.data_ptr(), None, 0, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
-                               None, None, None, rows, 128, 1e-5, 0.0, 0, 0, native.DTYPE_F32, st) == -1
+                               None, None, None, rows, 128, 1e-5, 0.0, 0, 0, None, native.DTYPE_F32, st) == -1
     assert lib.dskd_add_ln_bwd(dy.data_ptr(), None, z.data_ptr(), stats.data_ptr(), gamma.data_ptr(), dres.data_ptr(),
-                               None, dg.data_ptr(), db.data_ptr(), 1, rows, D, p, 1, 1, native.DTYPE_F32, st) == -1
+                               None, dg.data_ptr(), db.data_ptr(), 1, rows, D, p, 1, 1, None, native.DTYPE_F32, st) == -1
     # several accumulator copies: the column sums are spread over them
     dg4, db4 = torch.zeros(4, D, device=DEV), torch.zeros(4, D, device=DEV)
     rc = lib.dskd_add_ln_bwd(dy.data_ptr(), None, z.data_ptr(), stats.data_ptr(), gamma.data_ptr(), dres.data_ptr(),
-                             dh.data_ptr(), dg4.data_ptr(), db4.data_ptr(), 4, rows, D, p, 1234, 7, native.DTYPE_F32, st)
+                             dh.data_ptr(), dg4.data_ptr(), db4.data_ptr(), 4, rows, D, p, 1234, 7, None, native.DTYPE_F32, st)
     assert rc == 0
     torch.testing.assert_close(db4.sum(0), db, rtol=1e-4, atol=1e-3)
     torch.testing.assert_close(dg4.sum(0), dg, rtol=1e-4, atol=1e-3)

@@ -16,10 +16,12 @@ from dskd_amd.runner import build_optimizer
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CFG = os.path.join(ROOT, "configs", "dskd_gfl_deformable_detr_r50_70_10.py")
+CFG_40 = os.path.join(ROOT, "configs", "dskd_gfl_deformable_detr_r50_40_40.py")      # BASELINE configs[0] / [2] model
+CFG_SWIN = os.path.join(ROOT, "configs", "dskd_gfl_deformable_detr_swin_t_70_10.py")   # BASELINE configs[3] model
 
 
-def _build(seed=0, num_query=300):
-    cfg = Config.fromfile(CFG)
+def _build(seed=0, num_query=300, cfg_file=CFG):
+    cfg = Config.fromfile(cfg_file)
     cfg.model.bbox_head.num_query = num_query
     torch.manual_seed(seed)
     m = build_detector(cfg.model)
@@ -35,7 +37,7 @@ def _build(seed=0, num_query=300):
         for p in t.parameters():
             p.add_(torch.randn(p.shape, generator=g) * 1e-3)
     m.set_teacher(model=t)
-    m.LableInPCNTask = {"prev": list(range(70)), "curr": list(range(70, 80)), "next": []}
+    m.LableInPCNTask = {"prev": list(range(cfg.num_prev)), "curr": list(range(cfg.num_prev, 80)), "next": []}
     return cfg, m
 
 
@@ -52,10 +54,13 @@ def _batch(dev, B=2, H=192, W=256):
     return dict(img=img, img_metas=metas, gt_bboxes=gt_b, gt_labels=gt_l), inject
 
 
-def test_full_step_gpu_matches_cpu_oracle_fp32(oracle_checker):
+@pytest.mark.parametrize("cfg_file", [CFG, CFG_40, CFG_SWIN], ids=["r50_70_10", "r50_40_40", "swin_t_70_10"])
+def test_full_step_gpu_matches_cpu_oracle_fp32(oracle_checker, cfg_file):
     """Same weights, same batch, fp32: loss dict on the GPU (HIP kernels, device LSAP) vs on the
-    CPU (oracle kernels, oracle LSAP).  Also the gradient of a few parameters."""
-    cfg, m_cpu = _build()
+    CPU (oracle kernels, oracle LSAP).  Also the gradient of a few parameters.  The three detector
+    configurations BASELINE.json names: R50 70+10 (configs[1]), R50 40+40 (the model of configs[0] / [2]; the
+    config is the reference's chaosuan_..._40_..._il.py, see tests/test_host_logic.py) and Swin-T (configs[3])."""
+    cfg, m_cpu = _build(cfg_file=cfg_file)
     m_gpu = copy.deepcopy(m_cpu)
     m_gpu.to("cuda:0").train()
     m_cpu.train()
@@ -80,8 +85,10 @@ def test_full_step_gpu_matches_cpu_oracle_fp32(oracle_checker):
     for k in lv_c:
         rtol = 5e-2 if k == "loss_fg_feature" else 2e-3       # fp32 reference noise of decode_v1, see kernel tests
         assert lv_g[k] == pytest.approx(lv_c[k], rel=rtol, abs=1e-5), k
-    for name in ("bbox_head.cls_branches.0.weight", "bbox_head.transformer.decoder.layers.5.ffns.0.layers.1.weight",
-                 "bbox_head.transformer.encoder.layers.0.attentions.0.value_proj.weight", "neck.convs.0.conv.weight"):
+    names = ["bbox_head.cls_branches.0.weight", "bbox_head.transformer.decoder.layers.5.ffns.0.layers.1.weight",
+             "bbox_head.transformer.encoder.layers.0.attentions.0.value_proj.weight", "neck.convs.0.conv.weight"]
+    names.append("backbone.stages.3.blocks.1.attn.w_msa.qkv.weight" if cfg_file == CFG_SWIN else "backbone.layer4.2.conv3.weight")
+    for name in names:
         gc = dict(m_cpu.named_parameters())[name].grad
         gg = dict(m_gpu.named_parameters())[name].grad.cpu()
         rel = (gc - gg).norm() / (gc.norm() + 1e-12)
@@ -280,10 +287,8 @@ def test_graphed_dense_losses_equal_eager():
     assert len(graphs) == 1 and all(v is not False for v in graphs.values())       # captured after two eager calls
 
 
-@pytest.mark.xfail(strict=False, reason="written after round 1's GPU minutes were spent: first executed by the round-end run; "
-                                        "the same cases pass on the CPU path (tests/test_golden_reference.py)")
-@pytest.mark.parametrize("name", ["loss_b2_l70.npz", "loss_ragged_no_teacher_boxes.npz", "loss_ragged_no_gt.npz",
-                                  "loss_ragged_empty.npz"])
+@pytest.mark.parametrize("name", ["loss_b1_l40.npz", "loss_b2_l70.npz", "loss_ragged_no_teacher_boxes.npz",
+                                  "loss_ragged_no_gt.npz", "loss_ragged_empty.npz"])
 def test_head_loss_on_gpu_vs_reference_goldens(name):
     """The head's ``loss`` on the GPU (fused cost + batched device LSAP, HIP DSKD losses) against the outputs of the
     reference's own ``loss`` -- including RAGGED batches whose second image has no teacher detection / no ground
@@ -315,3 +320,101 @@ def test_head_loss_on_gpu_vs_reference_goldens(name):
     torch.testing.assert_close(cls.grad.abs().sum(-1).cpu(), t(z["grad/cls_sum_abs"]), rtol=2e-3, atol=1e-5)
     if head.last_lsap_status is not None:
         native.raise_for_lsap_status(head.last_lsap_status)
+
+
+@pytest.mark.parametrize("tag,feats_distill,memory_distill,key", [
+    ("decode_v2", "corr + fg_info + decode_v2", "", "loss_fg_feature"),
+    ("kldv", "corr + kldv", "", "loss_fd"),
+    ("memory", "corr", "memory", "loss_memory"),
+    ("sg_out", "corr + fg_info + sg_out", "", "loss_fg_feature"),
+    ("fg_only", "corr + fg_info + fg_only", "", "loss_fg_feature")])
+def test_other_distill_variants_on_gpu_vs_reference_goldens(tag, feats_distill, memory_distill, key):
+    """SURVEY.md 8f row 4 on the GPU: the other feature / memory distillation branches of the reference's ``loss()``
+    (gfl_deformable_detr_head_il.py:646-661, :721-772, :860-925, :1082-1129) with every tensor on cuda:0 (HIP cost /
+    LSAP / loss_corr kernels underneath), against the goldens produced by the reference itself."""
+    from test_golden_reference import _distill_variant_case
+    _distill_variant_case(tag, feats_distill, memory_distill, key, torch.device("cuda:0"), rtol=5e-4, grad_rtol=2e-3)
+
+
+@pytest.mark.parametrize("tag", ["many", "few", "none", "rescale", "cfg"])
+def test_teacher_decode_values_on_gpu_vs_reference_goldens(tag):
+    """Row A6 on the GPU: ``get_bboxes`` -> ``_get_bboxes_single`` -> ``filter_scores_and_topk`` on cuda:0 against
+    the outputs of the reference's own methods (gfl_deformable_detr_head_il.py:1535-1668, core/utils/misc.py:119-165):
+    kept (query, class) pairs, their order, boxes and logits -- VALUES, not shapes."""
+    from test_golden_reference import _teacher_decode_case
+    _teacher_decode_case(tag, torch.device("cuda:0"))
+
+
+def test_adamw_clip_update_gpu_matches_cpu():
+    """Row A13: three optimizer updates (global-norm clip max_norm=0.1, AdamW with the config's parameter groups /
+    lr multipliers, warm-up lr) on the GPU -- fused multi-tensor AdamW -- against the same updates on the CPU from
+    identical gradients: every parameter agrees to rounding, and so does the clip's norm."""
+    from dskd_amd.runner import StepLrWarmup
+    cfg, m_cpu = _build(seed=4, num_query=50)
+    m_gpu = copy.deepcopy(m_cpu).to("cuda:0")
+    opts, lrs = [], []
+    for m in (m_cpu, m_gpu):
+        o = build_optimizer(m, cfg.optimizer[0])
+        opts.append(o)
+        lrs.append(StepLrWarmup(o, **{k: v for k, v in dict(cfg.lr_config[0]).items() if k != "policy"}))
+    assert opts[1].defaults.get("fused") and not opts[0].defaults.get("fused")
+    g = torch.Generator().manual_seed(99)
+    pc, pg = dict(m_cpu.named_parameters()), dict(m_gpu.named_parameters())
+    train = [n for n, p in pc.items() if p.requires_grad]
+    assert len(train) > 150
+    for it in range(3):
+        for n in train:
+            gr = torch.randn(pc[n].shape, generator=g) * (10.0 ** (it - 1))      # clip active, very different scales
+            pc[n].grad, pg[n].grad = gr.clone(), gr.to("cuda:0")
+        norms = []
+        for lr, o, params in ((lrs[0], opts[0], pc), (lrs[1], opts[1], pg)):
+            lr.set(0, it)
+            norms.append(float(torch.nn.utils.clip_grad_norm_([params[n] for n in train], max_norm=0.1, norm_type=2)))
+            o.step()
+        assert norms[1] == pytest.approx(norms[0], rel=1e-5)
+        assert [gr["lr"] for gr in opts[0].param_groups] == [gr["lr"] for gr in opts[1].param_groups]
+    worst = 0.0
+    for n in train:
+        torch.testing.assert_close(pg[n].detach().cpu(), pc[n].detach(), rtol=2e-5, atol=2e-7, msg=lambda m: f"{n}: {m}")
+        worst = max(worst, float((pg[n].detach().cpu() - pc[n].detach()).abs().max()))
+    # the parameters did move (lr_mult 0.1 groups included)
+    assert float((pc["backbone.layer4.2.conv3.weight"] - dict(_build(seed=4, num_query=50)[1].named_parameters())
+                  ["backbone.layer4.2.conv3.weight"]).abs().max()) > 0
+
+
+def test_teacher_ahead_is_invalidated_by_set_teacher():
+    """graphs captured for one teacher must not be replayed for the next one (task t+1 swaps the
+    teacher in; same batch signature), and a batch launched for another image must not be consumed."""
+    cfg, m = _build(seed=6, num_query=50)
+    m.to("cuda:0").train()
+    data, _ = _batch(torch.device("cuda:0"))
+    ahead = m.teacher_ahead()
+    ahead.use_graphs, ahead.graph_warmup = True, 1
+    for _ in range(4):                                     # capture happens here
+        ahead.launch(data["img"], data["img_metas"])
+        ti_old = ahead.finish(data["img"], data["img_metas"])
+    assert any(ahead._graphs.values())
+    old_feat = ti_old["neck_feats"][0].clone()
+    # new teacher with clearly different weights, same batch signature
+    t2 = copy.deepcopy(m.teacher_model)
+    with torch.no_grad():
+        for p in t2.parameters():
+            p.mul_(1.5)
+    m.set_teacher(model=t2)
+    assert m.__dict__.get("_teacher_ahead") is None
+    ahead2 = m.teacher_ahead()
+    assert ahead2 is not ahead and not ahead2._graphs
+    ahead2.use_graphs, ahead2.graph_warmup = True, 1
+    feats_inline, *_ = m.out_teacher(data["img"], data["img_metas"])
+    for _ in range(4):
+        ahead2.launch(data["img"], data["img_metas"])
+        ti_new = ahead2.finish(data["img"], data["img_metas"])
+        torch.testing.assert_close(ti_new["neck_feats"][0], feats_inline[0], rtol=1e-3, atol=1e-3)
+    assert float((ti_new["neck_feats"][0] - old_feat).abs().max()) > 1e-3
+    # a pending batch that is not the one being trained on is discarded (inline teacher on the given image)
+    other = torch.randn_like(data["img"])
+    ahead2.launch(data["img"], data["img_metas"])
+    ti_other = ahead2.finish(other, data["img_metas"])
+    feats_other, *_ = m.out_teacher(other, data["img_metas"])
+    torch.testing.assert_close(ti_other["neck_feats"][0], feats_other[0], rtol=1e-4, atol=1e-4)
+    assert ahead2.pending is None

@@ -369,3 +369,57 @@ def test_gfl_hungarian_assigner_like_the_reference_test(cpu_ops):
     # no predictions at all
     res = asg.assign(torch.empty((0, 4)), torch.empty((0, 80)), gt_bboxes, gt_labels, None, img_meta)
     assert res.num_gts == 2 and len(res.gt_inds) == 0
+
+
+def test_own_40_40_config_describes_the_reference_model():
+    """configs/dskd_gfl_deformable_detr_r50_40_40.py (the copy that travels to the GPU box) against the reference's
+    chaosuan_gfl_deformable_detr_40_r50_8x4_1x_qoqo_il.py: same model dict (but for the pretrained-checkpoint path),
+    same optimizer / clip / lr schedule / runner lists, same class split."""
+    if not os.path.isfile(REF_CFG):
+        pytest.skip("reference tree not present")
+    from dskd_amd.config import Config
+
+    def plain(x):
+        if isinstance(x, dict):
+            return {k: plain(v) for k, v in x.items()}
+        if isinstance(x, (list, tuple)):
+            return [plain(v) for v in x]
+        return x
+    ref = Config.fromfile(REF_CFG)
+    own = Config.fromfile(os.path.join(ROOT, "configs", "dskd_gfl_deformable_detr_r50_40_40.py"))
+    mr, mo = plain(ref.model), plain(own.model)
+    mr["backbone"]["init_cfg"] = mo["backbone"]["init_cfg"] = None
+    assert mr == mo
+    for k in ("optimizer", "optimizer_config", "lr_config", "runner"):
+        assert plain(ref[k]) == plain(own[k]), k
+    assert tuple(ref.data.train.catsplit) == tuple(own.data.train.catsplit) == (40, 40)
+
+
+def test_train_increment_command_line_is_the_reference_drivers(cpu_ops, tmp_path):
+    """/root/reference/tools/dist_train_increment.sh:22-28 calls ``train_increment.py --config=... --work-dir=...
+    --resume-from=$CHECKPOINT --launcher=pytorch``; the same spelling drives ours (CONFIG may also be positional),
+    an empty --resume-from means none, and a checkpoint given there restores student, optimizer and counters."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("train_increment", os.path.join(ROOT, "tools", "train_increment.py"))
+    ti = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ti)
+    a = ti.parse_args([f"--config={OWN_CFG}", f"--work-dir={tmp_path}", "--resume-from=", "--launcher=none"])
+    assert a.config == OWN_CFG and a.resume_from == "" and not a.auto_resume
+    assert ti.parse_args([OWN_CFG]).config == OWN_CFG
+    for bad in ([], [OWN_CFG, f"--config={OWN_CFG}"]):
+        with pytest.raises(SystemExit):
+            ti.parse_args(bad)
+    small = ["--device", "cpu", "--max-iters", "1", "--cfg-options", "data.samples_per_gpu=1", "data.workers_per_gpu=0",
+             "data.train.num_images=2", "data.train.img_size=(64,96)", "data.train.n_gt=2", "model.bbox_head.num_query=30",
+             "data.train.catsplit=(80,)", "data.train.catload=(1,)"]
+    r1 = ti.main([f"--config={OWN_CFG}", f"--work-dir={tmp_path}", "--resume-from=", "--max-epochs", "1"] + small)
+    ck = os.path.join(str(tmp_path), "task_1_epoch_1.pth")
+    assert len(r1) == 1 and os.path.isfile(ck) and ti.find_latest_checkpoint(str(tmp_path)) == ck
+    # resume: epoch 1 is done, so a 2-epoch run executes exactly one more epoch and starts from the saved weights
+    r2 = ti.main([f"--config={OWN_CFG}", f"--work-dir={tmp_path}", f"--resume-from={ck}", "--max-epochs", "2"] + small)
+    assert r2[0].epoch == 2 and r2[0].iter == 2 and [h["epoch"] for h in r2[0].history] == [2]
+    # --auto-resume picks the newest checkpoint of the work dir (now epoch 2): one more epoch of three is left
+    r3 = ti.main([f"--config={OWN_CFG}", f"--work-dir={tmp_path}", "--auto-resume", "--max-epochs", "3"] + small)
+    assert r3[0].epoch == 3 and r3[0].iter == 3 and [h["epoch"] for h in r3[0].history] == [3]
+    with pytest.raises(FileNotFoundError):
+        ti.main([f"--config={OWN_CFG}", f"--work-dir={tmp_path}", "--resume-from=/nonexistent.pth"] + small)

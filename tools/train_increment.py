@@ -8,8 +8,13 @@ student (:250-251), dataset + ``set_datainfo`` (:268-272), DDP wrap of the stude
 (:301-303), optimizer / lr / grad-clip / runner from the per-task config lists, run.
 Data is the synthetic IL dataset (the reference's dataset class is missing).
 
-  python tools/train_increment.py CONFIG --work-dir DIR [--launcher pytorch] \
-      [--cfg-options k=v ...] [--device cuda|cpu] [--amp bf16] [--max-iters N]
+  python tools/train_increment.py --config=CONFIG --work-dir=DIR [--resume-from=CKPT] [--auto-resume] \
+      [--launcher=pytorch] [--cfg-options k=v ...] [--device cuda|cpu] [--amp bf16] [--max-iters N]
+
+The command line is the reference's (:33-101), so /root/reference/tools/dist_train_increment.sh:22-28 drives
+it unchanged; CONFIG may also be given positionally.  ``--resume-from`` / ``cfg.task.resume_by_epoch``
+restore student + optimizer + epoch counters into the runner of the first task that runs (:355-361);
+``cfg.task.resume_by_task`` skips the earlier tasks the way the reference does (:211-237).
 """
 import argparse
 import ast
@@ -33,19 +38,56 @@ from dskd_amd.runner import TaskEpochBasedRunner, build_optimizer  # noqa: E402
 
 def parse_args(argv=None):
     p = argparse.ArgumentParser(description="Train a detector incrementally (DSKD)")
-    p.add_argument("config")
+    p.add_argument("config_pos", nargs="?", default=None, metavar="CONFIG", help="alias of --config")
+    p.add_argument("--config", default=None, help="train config file path")
     p.add_argument("--work-dir")
+    p.add_argument("--resume-from", default="", help="the checkpoint file to resume from")
+    p.add_argument("--auto-resume", action="store_true", help="resume from the latest checkpoint in the work dir")
+    p.add_argument("--print-model", action="store_true")
+    p.add_argument("--gpu-id", type=int, default=0, help="accepted for compatibility (one process drives one GPU)")
+    p.add_argument("--find_unused_param", action="store_true",
+                   help="accepted for compatibility: the one parameter unused by construction is excluded from DDP")
     p.add_argument("--seed", type=int, default=111)
     p.add_argument("--diff-seed", action="store_true")
     p.add_argument("--deterministic", action="store_true")
-    p.add_argument("--launcher", choices=["none", "pytorch"], default="none")
+    p.add_argument("--launcher", choices=["none", "pytorch", "slurm", "mpi"], default="none")
     p.add_argument("--local_rank", "--local-rank", type=int, default=0)
+    p.add_argument("--options", nargs="+", default=[], help="deprecated alias of --cfg-options")
     p.add_argument("--cfg-options", nargs="+", default=[])
     p.add_argument("--device", default="cuda" if torch.cuda.is_available() else "cpu")
     p.add_argument("--amp", choices=["none", "bf16"], default="none")
     p.add_argument("--max-iters", type=int, default=None, help="iterations per epoch (smoke runs)")
     p.add_argument("--max-epochs", type=int, default=None)
-    return p.parse_args(argv)
+    args = p.parse_args(argv)
+    if args.config is not None and args.config_pos is not None:
+        p.error("give the config once: positionally or with --config")
+    args.config = args.config or args.config_pos
+    if args.config is None:
+        p.error("a config file is required (--config=FILE)")
+    if args.options and args.cfg_options:
+        raise ValueError("--options and --cfg-options cannot be both specified, --options is deprecated in favor "
+                         "of --cfg-options")
+    if args.options:
+        args.cfg_options = args.options
+    if args.launcher in ("slurm", "mpi"):
+        p.error(f"--launcher={args.launcher}: only 'none' and 'pytorch' (one process per GPU) are implemented")
+    if "LOCAL_RANK" not in os.environ:
+        os.environ["LOCAL_RANK"] = str(args.local_rank)
+    return args
+
+
+def find_latest_checkpoint(work_dir):
+    """Newest ``task_{t}_epoch_{e}.pth`` of a work dir by (task, epoch), or None."""
+    import re
+    best = None
+    if work_dir and os.path.isdir(work_dir):
+        for f in os.listdir(work_dir):
+            m = re.fullmatch(r"task_(\d+)_epoch_(\d+)\.pth", f)
+            if m:
+                key = (int(m.group(1)), int(m.group(2)))
+                if best is None or key > best[0]:
+                    best = (key, os.path.join(work_dir, f))
+    return best[1] if best else None
 
 
 def _parse_opts(pairs):
@@ -80,9 +122,38 @@ def main(argv=None, cpu_checker=None):
 
     task_nums = len(cfg.data.train.catsplit)
     assert cfg.data.get("cat_split_load", "auto") == "auto", "only continuous task training is implemented"
+    # resume controls of the reference driver (:140-142, :211-237, :355-361)
+    task_cfg = cfg.get("task") or {}
+    resume_by_task = int(task_cfg.get("resume_by_task") or 0)
+    resume_from = args.resume_from or task_cfg.get("resume_by_epoch") or cfg.get("resume_from") or ""
+    if not resume_from and args.auto_resume:
+        resume_from = find_latest_checkpoint(work_dir) or ""
+    if resume_from and not os.path.isfile(resume_from):
+        raise FileNotFoundError(f"--resume-from: {resume_from} does not exist")
+
+    def student_ckpt_of(tid):
+        tcfg = task_cfg.get(f"Task{tid}", {}) or {}
+        ck = tcfg.get("student_ckpt") if tcfg.get("load_student") else None
+        return ck if ck and os.path.isfile(str(ck)) else None
+
+    # "resume by task" means: the student of task `resume_by_task` comes from its checkpoint and training continues
+    # with the next task.  Without that checkpoint on disk there is nothing to resume from: train every task.
+    if resume_by_task and student_ckpt_of(resume_by_task) is None:
+        log(f"task.resume_by_task={resume_by_task}: no student checkpoint on disk, training from task 1")
+        resume_by_task = 0
     model, runners = None, []
     for tid in range(1, task_nums + 1):
+        if tid < resume_by_task:
+            log(f"======== Task-{tid} skipped (resume_by_task={resume_by_task}) ========")
+            continue
         log(f"======== Task-{tid} start ========")
+        if tid == resume_by_task:
+            model = build_detector(cfg.model, train_cfg=cfg.get("train_cfg"), test_cfg=cfg.get("test_cfg"))
+            model.init_weights()
+            model.set_student(ckptfile=student_ckpt_of(tid))
+            model.set_teacher(config=None, ckptfile=None, model=None, trainval="val")
+            log(f"======== Task-{tid} skipped: student resumed from {student_ckpt_of(tid)} ========")
+            continue
         if tid == 1:
             cfg.model.backbone.init_cfg = cfg.model.backbone.get("init_cfg") if cfg.model.backbone.get("init_cfg") and \
                 os.path.isfile(str(cfg.model.backbone.init_cfg.get("checkpoint", ""))) else None
@@ -119,6 +190,12 @@ def main(argv=None, cpu_checker=None):
                                       checkpoint_interval=cfg.get("checkpoint_config", {}).get("interval", 1),
                                       amp_dtype=torch.bfloat16 if args.amp == "bf16" else None,
                                       max_iters_per_epoch=args.max_iters, **rcfg)
+        if args.print_model and rank == 0 and not runners:
+            log(model)
+        if resume_from:                # student + optimizer + epoch / iteration counters of an interrupted task
+            meta = runner.resume(resume_from, map_location="cpu")
+            log(f"resumed from {resume_from}: {meta}")
+            resume_from = ""
         tic = time.time()
         runner.run([loader], cfg.get("workflow", [("train", 1)]), cur_task=tid)
         log(f"======== Task-{tid} done in {time.time() - tic:.1f}s ========")
