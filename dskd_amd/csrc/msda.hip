@@ -28,6 +28,7 @@
 //    full-rate shape, MI355X_MICROARCH.md "Global float atomics"); grad_loc / grad_attn
 //    come from per-head dot products reduced with DPP inside 8- / 4-lane groups.
 #include "common.h"
+#include "msda_internal.h"
 #include <stdlib.h>
 
 namespace dskd {
@@ -985,13 +986,42 @@ int launch_value_variant(const float* loc, const float* attn, const T* grad_out,
   }
 }
 
+// variants: bit v set = launch level group v (0: level 0, 1: level 1, 2: levels 2+3)
 template <typename T>
 int launch_value(const float* loc, const float* attn, const T* grad_out, float* grad_value,
                  const ValueGeom& g, const VarGeom* var, const size_t* lds, int B, int Nq, int LP,
-                 int points, hipStream_t st) {
-  if (int rc = launch_value_variant<T, 0>(loc, attn, grad_out, grad_value, g, var[0], lds[0], B, Nq, LP, points, st)) return rc;
-  if (int rc = launch_value_variant<T, 1>(loc, attn, grad_out, grad_value, g, var[1], lds[1], B, Nq, LP, points, st)) return rc;
-  return launch_value_variant<T, 2>(loc, attn, grad_out, grad_value, g, var[2], lds[2], B, Nq, LP, points, st);
+                 int points, hipStream_t st, int variants = 7) {
+  if (variants & 1)
+    if (int rc = launch_value_variant<T, 0>(loc, attn, grad_out, grad_value, g, var[0], lds[0], B, Nq, LP, points, st)) return rc;
+  if (variants & 2)
+    if (int rc = launch_value_variant<T, 1>(loc, attn, grad_out, grad_value, g, var[1], lds[1], B, Nq, LP, points, st)) return rc;
+  if (variants & 4)
+    return launch_value_variant<T, 2>(loc, attn, grad_out, grad_value, g, var[2], lds[2], B, Nq, LP, points, st);
+  return DSKD_OK;
+}
+
+// rows [row0, row0 + nrows) of every image of grad_value ([B, Nv, 256] f32) = 0
+__global__ void zero_rows_kernel(float* __restrict__ gv, int Nv, int row0, int nrows) {
+  u32x4* base = reinterpret_cast<u32x4*>(gv + ((size_t)blockIdx.y * Nv + row0) * (kHeads * kCh));
+  const size_t n16 = (size_t)nrows * (kHeads * kCh) / 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+    base[i] = u32x4{0u, 0u, 0u, 0u};
+}
+
+// Levels whose grad_value rows the tiled pull kernel (msda_pull.hip) produces; the others stay on the windowed
+// LDS-accumulation kernels.  Default: level 0 (75 % of the pixels, ~21 contributions per cell -> gather form: 124 us
+// against 197 us at B=4); from level 1 on a cell sums 85 / 340 / 1 300 contributions and accumulating in LDS windows
+// (scatter form) is faster (level 1: 175 us windowed, 209 us pulled -- profiles/r02_msda_bwd_pull_ab.txt).
+// DSKD_MSDA_PULL_LEVELS=<digits> overrides ("" or "none": no pull; levels 2 and 3 only together).
+inline int pull_level_mask() {
+  int mask = 1;
+  if (const char* e = getenv("DSKD_MSDA_PULL_LEVELS")) {
+    mask = 0;
+    for (const char* c = e; *c; ++c)
+      if (*c >= '0' && *c <= '3') mask |= 1 << (*c - '0');
+  }
+  if (((mask >> 2) & 3) != 0 && ((mask >> 2) & 3) != 3) mask &= 3;
+  return mask;
 }
 
 // ------------------------------------------------------------------ forward, windowed (encoder, bf16)
@@ -1488,12 +1518,14 @@ extern "C" int dskd_msda_fwd_fused(const void* value, const int64_t* spatial_sha
   return check_launch("dskd_msda_fwd_fused");
 }
 
-extern "C" int dskd_msda_bwd(const void* value, const int64_t* spatial_shapes,
-                             const int64_t* level_start, const float* loc,
-                             const float* attn, const void* grad_out, float* grad_value,
-                             float* grad_loc, float* grad_attn, int B, int Nv, int Nq,
-                             int heads, int ch, int levels, int points, int dtype,
-                             void* stream) {
+namespace dskd {
+namespace {
+// workspace != nullptr: the caller's grad_value is NOT assumed zeroed (this function zeroes what its atomics need)
+// and the fine levels may go through the pull kernel.
+int msda_bwd_impl(const void* value, const int64_t* spatial_shapes, const int64_t* level_start, const float* loc,
+                  const float* attn, const void* grad_out, float* grad_value, float* grad_loc, float* grad_attn,
+                  int B, int Nv, int Nq, int heads, int ch, int levels, int points, int dtype, void* workspace,
+                  size_t workspace_bytes, void* stream) {
   if (int rc = check_shapes("dskd_msda_bwd", B, Nv, Nq, heads, ch, levels, points, dtype)) return rc;
   if (!value || !loc || !attn || !grad_out || !grad_value || !grad_loc || !grad_attn ||
       !spatial_shapes || !level_start)
@@ -1514,13 +1546,35 @@ extern "C" int dskd_msda_bwd(const void* value, const int64_t* spatial_shapes,
   const char* env = getenv("DSKD_MSDA_BWD");   // "v1" forces the plain-atomics kernel (A/B tests)
   const bool force_v1 = env && env[0] == 'v' && env[1] == '1';
   const bool windowed = !force_v1 && Nq == Nv && make_value_geom(g, levels, points, Nq, &vg, var, lds);
+  int pull_mask = 0;
+  MsdaLevels ml;
+  if (workspace) {
+    for (int l = 0; l < kMaxLevels; ++l) { ml.H[l] = g.H[l]; ml.W[l] = g.W[l]; ml.start[l] = g.start[l]; }
+    if (windowed) {
+      pull_mask = pull_level_mask();
+      if (pull_mask && !pull_supported(ml, levels, points, Nv, Nq, dtype, pull_mask)) pull_mask = 0;
+    }
+    // zero what the atomics of the remaining kernels add into
+    if (pull_mask == 0) {
+      zero_fill(grad_value, sizeof(float) * (size_t)B * Nv * (kHeads * kCh), st);
+    } else {
+      for (int l = 0; l < levels; ++l)
+        if (!(pull_mask & (1 << l))) {
+          const int nrows = g.H[l] * g.W[l];
+          const int bx = (nrows * 64 + 255) / 256;
+          hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)(bx < 1024 ? bx : 1024), (unsigned)B), dim3(256), 0, st,
+                             grad_value, Nv, g.start[l], nrows);
+        }
+    }
+  }
+  const int variants = (pull_mask & 1 ? 0 : 1) | (pull_mask & 2 ? 0 : 2) | ((pull_mask >> 2) == 3 ? 0 : 4);
   if (windowed) {
     if (dtype == DSKD_DTYPE_F32) {
       hipLaunchKernelGGL((msda_bwd_kernel<float, false, 1>), grid, block, 0, st, (const float*)value, loc, attn,
                          (const float*)grad_out, grad_value, grad_loc, grad_attn, g, Nv, Nq, LP, points, qpb,
                          bpi);
       if (int rc = launch_value<float>(loc, attn, (const float*)grad_out, grad_value, vg, var, lds, B, Nq, LP,
-                                       points, st)) return rc;
+                                       points, st, variants)) return rc;
     } else {
 #define DSKD_BWD_BF16(PH)                                                                                         \
   hipLaunchKernelGGL((msda_bwd_kernel<__bf16, false, PH>), grid, block, 0, st, (const __bf16*)value, loc, attn,   \
@@ -1532,8 +1586,11 @@ extern "C" int dskd_msda_bwd(const void* value, const int64_t* spatial_shapes,
       }
 #undef DSKD_BWD_BF16
       if (int rc = launch_value<__bf16>(loc, attn, (const __bf16*)grad_out, grad_value, vg, var, lds, B, Nq, LP,
-                                        points, st)) return rc;
+                                        points, st, variants)) return rc;
     }
+    if (pull_mask)
+      if (int rc = launch_pull(loc, attn, grad_out, grad_value, ml, pull_mask, B, Nq, dtype, workspace,
+                               workspace_bytes, st)) return rc;
     return check_launch("dskd_msda_bwd");
   }
   if (dtype == DSKD_DTYPE_F32)
@@ -1545,6 +1602,41 @@ extern "C" int dskd_msda_bwd(const void* value, const int64_t* spatial_shapes,
                        attn, (const __bf16*)grad_out, grad_value, grad_loc, grad_attn, g, Nv,
                        Nq, LP, points, qpb, bpi);
   return check_launch("dskd_msda_bwd");
+}
+}  // namespace
+}  // namespace dskd
+
+extern "C" int dskd_msda_bwd(const void* value, const int64_t* spatial_shapes,
+                             const int64_t* level_start, const float* loc,
+                             const float* attn, const void* grad_out, float* grad_value,
+                             float* grad_loc, float* grad_attn, int B, int Nv, int Nq,
+                             int heads, int ch, int levels, int points, int dtype,
+                             void* stream) {
+  return msda_bwd_impl(value, spatial_shapes, level_start, loc, attn, grad_out, grad_value, grad_loc, grad_attn, B, Nv,
+                       Nq, heads, ch, levels, points, dtype, nullptr, 0, stream);
+}
+
+extern "C" int64_t dskd_msda_bwd_workspace(int B, int Nv, int Nq, int heads, int levels, int points) {
+  (void)Nv;
+  if (B < 0 || Nq < 0 || heads < 0 || levels < 0 || points < 0) return -1;
+  // header + room for 1/16 of all (query, head, point, corner) contributions as stray entries
+  int64_t entries = (int64_t)B * Nq * heads * levels * points * 4 / 16;
+  if (entries < 4096) entries = 4096;
+  return (int64_t)kPullWsHeader + entries * (int64_t)kPullWsEntry;
+}
+
+extern "C" int dskd_msda_bwd_ws(const void* value, const int64_t* spatial_shapes,
+                                const int64_t* level_start, const float* loc,
+                                const float* attn, const void* grad_out, float* grad_value,
+                                float* grad_loc, float* grad_attn, int B, int Nv, int Nq,
+                                int heads, int ch, int levels, int points, int dtype,
+                                void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!workspace || workspace_bytes < (int64_t)(kPullWsHeader + kPullWsEntry) ||
+      (reinterpret_cast<uintptr_t>(workspace) & 15))
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_msda_bwd_ws: need a 16-byte aligned workspace of at least %d bytes",
+                (int)(kPullWsHeader + kPullWsEntry));
+  return msda_bwd_impl(value, spatial_shapes, level_start, loc, attn, grad_out, grad_value, grad_loc, grad_attn, B, Nv,
+                       Nq, heads, ch, levels, points, dtype, workspace, (size_t)workspace_bytes, stream);
 }
 
 #ifdef DSKD_VALUE_PROFILE

@@ -29,6 +29,8 @@ _SIGNATURES = {
     "dskd_msda_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [C.c_int] * 8 + [_vp]),
     "dskd_msda_fwd_fused": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [C.c_int] * 8 + [_vp]),
     "dskd_msda_bwd": (C.c_int, [_vp] * 9 + [C.c_int] * 8 + [_vp]),
+    "dskd_msda_bwd_workspace": (C.c_int64, [C.c_int] * 6),
+    "dskd_msda_bwd_ws": (C.c_int, [_vp] * 9 + [C.c_int] * 8 + [_vp, _i64, _vp]),
     "dskd_msda_prep_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_msda_prep_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_add_ln_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, _f32, _f32,
@@ -206,15 +208,42 @@ def msda_backward_raw(value, shapes, loc, attn, grad_out):
     dt = {torch.float32: DTYPE_F32, torch.bfloat16: DTYPE_BF16}[value.dtype]
     value, loc, attn = value.contiguous(), loc.contiguous().float(), attn.contiguous().float()
     grad_out = grad_out.contiguous().to(value.dtype)
-    gv = torch.zeros((B, Nv, heads, ch), dtype=torch.float32, device=value.device)
     gl = torch.empty_like(loc)
     ga = torch.empty_like(attn)
+    # Encoder shape: the workspace entry point (fine levels through the tiled pull kernel, grad_value written, not
+    # accumulated -> no zero fill).  DSKD_MSDA_BWD=v1|win keeps the older kernels for A/B runs.
+    if Nq == Nv and L == 4 and P == 4 and os.environ.get("DSKD_MSDA_BWD", "") == "":
+        ws = _msda_bwd_workspace(value.device, B, Nv, Nq, heads, L, P)
+        gv = torch.empty((B, Nv, heads, ch), dtype=torch.float32, device=value.device)
+        with _timed("msda_bwd_enc"):
+            rc = load().dskd_msda_bwd_ws(value.data_ptr(), ss, ls, loc.data_ptr(), attn.data_ptr(), grad_out.data_ptr(),
+                                         gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), B, Nv, Nq, heads, ch, L, P, dt,
+                                         ws.data_ptr(), ws.numel(), _stream(value))
+        _check(rc, "dskd_msda_bwd_ws")
+        return gv, gl, ga
+    gv = torch.zeros((B, Nv, heads, ch), dtype=torch.float32, device=value.device)
     with _timed("msda_bwd_enc" if Nq == Nv else "msda_bwd_dec"):
         rc = load().dskd_msda_bwd(value.data_ptr(), ss, ls, loc.data_ptr(), attn.data_ptr(), grad_out.data_ptr(),
                                   gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), B, Nv, Nq, heads, ch, L, P, dt,
                                   _stream(value))
     _check(rc, "dskd_msda_bwd")
     return gv, gl, ga
+
+
+_msda_ws_cache = {}
+
+
+def _msda_bwd_workspace(device, B, Nv, Nq, heads, L, P) -> torch.Tensor:
+    """Workspace of ``dskd_msda_bwd_ws`` (stray-sample list; header zeroed once, the library leaves it zeroed),
+    one per (device, stream): launches on one stream are ordered, so consecutive calls can share it."""
+    need = int(load().dskd_msda_bwd_workspace(B, Nv, Nq, heads, L, P))
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _msda_ws_cache.get(key)
+    if ws is None or ws.numel() < need:
+        if torch.cuda.is_current_stream_capturing():
+            raise NativeError("msda backward workspace must be allocated before a hipGraph capture (run one eager step)")
+        ws = _msda_ws_cache[key] = torch.zeros(need, dtype=torch.uint8, device=device)
+    return ws
 
 
 class _MSDAFunction(torch.autograd.Function):

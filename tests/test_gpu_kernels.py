@@ -167,6 +167,114 @@ def test_msda_bwd_windowed_matches_plain_atomics_full_size(monkeypatch):
     torch.testing.assert_close(gv2.sum(dim=(1,)), gv1.sum(dim=(1,)), atol=5e-2, rtol=1e-3)
 
 
+def _bwd_oracle(value, shapes, loc, attn, go):
+    v = value.float().requires_grad_(True)
+    l = loc.clone().requires_grad_(True)
+    a = attn.clone().requires_grad_(True)
+    msda_ref.msda_grid_sample(v, shapes, l.nan_to_num(nan=-5.0), a).backward(go.float())
+    return v.grad, l.grad, a.grad
+
+
+@pytest.mark.parametrize("levels", ["01", "0123", "1", "023"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_msda_bwd_pull_levels_vs_oracle(monkeypatch, levels, dtype):
+    """The tiled pull kernel (msda_pull.hip) on any subset of the levels, the windowed kernels on the rest: grad_value
+    against autograd of the oracle, with border / rejected / NaN / far-away sampling locations in the batch (the
+    far ones go through the stray list and the apply kernel), an output buffer full of garbage (it is overwritten, not
+    accumulated into) and the workspace header left zeroed."""
+    shapes = [(40, 70), (20, 35), (10, 18), (5, 9)]
+    value, loc, attn, go = _encoder_like_inputs(shapes, 2, 77, 3.0, dtype)
+    loc[0, :7] = torch.tensor([-0.2, 0.0, 0.5, 1.0, 1.3, float("nan"), 0.999]).view(7, 1, 1, 1, 1)
+    loc[1, 100:140] += 0.37                                   # far beyond every candidate margin
+    gv_ref, _, _ = _bwd_oracle(value, shapes, loc, attn, go)
+    monkeypatch.setenv("DSKD_MSDA_PULL_LEVELS", levels)
+    lib = native.load()
+    B, Nv = value.shape[:2]
+    ss, ls, _ = native._geom(shapes)
+    vd, ld, ad, gd = value.to(DEV), loc.to(DEV), attn.to(DEV), go.to(DEV)
+    need = int(lib.dskd_msda_bwd_workspace(B, Nv, Nv, 8, 4, 4))
+    ws = torch.zeros(need, dtype=torch.uint8, device=DEV)
+    dt = native.DTYPE_F32 if dtype == torch.float32 else native.DTYPE_BF16
+    outs = []
+    for _ in range(2):                                        # second call: same workspace, header must have been reset
+        gv = torch.full((B, Nv, 8, 32), float("nan"), device=DEV)
+        gl, ga = torch.empty_like(ld), torch.empty_like(ad)
+        rc = lib.dskd_msda_bwd_ws(vd.data_ptr(), ss, ls, ld.data_ptr(), ad.data_ptr(), gd.data_ptr(), gv.data_ptr(),
+                                  gl.data_ptr(), ga.data_ptr(), B, Nv, Nv, 8, 32, 4, 4, dt, ws.data_ptr(), need,
+                                  torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, lib.dskd_last_error()
+        torch.cuda.synchronize()
+        assert int(ws[:64].to(torch.int32).sum()) == 0
+        outs.append(gv)
+    tol = dict(atol=2e-4, rtol=1e-3) if dtype == torch.float32 else dict(atol=4e-3, rtol=4e-3)
+    for gv in outs:
+        torch.testing.assert_close(gv.cpu(), gv_ref, **tol)
+
+
+def test_msda_bwd_pull_stray_list_overflow():
+    """A workspace with room for ONE stray entry while thousands of samples leave their candidate ranges: the apply
+    kernel ignores the list, walks every tile again and adds the strays directly -- same result."""
+    shapes = [(40, 70), (20, 35), (10, 18), (5, 9)]
+    value, loc, attn, go = _encoder_like_inputs(shapes, 2, 79, 14.0)
+    gv_ref, _, _ = _bwd_oracle(value, shapes, loc, attn, go)
+    lib = native.load()
+    B, Nv = value.shape[:2]
+    ss, ls, _ = native._geom(shapes)
+    vd, ld, ad, gd = value.to(DEV), loc.to(DEV), attn.to(DEV), go.to(DEV)
+    ws = torch.zeros(64 + 16, dtype=torch.uint8, device=DEV)
+    for _ in range(2):
+        gv = torch.full((B, Nv, 8, 32), float("nan"), device=DEV)
+        gl, ga = torch.empty_like(ld), torch.empty_like(ad)
+        rc = lib.dskd_msda_bwd_ws(vd.data_ptr(), ss, ls, ld.data_ptr(), ad.data_ptr(), gd.data_ptr(), gv.data_ptr(),
+                                  gl.data_ptr(), ga.data_ptr(), B, Nv, Nv, 8, 32, 4, 4, native.DTYPE_F32, ws.data_ptr(),
+                                  ws.numel(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, lib.dskd_last_error()
+        torch.cuda.synchronize()
+        assert int(ws[:64].to(torch.int32).sum()) == 0
+        torch.testing.assert_close(gv.cpu(), gv_ref, atol=2e-4, rtol=1e-3)
+    # argument checks
+    assert lib.dskd_msda_bwd_ws(vd.data_ptr(), ss, ls, ld.data_ptr(), ad.data_ptr(), gd.data_ptr(), gv.data_ptr(),
+                                gl.data_ptr(), ga.data_ptr(), B, Nv, Nv, 8, 32, 4, 4, native.DTYPE_F32, None, 0,
+                                torch.cuda.current_stream().cuda_stream) == -1
+    assert lib.dskd_msda_bwd_workspace(2, Nv, Nv, 8, 4, 4) >= 64 + 16 * 4096
+
+
+def test_msda_bwd_heavy_tailed_gradient():
+    """One grad_out element 1e4 times the rest.  The pull kernel accumulates level 0 (75 % of the
+    value rows) in f32 registers, so a cell's error is relative to the cell: its rows keep the usual tolerance next to
+    the spike.  Levels 1-3 accumulate in 32-bit fixed point scaled by the REGION's bound max|grad_out| * sum|attn|
+    (msda.hip), quantum = bound / 1e9 per contribution: inside the spike's region (<= 32 x 32 level-0 pixels) the
+    absolute error of a cell is a few quanta times sqrt(contributions) -- stated and checked here -- and every other
+    region keeps the usual tolerance."""
+    value, loc, attn, go = _encoder_like_inputs(SHAPES_FULL, 1, 47, 2.5)
+    spike_q = 50 * 167 + 80                                   # a level-0 query in the middle of the image
+    go[0, spike_q, 37] = 1.0e4
+    gv_ref, _, _ = _bwd_oracle(value, SHAPES_FULL, loc, attn, go)
+    gv, _, _ = native.msda_backward_raw(value.to(DEV), SHAPES_FULL, loc.to(DEV), attn.to(DEV), go.to(DEV))
+    gv = gv.cpu()
+    n0 = 100 * 167
+    torch.testing.assert_close(gv[:, :n0], gv_ref[:, :n0], atol=2e-4, rtol=1e-3)
+    # fixed-point levels: bound <= 1e4 * sum|attn| over the region's ~700 queries (4..8 of 16 samples each: ~250) = 2.5e6,
+    # quantum 2.5e-3; a level-1 / 2 / 3 cell sums ~85 / ~340 / ~1 300 contributions -> error of a few 1e-2 next to the spike
+    err = (gv[:, n0:] - gv_ref[:, n0:]).abs()
+    assert float(err.max()) < 0.5, float(err.max())
+    ok = err <= 2e-4 + 1e-3 * gv_ref[:, n0:].abs()
+    assert float(ok.float().mean()) > 0.85, float(ok.float().mean())     # every cell outside the spike's region
+
+
+def test_msda_bwd_pull_matches_windowed_full_size(monkeypatch):
+    """BASELINE size, B=2, bf16 (the benchmark's mode): default path (pull on level 0) against the all-windowed
+    path of round 1 (DSKD_MSDA_BWD=win); grad_loc / grad_attn come from the same gather kernel in both."""
+    value, loc, attn, go = _encoder_like_inputs(SHAPES_FULL, 2, 49, 2.5, torch.bfloat16)
+    args = (value.to(DEV), SHAPES_FULL, loc.to(DEV), attn.to(DEV), go.to(DEV))
+    gv2, gl2, ga2 = native.msda_backward_raw(*args)
+    monkeypatch.setenv("DSKD_MSDA_BWD", "win")
+    gv1, gl1, ga1 = native.msda_backward_raw(*args)
+    monkeypatch.delenv("DSKD_MSDA_BWD")
+    torch.testing.assert_close(gv2, gv1, atol=4e-3, rtol=4e-3)
+    assert torch.equal(gl2, gl1) and torch.equal(ga2, ga1)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_msda_bwd_full_size_vs_oracle(dtype):
     """BASELINE size (100x167 ... 13x21, Nq = Nv = 22 223), one image: grad_value, grad_loc and grad_attn of the

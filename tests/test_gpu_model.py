@@ -82,9 +82,46 @@ def test_full_step_gpu_matches_cpu_oracle_fp32(oracle_checker, cfg_file):
         native.install_cpu_checker(None)
     lv_g = run(m_gpu, data_g, inj_g)
     assert set(lv_c) == set(lv_g)
+    # An untrained detector sits on assignment near-ties: the three teacher boxes of this batch are matched to three
+    # of 300 almost identical queries, and loss_corr is the distance matrix of exactly those three embeddings.  With
+    # the Swin trunk the GPU / CPU fp32 difference (fused attention) is enough to move one of them, so for that
+    # configuration loss_corr is compared in the two-stage form below (same head inputs on both devices) instead.
+    loose = {"loss_corr"} if cfg_file == CFG_SWIN else set()
+    bad = []
     for k in lv_c:
         rtol = 5e-2 if k == "loss_fg_feature" else 2e-3       # fp32 reference noise of decode_v1, see kernel tests
-        assert lv_g[k] == pytest.approx(lv_c[k], rel=rtol, abs=1e-5), k
+        if k not in loose and lv_g[k] != pytest.approx(lv_c[k], rel=rtol, abs=1e-5):
+            bad.append((k, lv_g[k], lv_c[k]))
+    assert not bad, bad
+    # two-stage form: trunk outputs GPU vs CPU, then the head's loss() on the GPU against loss() on the CPU
+    # (oracle ops) fed with the SAME head inputs (the GPU's, copied)
+    dev, cpu = torch.device("cuda:0"), torch.device("cpu")
+    with torch.no_grad():
+        xg = m_gpu.extract_feat(data_g["img"])
+        og = m_gpu.bbox_head.forward(xg, data_g["img_metas"])
+        feats_t, outs_t, *_ = m_gpu.out_teacher(data_g["img"], data_g["img_metas"])
+
+    def to(x, d):
+        if torch.is_tensor(x):
+            return x.to(d)
+        if isinstance(x, (list, tuple)):
+            return type(x)(to(y, d) for y in x)
+        return x
+    tl = m_gpu.LableInPCNTask
+    ti_g = dict(neck_feats=feats_t, head_outs=outs_t, pred_keepid=inj_g["pred_keepid"], pred_logits=None, pred_scores=None,
+                pred_labels=inj_g["pred_labels"], pred_bboxes=inj_g["pred_bboxes"])
+    lg = m_gpu.bbox_head.loss(*og, data_g["gt_bboxes"], data_g["gt_labels"], data_g["img_metas"], student_feat=xg,
+                              teacher_info=ti_g, task_labels=tl)
+    native.install_cpu_checker(oracle_checker)
+    try:
+        lc = m_cpu.bbox_head.loss(*to(og, cpu), data_c["gt_bboxes"], data_c["gt_labels"], data_c["img_metas"],
+                                  student_feat=to(xg, cpu), teacher_info=to(ti_g, cpu), task_labels=tl)
+    finally:
+        native.install_cpu_checker(None)
+    assert set(lg) == set(lc)
+    for k in lc:
+        rtol = 5e-2 if k == "loss_fg_feature" else 1e-3
+        torch.testing.assert_close(lg[k].detach().cpu(), lc[k].detach(), rtol=rtol, atol=1e-6, msg=lambda m: f"{k}: {m}")
     names = ["bbox_head.cls_branches.0.weight", "bbox_head.transformer.decoder.layers.5.ffns.0.layers.1.weight",
              "bbox_head.transformer.encoder.layers.0.attentions.0.value_proj.weight", "neck.convs.0.conv.weight"]
     names.append("backbone.stages.3.blocks.1.attn.w_msa.qkv.weight" if cfg_file == CFG_SWIN else "backbone.layer4.2.conv3.weight")
