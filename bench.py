@@ -132,10 +132,10 @@ def train_step(model, wrapped, optimizer, data, synth, amp_dtype, max_norm=0.1, 
     return loss, log_vars
 
 
-def cpu_baseline(seed, num_prev):
-    """The CPU oracle path of the same step (PyTorch CPU kernels + grid_sample MSDA + oracle
-    LSAP + loop DSKD losses), B=1 at 800x1333, 1 step, all host cores.  Bounded sample: one
-    image-step (~10-30 s of CPU work)."""
+def cpu_baseline(seed, num_prev, batch=1, timed=3):
+    """The CPU oracle path of the same step (PyTorch CPU kernels + grid_sample MSDA + oracle LSAP + loop DSKD
+    losses) on this host's cores: 1 warm-up + ``timed`` timed steps at ``batch`` images (SURVEY.md section 8d
+    protocol), 800x1333, fp32.  Bounded sample: (1 + timed) image-steps at B=1 are ~30-40 s of CPU work."""
     from oracle.checker import OracleChecker
     native.install_cpu_checker(OracleChecker())
     try:
@@ -146,17 +146,68 @@ def cpu_baseline(seed, num_prev):
             avail = os.cpu_count() or 1
         cores = max(1, min(avail, 16))
         torch.set_num_threads(cores)
-        print(f"[bench] cpu_baseline: 1 step, B=1, {cores} threads ...", file=sys.stderr, flush=True)
+        print(f"[bench] cpu_baseline: 1 warm-up + {timed} timed steps, B={batch}, {cores} threads ...", file=sys.stderr,
+              flush=True)
         cfg, model = build_models(torch.device("cpu"), seed, dropout=None)
         opt = build_optimizer(model, cfg.optimizer[0])
-        data, synth = make_batch(1, num_prev, seed, torch.device("cpu"))
-        t0 = time.time()
-        train_step(model, model, opt, data, synth, None)
-        dt = time.time() - t0
-        return {"value": round(1.0 / dt, 5), "unit": "images/sec", "cores": cores, "kind": "port",
-                "sample": f"1 full distillation step, B=1, 800x1333, fp32, oracle CPU path ({dt:.1f} s)"}
+        data, synth = make_batch(batch, num_prev, seed, torch.device("cpu"))
+        times = []
+        for i in range(1 + timed):
+            t0 = time.time()
+            train_step(model, model, opt, data, synth, None)
+            times.append(time.time() - t0)
+            print(f"[bench] cpu_baseline step {i}: {times[-1]:.1f} s", file=sys.stderr, flush=True)
+        dt = sum(times[1:]) / max(len(times) - 1, 1)
+        return {"value": round(batch / dt, 5), "unit": "images/sec", "cores": cores, "kind": "port",
+                "sample": f"1 warm-up + {timed} timed full distillation steps, B={batch}, 800x1333, fp32, oracle CPU path "
+                          f"({dt:.1f} s/step; warm-up {times[0]:.1f} s)"}
     finally:
         native.install_cpu_checker(None)
+
+
+GEMM_CONV_PATTERNS = ("Cijk_", "ck::", "_ZN2ck", "igemm_", "miopen", "MIOpen", "gemm_xdl", "xdlops", "wrw_", "naive_conv",
+                      "attn_fwd", "bwd_kernel_dk_dv", "bwd_kernel_dq")
+MFMA_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
+
+
+def mfma_utilisation(step_fn, dtype):
+    """north_star: 'MFMA utilisation vs gfx950 peak' of the dense part.  One eager step under FlopCounterMode counts the
+    FLOPs of every GEMM / convolution / attention call (forward and backward, teacher and student); one eager step
+    under the profiler sums the device time of the library kernels that execute them; utilisation = FLOPs / that
+    time / dense bf16 peak."""
+    from torch.profiler import ProfilerActivity, profile
+    from torch.utils.flop_counter import FlopCounterMode
+
+    def addmm_act_flop(self_shape, a_shape, b_shape, *args, out_shape=None, **kwargs):   # bias + [m,k] x [k,n] + activation
+        return 2 * a_shape[0] * a_shape[1] * b_shape[1]
+    with FlopCounterMode(display=False, custom_mapping={torch.ops.aten._addmm_activation: addmm_act_flop}) as fc:
+        step_fn()
+    torch.cuda.synchronize()
+    flops = float(fc.get_total_flops())
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        step_fn()
+        torch.cuda.synchronize()
+    t_us, n, total_us, names = 0.0, 0, 0.0, {}
+    for e in prof.key_averages():
+        dt = float(getattr(e, "self_device_time_total", 0.0) or 0.0)
+        if dt <= 0 or "Memcpy" in e.key or "Memset" in e.key:
+            continue
+        total_us += dt
+        if any(pat in e.key for pat in GEMM_CONV_PATTERNS):
+            t_us += dt
+            n += e.count
+            names[e.key[:48]] = names.get(e.key[:48], 0.0) + dt
+    if t_us <= 0:
+        return None
+    top = sorted(names.items(), key=lambda kv: -kv[1])[:4]
+    tflops = flops / (t_us * 1e-6) / 1e12
+    peak = MFMA_PEAK_TFLOPS if dtype == "bf16" else MFMA_PEAK_TFLOPS / 16      # fp32: no MFMA-rate claim, reported for scale
+    return {"flops_per_step": round(flops / 1e12, 3), "unit": "TFLOP", "gemm_conv_kernel_ms": round(t_us / 1e3, 2),
+            "gemm_conv_launches": n, "all_kernel_ms": round(total_us / 1e3, 2), "achieved_TFLOPs": round(tflops, 1),
+            "peak_TFLOPs": peak, "frac": round(tflops / peak, 4),
+            "counted": "aten mm/addmm/bmm/convolution/sdpa, forward + backward, teacher + student (FlopCounterMode); time "
+                       "= device time of the hipBLASLt / CK / MIOpen / attention kernels in one profiled eager step",
+            "top_kernels_ms": {k: round(v / 1e3, 2) for k, v in top}}
 
 
 def main():
@@ -168,6 +219,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--dropout", type=float, default=None, help="override dropout p (default: config, 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-batch", type=int, default=1, help="images per CPU-baseline step (SURVEY 8d: B=1 and "
+                    "B=4; B=4 takes ~2.5 min more)")
+    ap.add_argument("--no-mfma-probe", action="store_true", help="skip the FLOP count / profiler pass behind `mfma`")
     ap.add_argument("--graph", action="store_true", help="EXPERIMENTAL: replay the step as hipGraphs "
                     "(dskd_amd/graph_step.py) instead of eager launches + DDP")
     ap.add_argument("--no-teacher-ahead", action="store_true", help="run the teacher inline on the main stream "
@@ -299,6 +353,9 @@ def main():
     # launch can be bracketed by HIP events on the launch stream (events cannot be recorded
     # inside a replayed hipGraph on ROCm).  Not part of the timed region.
     native.timing_enable(True)
+    model.bbox_head.graph_head = False          # launches inside a replayed hipGraph cannot be bracketed by events
+    if ahead is not None:
+        ahead.use_graphs = False                # the teacher's 12 fused MSDA forwards too: probe them eagerly
     for _ in range(args.probe_steps):
         if stepper is not None:
             stepper.eager_step(data, inject)
@@ -307,6 +364,13 @@ def main():
     torch.cuda.synchronize()
     kt = native.timing_collect()
     native.timing_enable(False)
+    mfma = None
+    if world == 1 and not args.no_mfma_probe and stepper is None:      # N=1 only: extra steps on one rank would hang DDP
+        try:
+            mfma = mfma_utilisation(lambda: train_step(model, wrapped, optimizer, data, synth, amp_dtype, ahead=ahead),
+                                    args.dtype)
+        except Exception as e:  # noqa: BLE001  (a diagnostic, never a reason to lose the bench line)
+            print(f"[bench] mfma probe failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
 
     tmax = torch.tensor([dt], device=device, dtype=torch.float64)
     if world > 1:
@@ -335,14 +399,16 @@ def main():
             # launch shape (profiles/r01_msda_pmc_hbm_B4_bf16.json: FETCH_SIZE doubled per the
             # gfx950 correction + WRITE_SIZE), valid for the default B=4 bf16 workload only.
             traffic = traffic_detail = None
-            pmc = os.path.join(ROOT, "profiles", "r01_msda_pmc_hbm_B4_bf16.json")
+            pmc = os.path.join(ROOT, "profiles", "r02_msda_pmc_hbm_B4_bf16.json")
+            if not os.path.exists(pmc):
+                pmc = os.path.join(ROOT, "profiles", "r01_msda_pmc_hbm_B4_bf16.json")
             if args.batch == 4 and args.dtype == "bf16" and os.path.exists(pmc):
                 with open(pmc) as f:
                     t_mb = json.load(f).get("traffic_corrected_MB", {}).get(dom)
                 if t_mb:      # same unit as `achieved`: PMC bytes of one launch / measured launch time
                     traffic = round(t_mb / 1e3 / (kernels[dom]["avg_us"] * 1e-6), 1)
                     traffic_detail = {"MB_per_launch": t_mb, "algorithmic_MB_per_launch": kernels[dom]["algorithmic_MB"],
-                                      "source": "profiles/r01_msda_pmc_hbm_B4_bf16.json (rocprofv3 --pmc, separate passes)"}
+                                      "source": f"profiles/{os.path.basename(pmc)} (rocprofv3 --pmc, separate passes)"}
             roofline = {"bound": "hbm", "kernel": dom, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(a / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_detail": traffic_detail,
                         "timing": f"HIP events around each launch, {args.probe_steps} eager steps of the same "
@@ -362,9 +428,9 @@ def main():
                           "per_gpu_batch": args.batch, "image": [IMG_H, IMG_W], "queries": 300, "prev_classes": cfg.num_prev,
                           "parallelism": f"dp{world}", "execution": mode, "extra_untimed_warmup": extra_warmup,
                           "final_loss": round(final_loss, 4)},
-               "roofline": roofline}
+               "roofline": roofline, "mfma": mfma}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.seed, cfg.num_prev)
+            out["cpu_baseline"] = cpu_baseline(args.seed, cfg.num_prev, batch=args.cpu_baseline_batch)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -68,7 +68,9 @@ __global__ __launch_bounds__(256) void proto_kernel(
     int nt = 0;
     for (int base = 0; base < M; base += 64) {
       const int k = base + lane;
-      const bool hit = k < M && labels_t[k] == (int64_t)r;
+      // a keepid outside [0, N) would be an IndexError in the reference; here the detection is ignored (never read
+      // out of bounds: a fault can take the whole node down)
+      const bool hit = k < M && labels_t[k] == (int64_t)r && (unsigned long long)keepid_t[k] < (unsigned long long)N;
       const unsigned long long m = __ballot(hit);
       if (hit) s_idx[N + nt + __popcll(m & ((1ull << lane) - 1ull))] = (int)keepid_t[k];
       nt += __popcll(m);

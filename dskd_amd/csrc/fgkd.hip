@@ -107,7 +107,9 @@ __global__ __launch_bounds__(256) void fgkd_pairs_kernel(
   const int cnt = s_count;
   for (int k = wave; k < M; k += 4) {
     float* mk = ws.m + (size_t)k * D;
-    if (k >= cnt) {  // reference would raise IndexError; flagged through status
+    if (k >= cnt || (unsigned long long)keepid_t[k] >= (unsigned long long)N) {
+      // reference would raise IndexError; flagged through status (k >= cnt) / ignored (keepid outside [0, N): never
+      // read out of bounds)
       for (int c = lane; c < D; c += 64) mk[c] = 0.f;
       continue;
     }
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(kStrip * kRowGroups) void fgkd_kl_kernel(
 // block 0: loss; blocks 1..: one wave per pair -> softmax / abs backward into grad_hs_s
 __global__ __launch_bounds__(256) void fgkd_finish_kernel(
     const float* __restrict__ hs_t, const int64_t* __restrict__ keepid_t,
-    const float* __restrict__ hs_s, int D, int M, long long nblocks, float scale, FgWs ws,
+    const float* __restrict__ hs_s, int N, int D, int M, long long nblocks, float scale, FgWs ws,
     const int* __restrict__ status, float* __restrict__ loss, float* __restrict__ grad_hs) {
   if (blockIdx.x == 0) {
     __shared__ float s_p[256];
@@ -327,6 +329,7 @@ __global__ __launch_bounds__(256) void fgkd_finish_kernel(
   float dot = 0.f;
   for (int c = lane; c < D; c += 64) dot = fmaf(mk[c], gk[c], dot);
   dot = wave_sum(dot);
+  if ((unsigned long long)keepid_t[k] >= (unsigned long long)N) return;     // as in fgkd_pairs_kernel: m_k == 0
   const float* t = hs_t + (size_t)keepid_t[k] * D;
   const int row = ws.id_pred[k];
   const float* s = hs_s + (size_t)row * D;
@@ -453,6 +456,6 @@ extern "C" int dskd_fgkd_fwd(const float* const* feat_s, const float* const* fea
   if (int rc = check_launch("dskd_fgkd_fwd/kl")) return rc;
   const float scale = loss_weight / (float)B;
   hipLaunchKernelGGL(fgkd_finish_kernel, dim3(1 + (M + 3) / 4), dim3(256), 0, st, hs_t, keepid_t, hs_s,
-                     D, M, plan.nblocks, scale, ws, status, loss, grad_hs_s);
+                     N, D, M, plan.nblocks, scale, ws, status, loss, grad_hs_s);
   return check_launch("dskd_fgkd_fwd/finish");
 }

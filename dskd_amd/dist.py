@@ -19,6 +19,34 @@ def get_dist_info():
     return 0, 1
 
 
+def ranks_share_a_device():
+    """True when more than one rank of this job drives the same GPU (the one-GPU rehearsal of the multi-process
+    path: ``DSKD_BENCH_REHEARSE``, or more local ranks than devices).  The compute queues of different PROCESSES on one
+    GPU are time-sliced by the hardware scheduler: a 0.75 ms kernel of one rank was bracketed at 120-134 ms while the
+    other rank's queue held the device, and replaying hipGraphs (hundreds of nodes per submission) stretched a step to
+    5-10 s (gpurun_out/rehearse.json, rh.out of round 1).  That is a property of sharing the card, not of the graphs or
+    of the teacher side stream; with one rank per GPU -- the only production layout -- no queue of another process
+    exists.  Graph replays are therefore switched off exactly in this situation."""
+    if os.environ.get("DSKD_BENCH_REHEARSE"):
+        return True
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return False
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", dist.get_world_size()))
+    return torch.cuda.is_available() and local_world > torch.cuda.device_count()
+
+
+def hipgraphs_allowed():
+    """hipGraph replays of training regions (dense losses, student head): single process, or one rank per GPU over
+    RCCL.  ``DSKD_FORCE_GRAPHS=1`` / ``DSKD_NO_GRAPHS=1`` override."""
+    if os.environ.get("DSKD_NO_GRAPHS"):
+        return False
+    if os.environ.get("DSKD_FORCE_GRAPHS") or os.environ.get("DSKD_FORCE_GRAPHED_LOSSES"):
+        return True
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return True
+    return dist.get_backend() == "nccl" and not ranks_share_a_device()
+
+
 def init_dist(launcher="pytorch", backend="nccl", **kwargs):
     """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torchrun)."""
     if dist.is_initialized():

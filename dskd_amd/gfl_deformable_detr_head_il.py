@@ -178,9 +178,95 @@ class GFLDeformableDETRHead_il(nn.Module):
         dev = mlvl_feats[0].device.type
         if mlvl_feats[0].is_cuda and torch.is_grad_enabled() and torch.is_autocast_enabled(dev):
             # training under autocast: all Linear parameters cast to the compute dtype in one launch
-            with lowp_params(self, torch.get_autocast_dtype(dev)):
-                return self._forward(mlvl_feats, img_metas)
+            with lowp_params(self, torch.get_autocast_dtype(dev)) as lp:
+                out = self._forward_graphed(mlvl_feats, img_metas, lp)
+                return out if out is not None else self._forward(mlvl_feats, img_metas)
         return self._forward(mlvl_feats, img_metas)
+
+    # The student's transformer + branches (forward AND backward) as two hipGraph replays once the batch signature has
+    # repeated: ~1 000 launches and their Python / autograd bookkeeping per step become two.  Possible because nothing in
+    # the region depends on data-dependent sizes, every parameter is read from storage that stays put (the step's
+    # low-precision copies live in persistent buffers, ``lowp_params``), and the dropout kernels take the per-step part
+    # of their key from a device word (``native.advance_dropout_epoch``).  DSKD_EAGER_HEAD=1 disables.
+    graph_head = not os.environ.get("DSKD_EAGER_HEAD")
+
+    def _forward_graphed(self, mlvl_feats, img_metas, lp):
+        from .dist import hipgraphs_allowed
+        if not (self.graph_head and self.training and hipgraphs_allowed() and not torch.cuda.is_current_stream_capturing()
+                and all(f.requires_grad for f in mlvl_feats)):
+            return None
+        H, W = img_metas[0]["batch_input_shape"]
+        if not all(tuple(m["img_shape"][:2]) == (H, W) for m in img_metas):
+            return None                                   # padded batches: masks depend on the data, stay eager
+        dev = mlvl_feats[0].device
+        dtype = torch.get_autocast_dtype("cuda")
+        feats = [f.contiguous() for f in mlvl_feats]
+        extra = self.__dict__.get("_graph_extra")
+        if extra is None:
+            covered = {id(p) for p in lp.params}
+            extra = [(n, p) for n, p in self.named_parameters() if p.requires_grad and id(p) not in covered]
+            self.__dict__["_graph_extra"] = extra
+        statics = list(lp.outs) + [p for _, p in extra]      # + LayerNorm weights, level / query embeddings ...
+        drops = tuple(m.p for m in self.modules() if isinstance(m, nn.Dropout))
+        sig = (tuple((tuple(f.shape), f.dtype) for f in feats), (H, W), dtype, drops, len(statics))
+        graphs = self.__dict__.setdefault("_head_graphs", {})
+        g = graphs.get(sig)
+        if g is not None and g is not False and not g.matches(feats, statics):
+            g = graphs[sig] = None                        # parameters were re-allocated (.to(), load): capture again
+        if g is None:
+            seen = self.__dict__.setdefault("_head_seen", {})
+            seen[sig] = seen.get(sig, 0) + 1
+            if seen[sig] <= 2:                            # a couple of eager steps first (allocator, caches, workspaces)
+                return None
+            metas = [dict(img_shape=tuple(m["img_shape"]), batch_input_shape=(H, W)) for m in img_metas]
+
+            from torch.nn.utils.stateless import _reparametrize_module
+            nf, nlp = len(feats), len(lp.outs)
+
+            def fn(*a):          # a pure function of (features, low-precision parameters, the other parameters)
+                prev = lp.install(a[nf:nf + nlp])
+                try:
+                    with _reparametrize_module(self, {n: t for (n, _), t in zip(extra, a[nf + nlp:])}, tie_weights=False,
+                                               strict=False):
+                        cls, box, info_all, hs = self._forward(list(a[:nf]), metas)
+                finally:
+                    lp.install(prev)
+                return cls, box, info_all[0], hs
+            try:
+                # Is the region graph-safe at this shape?  Checked on a throw-away capture with dropout off (with
+                # dropout a replay legitimately differs from the last one): three replays must agree with each other
+                # (a memset node replays with a garbage fill value from the second replay on) and with eager.
+                drop_mods = [(m, m.p) for m in self.modules() if isinstance(m, nn.Dropout) and m.p > 0]
+                mha_mods = [(m, m.dropout) for m in self.modules() if isinstance(m, nn.MultiheadAttention) and m.dropout > 0]
+                try:
+                    for m, _ in drop_mods:
+                        m.p = 0.0
+                    for m, _ in mha_mods:
+                        m.dropout = 0.0
+                    pn = {id(p): n for n, p in self.named_parameters()}
+                    names = [f"feat{i}" for i in range(nf)] + [pn.get(id(p), "?") for p in lp.params] + [n for n, _ in extra]
+                    probe = GraphedFunction(fn, feats, statics, verify=True, autocast_dtype=dtype, against_eager=True,
+                                            arg_names=names)
+                    del probe
+                finally:
+                    for m, p0 in drop_mods:
+                        m.p = p0
+                    for m, p0 in mha_mods:
+                        m.dropout = p0
+                g = GraphedFunction(fn, feats, statics, verify=False, autocast_dtype=dtype) if (drop_mods or mha_mods) else \
+                    GraphedFunction(fn, feats, statics, verify=True, autocast_dtype=dtype, against_eager=True)
+            except Exception as e:  # noqa: BLE001  (an accelerator, not a requirement)
+                import warnings
+                warnings.warn(f"student-head hipGraph capture failed ({type(e).__name__}: {e}); staying eager")
+                torch.cuda.synchronize(dev)
+                g = False
+            graphs[sig] = g
+        if g is False:
+            return None
+        native.advance_dropout_epoch(dev)
+        cls, box, memory, hs = g(*feats, *statics)
+        shapes = device_const([tuple(f.shape[-2:]) for f in feats], torch.long, dev)
+        return cls, box, (memory, shapes), hs
 
     def _forward(self, mlvl_feats, img_metas):
         batch_size = mlvl_feats[0].size(0)
@@ -299,7 +385,8 @@ class GFLDeformableDETRHead_il(nn.Module):
         return loss_cls, loss_bbox, loss_iou, loss_dfl
 
     def __deepcopy__(self, memo):
-        return deepcopy_without(self, memo, ("_dense_graphs", "_dense_seen"))
+        return deepcopy_without(self, memo, ("_dense_graphs", "_dense_seen", "_head_graphs", "_head_seen", "_graph_extra",
+                                             "_lp_static", "_lowp_mods", "_lowp_mhas"))
 
     # replay the dense detection losses as hipGraphs on the GPU (utils.GraphedFunction); DSKD_EAGER_LOSSES=1 disables
     graph_dense_losses = not os.environ.get("DSKD_EAGER_LOSSES")
@@ -377,12 +464,9 @@ class GFLDeformableDETRHead_il(nn.Module):
         """``loss_layers_dense``, as a hipGraph replay (forward and backward) once the shapes have
         repeated: 378 tiny launches become ~6.  Eager when gradients are off, on the CPU, inside
         another capture, or if capture fails."""
-        # Single-process only: with two ranks sharing one GPU over gloo (the only multi-process set-up that
-        # can be rehearsed here) the replays stalled for seconds per step; until that is understood on a real
-        # multi-GPU node the data-parallel path keeps the eager losses.
+        # Not when several ranks share one GPU (the one-GPU rehearsal of the multi-process path): dist.ranks_share_a_device
         if not (self.graph_dense_losses and cls_scores.is_cuda and torch.is_grad_enabled() and cls_scores.requires_grad
-                and (not _dist_on() or os.environ.get("DSKD_FORCE_GRAPHED_LOSSES"))
-                and not torch.cuda.is_current_stream_capturing()):
+                and _graphs_allowed() and not torch.cuda.is_current_stream_capturing()):
             return self.loss_layers_dense(cls_scores, bbox_cxcywh, bbox_lrtb, labels, bbox_targets, pos, factors, avg_pos)
         if not torch.is_tensor(avg_pos):
             avg_pos = device_const(float(avg_pos), torch.float32, cls_scores.device)
@@ -586,6 +670,11 @@ class GFLDeformableDETRHead_il(nn.Module):
         return self.get_bboxes(*outs, img_metas, rescale=rescale)
 
     simple_test = simple_test_bboxes
+
+
+def _graphs_allowed():
+    from .dist import hipgraphs_allowed
+    return hipgraphs_allowed()
 
 
 def _dist_on():

@@ -57,6 +57,11 @@ class GraphedDistillStep:
         self._seen = {}
         self.last_logs = None
         self._avg_pos = None
+        # this class captures the whole step itself: the head's own forward / backward graphs (utils.GraphedFunction)
+        # would be replayed inside its eager warm-up steps and then sit inside its captures
+        module = model.module if hasattr(model, "module") else model
+        if hasattr(module, "bbox_head"):
+            module.bbox_head.graph_head = False
 
     # ------------------------------------------------------------------ pieces of a step
     def _autocast(self):

@@ -106,6 +106,17 @@ def mse_loss(pred, target):
 def knowledge_distillation_kl_div_loss(pred, soft_label, T, detach_target=True):
     """kd_loss.py:10-43 (softmax over dim=1)."""
     assert pred.size() == soft_label.size()
+    if pred.is_cuda and pred.dtype == torch.float32:
+        # The DSKD feature terms feed this loss with almost identical, almost uniform distributions (masked maps:
+        # KL = O(d^2) from O(log H) terms), where fp32 log-softmax cancellation IS the result: the reference's own
+        # CPU evaluation is ~0.5 % off the exact value and an fp32 GPU evaluation of the same formula 70 % (different
+        # rounding in softmax / log).  fp64 is cheap on MI355X and these branches are not on the hot path
+        # (decode_v1 has its own kernel), so the GPU evaluates the formula in double and rounds once.
+        p64, s64 = pred.double(), soft_label.double()
+        t64 = F.softmax(s64 / T, dim=1)
+        if detach_target:
+            t64 = t64.detach()
+        return (F.kl_div(F.log_softmax(p64 / T, dim=1), t64, reduction="none").mean(1) * (T * T)).float()
     target = F.softmax(soft_label / T, dim=1)
     if detach_target:
         target = target.detach()

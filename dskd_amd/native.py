@@ -26,6 +26,7 @@ _SIGNATURES = {
     "dskd_abi_version": (C.c_int, []),
     "dskd_last_error": (C.c_char_p, []),
     "dskd_device_count": (C.c_int, []),
+    "dskd_zero_fill": (C.c_int, [_vp, _i64, _vp]),
     "dskd_msda_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [C.c_int] * 8 + [_vp]),
     "dskd_msda_fwd_fused": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [C.c_int] * 8 + [_vp]),
     "dskd_msda_bwd": (C.c_int, [_vp] * 9 + [C.c_int] * 8 + [_vp]),
@@ -77,6 +78,20 @@ def load() -> C.CDLL:
             raise NativeError("libdskd_hip.so ABI version mismatch")
         _lib = lib
     return _lib
+
+
+def zeros(shape, dtype, device) -> torch.Tensor:
+    """``torch.zeros`` for the accumulators the kernels add into, filled by a KERNEL: ``torch.zeros`` issues
+    hipMemsetAsync, and a memset node captured into a hipGraph replays with a garbage fill value on this ROCm runtime
+    (csrc/common.h) -- a replayed backward would then accumulate into garbage."""
+    t = torch.empty(shape, dtype=dtype, device=device)
+    nbytes = t.numel() * t.element_size()
+    if nbytes == 0:
+        return t
+    if nbytes % 16 or t.data_ptr() % 16 or not t.is_cuda:
+        return t.zero_()
+    _check(load().dskd_zero_fill(t.data_ptr(), nbytes, _stream(t)), "dskd_zero_fill")
+    return t
 
 
 def _check(rc: int, what: str) -> None:
@@ -221,7 +236,7 @@ def msda_backward_raw(value, shapes, loc, attn, grad_out):
                                          ws.data_ptr(), ws.numel(), _stream(value))
         _check(rc, "dskd_msda_bwd_ws")
         return gv, gl, ga
-    gv = torch.zeros((B, Nv, heads, ch), dtype=torch.float32, device=value.device)
+    gv = zeros((B, Nv, heads, ch), torch.float32, value.device)
     with _timed("msda_bwd_enc" if Nq == Nv else "msda_bwd_dec"):
         rc = load().dskd_msda_bwd(value.data_ptr(), ss, ls, loc.data_ptr(), attn.data_ptr(), grad_out.data_ptr(),
                                   gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), B, Nv, Nq, heads, ch, L, P, dt,
@@ -235,9 +250,11 @@ _msda_ws_cache = {}
 
 def _msda_bwd_workspace(device, B, Nv, Nq, heads, L, P) -> torch.Tensor:
     """Workspace of ``dskd_msda_bwd_ws`` (stray-sample list; header zeroed once, the library leaves it zeroed),
-    one per (device, stream): launches on one stream are ordered, so consecutive calls can share it."""
+    one per device: a training step runs its backward launches one after the other (eagerly on the main stream or as
+    a hipGraph replay on it), never two encoder backwards at once; a capture stream finds the buffer the eager
+    warm-up steps made."""
     need = int(load().dskd_msda_bwd_workspace(B, Nv, Nq, heads, L, P))
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    key = torch.device(device)
     ws = _msda_ws_cache.get(key)
     if ws is None or ws.numel() < need:
         if torch.cuda.is_current_stream_capturing():
@@ -412,13 +429,13 @@ class _AddLNFunction(torch.autograd.Function):
         z, stats, gamma_f = ctx.saved_tensors
         dt, rows, D, p, seed, offset, pos_shape, gdtype, want_q = ctx.meta
         if dy is None:
-            dy = torch.zeros_like(z)
+            dy = zeros(z.shape, z.dtype, z.device)
         dy = dy.contiguous().to(z.dtype)
         dq = dq.contiguous().to(z.dtype) if (want_q and dq is not None) else None
         dres = torch.empty_like(z)
         dh = torch.empty_like(z) if p > 0 else None
         copies = _colsum_copies(rows)
-        dgb = torch.zeros((2, copies, D), dtype=torch.float32, device=z.device)
+        dgb = zeros((2, copies, D), torch.float32, z.device)
         rc = load().dskd_add_ln_bwd(dy.data_ptr(), None if dq is None else dq.data_ptr(), z.data_ptr(), stats.data_ptr(),
                                     gamma_f.data_ptr(), dres.data_ptr(), None if dh is None else dh.data_ptr(),
                                     dgb[0].data_ptr(), dgb[1].data_ptr(), copies, rows, D, p, seed, offset,
@@ -474,7 +491,7 @@ def relu_dropout_bwd(g: torch.Tensor, y_dropped: torch.Tensor, p: float, want_co
     rows = g.numel() // Cc
     out = torch.empty_like(g)
     copies = _colsum_copies(rows)
-    colsum = torch.zeros((copies, Cc), dtype=torch.float32, device=g.device) if want_colsum else None
+    colsum = zeros((copies, Cc), torch.float32, g.device) if want_colsum else None
     rc = load().dskd_relu_dropout_bwd(g.data_ptr(), y_dropped.data_ptr(), out.data_ptr(),
                                       None if colsum is None else colsum.data_ptr(), copies, rows, Cc, p, DTYPE_BF16,
                                       _stream(g))
@@ -499,7 +516,7 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
     Cc = x.shape[-1]
     rows = x.numel() // Cc
     copies = _colsum_copies(rows)
-    out = torch.zeros((copies, Cc), dtype=torch.float32, device=x.device)
+    out = zeros((copies, Cc), torch.float32, x.device)
     rc = load().dskd_colsum(x.data_ptr(), out.data_ptr(), copies, rows, Cc, DTYPE_BF16, _stream(x))
     _check(rc, "dskd_colsum")
     return out.sum(0) if copies > 1 else out[0]
@@ -572,7 +589,7 @@ def lsap_batched(cost_flat: torch.Tensor, nr: Sequence[int], nc: Sequence[int], 
         acc += min(int(r), int(c))
     row = torch.empty(max(acc, 1), dtype=torch.int64, device=cost_flat.device)
     col = torch.empty(max(acc, 1), dtype=torch.int64, device=cost_flat.device)
-    status = torch.zeros(max(nprob, 1), dtype=torch.int32, device=cost_flat.device)
+    status = zeros(max(nprob, 1) * 4, torch.int32, cost_flat.device)[:max(nprob, 1)]
     rc = load().dskd_lsap_batched(cost_flat.data_ptr(), _host_i32(nr), _host_i32(nc), _host_i64(offsets), nprob,
                                   row.data_ptr(), col.data_ptr(), _host_i64(outs), status.data_ptr(),
                                   _stream(cost_flat))
@@ -689,7 +706,7 @@ def fgkd_loss(feats_s: List[torch.Tensor], feats_t: List[torch.Tensor], boxes: L
     x = hs_s.detach().contiguous().float()
     loss = torch.empty(1, dtype=torch.float32, device=x.device)
     grad = torch.empty_like(x)
-    status = torch.zeros(1, dtype=torch.int32, device=x.device)
+    status = zeros(4, torch.int32, x.device)[:1]
     ps = (C.c_void_p * levels)(*[t.data_ptr() for t in fs])
     pt = (C.c_void_p * levels)(*[t.data_ptr() for t in ft])
     ht_, kt_ = hs_t.detach().contiguous().float(), keepid_t.contiguous().long()

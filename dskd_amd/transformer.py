@@ -48,6 +48,33 @@ def _token_chunk(T, out_elems=65536, lo=256, hi=4096):
     return _CHUNK_CACHE[key]
 
 
+_ONES = {}
+
+
+def rowsum(t2d):
+    """Column sums of a [rows, C] CUDA tensor as a GEMM with a row of ones (result in t2d's dtype, f32 accumulation).
+    ATen's ``sum(0)`` splits a tall reduction over several workgroups and resets their semaphore with
+    hipMemsetAsync; captured into a hipGraph that memset replays with a garbage value on this ROCm runtime
+    (csrc/common.h), so bias gradients inside a replayed region must not come from it."""
+    key = (t2d.shape[0], t2d.dtype, t2d.device)
+    ones = _ONES.get(key)
+    if ones is None:
+        if len(_ONES) > 64:
+            _ONES.clear()
+        ones = _ONES[key] = torch.ones((1, t2d.shape[0]), dtype=t2d.dtype, device=t2d.device)
+    return torch.mm(ones, t2d).view(-1)
+
+
+def bias_grad(g2):
+    """d(bias) of a Linear from the [rows, C] output gradient: the library's column-sum kernel where it applies, else
+    the ones-GEMM; ATen's reduction only on the CPU."""
+    if not g2.is_cuda:
+        return g2.sum(0, dtype=torch.float32).to(g2.dtype)
+    if g2.dtype == torch.bfloat16 and g2.shape[-1] in native.COLSUM_WIDTHS and g2.is_contiguous() and g2.shape[0] >= 4096:
+        return native.colsum(g2).to(g2.dtype)
+    return rowsum(g2.contiguous())
+
+
 class _TallLinearFn(torch.autograd.Function):
     """y = x W^T + b for a very tall x (tens of thousands of tokens, 256..1024 features).
     Forward and dX are ordinary GEMMs.  dW = dY^T X has a tiny output (<= 1024 x 256) and a
@@ -81,14 +108,14 @@ class _TallLinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = (g2 @ weight).view(x.shape)
         if ctx.needs_input_grad[1]:
-            nb = x2.shape[0] // ctx.chunk
-            part = torch.bmm(g2.view(nb, ctx.chunk, -1).transpose(1, 2), x2.view(nb, ctx.chunk, -1))
-            gw = part.sum(0, dtype=torch.float32).to(weight.dtype)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            if g2.is_cuda and g2.dtype == torch.bfloat16 and g2.shape[-1] in native.COLSUM_WIDTHS and g2.is_contiguous():
-                gb = native.colsum(g2).to(g.dtype)
+            if ctx.chunk is None:
+                gw = g2.t() @ x2
             else:
-                gb = g2.sum(0, dtype=torch.float32).to(g.dtype)
+                nb = x2.shape[0] // ctx.chunk
+                part = torch.bmm(g2.view(nb, ctx.chunk, -1).transpose(1, 2), x2.view(nb, ctx.chunk, -1))
+                gw = part.sum(0, dtype=torch.float32).to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = bias_grad(g2)
         return gx, gw, gb, None, None
 
 
@@ -147,12 +174,14 @@ class _CastParams(torch.autograd.Function):
     GPU time and ~10 us of host time."""
 
     @staticmethod
-    def forward(ctx, dtype, *params):
+    def forward(ctx, dtype, static, *params):
+        """``static``: persistent ``dtype`` buffers to cast into (their storage is then the same on every step, which
+        is what lets a captured hipGraph read the step's parameters), or None for fresh tensors."""
         ctx.set_materialize_grads(False)
         ctx.pdtypes = [p.dtype for p in params]
-        outs = [torch.empty_like(p, dtype=dtype) for p in params]
+        outs = [torch.empty_like(p, dtype=dtype) for p in params] if static is None else static
         torch._foreach_copy_(outs, [p.detach() for p in params])
-        return tuple(outs)
+        return tuple(outs) if static is None else tuple(o.detach() for o in outs)
 
     @staticmethod
     def backward(ctx, *grads):
@@ -163,7 +192,24 @@ class _CastParams(torch.autograd.Function):
         out = [None] * len(grads)
         for j, i in enumerate(idx):
             out[i] = ups[j]
-        return (None, *out)
+        return (None, None, *out)
+
+
+class _AddLevelEmbed(torch.autograd.Function):
+    """``pos + level_embed`` for one level ([B, HW, C] + [C]) whose d(level_embed) is a ones-GEMM instead of ATen's
+    multi-workgroup reduction over B * HW rows (see rowsum)."""
+
+    @staticmethod
+    def forward(ctx, pos, emb):
+        return pos + emb.view(1, 1, -1)
+
+    @staticmethod
+    def backward(ctx, g):
+        ge = None
+        if ctx.needs_input_grad[1]:
+            g2 = g.reshape(-1, g.shape[-1])
+            ge = rowsum(g2.contiguous()) if g2.is_cuda else g2.sum(0)
+        return (g if ctx.needs_input_grad[0] else None), ge
 
 
 class lowp_params:
@@ -193,8 +239,15 @@ class lowp_params:
                 params.append(m.bias)
         for m in self.live_mha:
             params += [m.attn.in_proj_weight, m.attn.in_proj_bias, m.attn.out_proj.weight, m.attn.out_proj.bias]
+        self.params, self.outs = params, []
         if params:
-            outs = iter(_CastParams.apply(self.dtype, *params))
+            key = tuple((p.data_ptr(), tuple(p.shape)) for p in params) + (self.dtype,)
+            static = self.root.__dict__.get("_lp_static")
+            if static is None or static[0] != key:
+                static = (key, [torch.empty_like(p, dtype=self.dtype) for p in params])
+                self.root.__dict__["_lp_static"] = static
+            self.outs = list(_CastParams.apply(self.dtype, static[1], *params))
+            outs = iter(self.outs)
             for m in self.live:
                 m.__dict__["_live_lp"] = (next(outs), next(outs) if m.bias is not None else None)
             for m in self.live_mha:
@@ -205,6 +258,17 @@ class lowp_params:
         for m in self.live + self.live_mha:
             m.__dict__.pop("_live_lp", None)
         return False
+
+    def install(self, tensors):
+        """Make the modules read ``tensors`` (same order and shapes as ``self.outs``) as their low-precision
+        parameters; returns the previous assignment (a list to pass back here)."""
+        prev = [m.__dict__.get("_live_lp") for m in self.live + self.live_mha]
+        it = iter(tensors)
+        for m in self.live:
+            m.__dict__["_live_lp"] = (next(it), next(it) if m.bias is not None else None)
+        for m in self.live_mha:
+            m.__dict__["_live_lp"] = (next(it), next(it), next(it), next(it))
+        return [t for pr in prev for t in (pr if pr is not None else ()) if t is not None]
 
 
 class Linear(nn.Linear):
@@ -246,20 +310,23 @@ def tall_linear(x, weight, bias, relu=False):
     bias+ReLU GEMM epilogue -- for very tall inputs."""
     dev = x.device.type
     tokens = x.numel() // max(x.shape[-1], 1)
-    if tokens >= 16384 and weight.requires_grad and torch.is_grad_enabled() and x.is_contiguous():
-        chunk = _token_chunk(tokens, weight.numel())
-        if chunk is not None:
-            lead = x.shape[:-1]
-            x2 = x.reshape(tokens, x.shape[-1])
-            if torch.is_autocast_enabled(dev):       # what autocast would do for F.linear
-                dtype = torch.get_autocast_dtype(dev)
-                x2, weight = x2.to(dtype), weight.to(dtype)
-                bias = None if bias is None else bias.to(dtype)
-                with torch.autocast(dev, enabled=False):
-                    y = _TallLinearFn.apply(x2, weight, bias, chunk, relu)
-            else:
+    if x.is_cuda and weight.requires_grad and torch.is_grad_enabled() and tokens > 0:
+        # own backward on the GPU for every size: split-K dW for very tall inputs, and bias gradients that never go
+        # through ATen's multi-workgroup reduction (see rowsum)
+        chunk = _token_chunk(tokens, weight.numel()) if (tokens >= 16384 and x.is_contiguous()) else None
+        lead = x.shape[:-1]
+        x2 = x.reshape(tokens, x.shape[-1])
+        if torch.is_autocast_enabled(dev):       # what autocast would do for F.linear
+            dtype = torch.get_autocast_dtype(dev)
+            x2, weight = x2.to(dtype), weight.to(dtype)
+            bias = None if bias is None else bias.to(dtype)
+            with torch.autocast(dev, enabled=False):
                 y = _TallLinearFn.apply(x2, weight, bias, chunk, relu)
-            return y.view(*lead, y.shape[-1])
+        else:
+            if x2.dtype != weight.dtype:
+                x2 = x2.to(weight.dtype)
+            y = _TallLinearFn.apply(x2, weight, bias, chunk, relu)
+        return y.view(*lead, y.shape[-1])
     y = F.linear(x, weight, bias)
     return torch.relu_(y) if relu else y
 
@@ -466,15 +533,15 @@ class MultiheadAttention(nn.Module):
         L, B, _ = query.shape
         S = key.shape[0]
         if query is key:
-            q, k = F.linear(query, w[:2 * E], b[:2 * E]).split(E, dim=-1)
+            q, k = tall_linear(query, w[:2 * E], b[:2 * E]).split(E, dim=-1)
         else:
-            q, k = F.linear(query, w[:E], b[:E]), F.linear(key, w[E:2 * E], b[E:2 * E])
-        v = F.linear(value, w[2 * E:], b[2 * E:])
+            q, k = tall_linear(query, w[:E], b[:E]), tall_linear(key, w[E:2 * E], b[E:2 * E])
+        v = tall_linear(value, w[2 * E:], b[2 * E:])
         q = q.reshape(L, B, H, E // H).permute(1, 2, 0, 3)
         k = k.reshape(S, B, H, E // H).permute(1, 2, 0, 3)
         v = v.reshape(S, B, H, E // H).permute(1, 2, 0, 3)
         out = F.scaled_dot_product_attention(q, k, v, dropout_p=self.attn.dropout if self.training else 0.0)
-        return F.linear(out.permute(2, 0, 1, 3).reshape(L, B, E), wo, bo)
+        return tall_linear(out.permute(2, 0, 1, 3).reshape(L, B, E), wo, bo)
 
     def tail_dropout_p(self):
         """p of ``dropout_layer`` when the tail can be fused (no extra ``proj_drop``), else None."""
@@ -906,7 +973,7 @@ class DeformableDetrTransformer(nn.Module):
             feat_flatten.append(feat.flatten(2).transpose(1, 2))
             if not all_valid:
                 mask_flatten.append(mask.flatten(1))
-            lvl_pos_embed_flatten.append(pos_embed.flatten(2).transpose(1, 2) + self.level_embeds[lvl].view(1, 1, -1))
+            lvl_pos_embed_flatten.append(_AddLevelEmbed.apply(pos_embed.flatten(2).transpose(1, 2), self.level_embeds[lvl]))
         feat_flatten = torch.cat(feat_flatten, 1)
         mask_flatten = torch.cat(mask_flatten, 1) if not all_valid else None
         lvl_pos_embed_flatten = torch.cat(lvl_pos_embed_flatten, 1)

@@ -69,6 +69,10 @@ extern "C" {
 int dskd_abi_version(void);
 /* Last error message of the calling thread ("" when none). */
 const char* dskd_last_error(void);
+/* Zero `bytes` bytes at `p` (device, 16-byte aligned, bytes % 16 == 0) with a KERNEL on `stream`.  For the buffers the
+ * entry points below want zeroed by the caller: hipMemsetAsync (what torch.zeros issues) captured into a hipGraph
+ * replays with a garbage fill value on this ROCm runtime (csrc/common.h). */
+int dskd_zero_fill(void* p, int64_t bytes, void* stream);
 /* Number of HIP devices visible to the library (0 when there is no GPU). */
 int dskd_device_count(void);
 

@@ -3,7 +3,7 @@
 set -uo pipefail
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests -q -m gpu -x -rxXs > gpurun_out/r02_gpu_tests.log 2>&1; rc=$?
+timeout -k 10 900 python -m pytest tests -q -m gpu -rxXs > gpurun_out/r02_gpu_tests.log 2>&1; rc=$?
 tail -25 gpurun_out/r02_gpu_tests.log
 [ $rc -eq 0 ] || exit $rc
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r02_smoke.log 2>&1; rc=$?

@@ -873,3 +873,19 @@ def test_fgkd_full_size_properties():
     out2 = native.fgkd_loss(fsd, [f.to(DEV) for f in ft], [b.to(DEV) for b in boxes], img_hw, hs_t.to(DEV),
                             keep.to(DEV), xd, labels.to(DEV), prev.to(DEV), 2.0, 1.0)
     assert float(out2.detach()) > 0 and np.isfinite(float(out2.detach()))
+
+
+def test_dskd_losses_ignore_out_of_range_keepid():
+    """A teacher keepid outside [0, B*Q) is an IndexError in the reference; the kernels must never read out of bounds
+    (a GPU fault can take the node down): such a detection contributes nothing, every other one is unchanged."""
+    hs_s, hs_t, labels, keep, lab_t, prev = _loss_inputs(2, 70, 131)
+    L = 70
+    N = hs_s.shape[0]
+    ok = native.proto_corr_loss(hs_s.to(DEV), labels.to(DEV), prev.to(DEV), hs_t.to(DEV), keep.to(DEV), lab_t.to(DEV), L, 1.0)
+    # the same detections plus two whose query index is far outside the batch, with labels that already have a prototype
+    bad_keep = torch.cat([keep, torch.tensor([N + 225, 10 ** 9])])
+    bad_lab = torch.cat([lab_t, lab_t[:2]])
+    bad = native.proto_corr_loss(hs_s.to(DEV), labels.to(DEV), prev.to(DEV), hs_t.to(DEV), bad_keep.to(DEV), bad_lab.to(DEV),
+                                 L, 1.0)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(bad, ok, rtol=1e-6, atol=0)
