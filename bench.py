@@ -42,7 +42,8 @@ from dskd_amd.graph_step import GraphedDistillStep  # noqa: E402
 from dskd_amd.runner import build_optimizer  # noqa: E402
 
 CONFIGS = {"r50": os.path.join(ROOT, "configs", "dskd_gfl_deformable_detr_r50_70_10.py"),           # BASELINE configs[1]
-           "swin_t": os.path.join(ROOT, "configs", "dskd_gfl_deformable_detr_swin_t_70_10.py")}      # BASELINE configs[3]
+           "swin_t": os.path.join(ROOT, "configs", "dskd_gfl_deformable_detr_swin_t_70_10.py"),      # BASELINE configs[3]
+           "gfl_r50": os.path.join(ROOT, "configs", "dskd_gfl_r50_fpn_40_40.py")}                   # BASELINE configs[4]
 CONFIG = CONFIGS["r50"]
 IMG_H, IMG_W = 800, 1333
 LEVELS = [(100, 167), (50, 84), (25, 42), (13, 21)]
@@ -231,7 +232,8 @@ def main():
     ap.add_argument("--probe-steps", type=int, default=3, help="eager steps after the timed region that bracket "
                     "every MSDeformAttn launch with HIP events (roofline)")
     ap.add_argument("--backbone", default="r50", choices=sorted(CONFIGS), help="r50 = BASELINE configs[1] (the headline "
-                    "workload); swin_t = configs[3] (SURVEY.md 8f row 2), reported in DESIGN.md only")
+                    "workload); swin_t = configs[3] (SURVEY.md 8f row 2) and gfl_r50 = configs[4] (GFL CNN head with the "
+                    "DSKD feature-map term only), reported in DESIGN.md only")
     ap.add_argument("--seed", type=int, default=111)
     args = ap.parse_args()
 
@@ -309,7 +311,7 @@ def main():
             from dskd_amd.dist import wrap_ddp
             wrapped = wrap_ddp(model, device_ids=[local_rank])
         optimizer = build_optimizer(model, cfg.optimizer[0])
-        ahead = None if args.no_teacher_ahead else model.teacher_ahead()
+        ahead = None if (args.no_teacher_ahead or args.backbone == "gfl_r50") else model.teacher_ahead()
         if ahead is not None:
             ahead.use_graphs = not args.no_teacher_graph
             mode += "+teacher_ahead" + ("(hipgraph)" if ahead.use_graphs else "")
@@ -353,7 +355,8 @@ def main():
     # launch can be bracketed by HIP events on the launch stream (events cannot be recorded
     # inside a replayed hipGraph on ROCm).  Not part of the timed region.
     native.timing_enable(True)
-    model.bbox_head.graph_head = False          # launches inside a replayed hipGraph cannot be bracketed by events
+    if hasattr(model.bbox_head, "graph_head"):
+        model.bbox_head.graph_head = False      # launches inside a replayed hipGraph cannot be bracketed by events
     if ahead is not None:
         ahead.use_graphs = False                # the teacher's 12 fused MSDA forwards too: probe them eagerly
     for _ in range(args.probe_steps):
@@ -377,7 +380,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     final_loss = float(loss.detach().float().item())
-    if model.bbox_head.last_lsap_status is not None:
+    if getattr(model.bbox_head, "last_lsap_status", None) is not None:
         native.raise_for_lsap_status(model.bbox_head.last_lsap_status)
 
     if rank == 0:
@@ -414,17 +417,20 @@ def main():
                         "timing": f"HIP events around each launch, {args.probe_steps} eager steps of the same "
                                   "workload right after the timed region", "kernels": kernels}
         ips = args.batch * world * args.steps / dt
-        out = {"metric": "images/sec (teacher+student distill step), DefDETR-%s COCO 800x1333" %
-                         ("R50" if args.backbone == "r50" else "SwinT"), "value": round(ips, 3),
+        out = {"metric": "images/sec (teacher+student distill step), %s COCO 800x1333" %
+                         {"r50": "DefDETR-R50", "swin_t": "DefDETR-SwinT", "gfl_r50": "GFL-R50"}[args.backbone],
+               "value": round(ips, 3),
                "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype,
                "data": "synthetic (N(0,1) images 800x1333, 7 GT + 10 injected teacher detections per image, "
                        "random-init weights, teacher = perturbed copy)",
-               "config": {"workload": ("Deformable-DETR R50 70+10 incremental DSKD distillation step "
-                                       "(BASELINE.json configs[1])" if args.backbone == "r50" else
-                                       "Deformable-DETR Swin-T 70+10 incremental DSKD distillation step "
-                                       "(BASELINE.json configs[3])"), "global_batch": args.batch * world,
+               "config": {"workload": {"r50": "Deformable-DETR R50 70+10 incremental DSKD distillation step "
+                                              "(BASELINE.json configs[1])",
+                                       "swin_t": "Deformable-DETR Swin-T 70+10 incremental DSKD distillation step "
+                                                 "(BASELINE.json configs[3])",
+                                       "gfl_r50": "GFL R50-FPN 40+40 incremental step with the DSKD feature-map term "
+                                                  "(BASELINE.json configs[4])"}[args.backbone], "global_batch": args.batch * world,
                           "per_gpu_batch": args.batch, "image": [IMG_H, IMG_W], "queries": 300, "prev_classes": cfg.num_prev,
                           "parallelism": f"dp{world}", "execution": mode, "extra_untimed_warmup": extra_warmup,
                           "final_loss": round(final_loss, 4)},

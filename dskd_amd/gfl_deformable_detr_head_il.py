@@ -43,7 +43,8 @@ def multi_apply(func, *args, **kwargs):
 
 
 def filter_scores_and_topk(scores, score_thr, topk, results=None):
-    """/root/reference/mmdet/core/utils/misc.py:119-165 (results=None form)."""
+    """/root/reference/mmdet/core/utils/misc.py:119-165: ``results`` (a dict of per-row tensors, a tensor or None) is
+    gathered with the kept row indices."""
     valid_mask = scores > score_thr
     scores = scores[valid_mask]
     valid_idxs = torch.nonzero(valid_mask)
@@ -52,7 +53,17 @@ def filter_scores_and_topk(scores, score_thr, topk, results=None):
     scores = scores[:num_topk]
     topk_idxs = valid_idxs[idxs[:num_topk]]
     keep_idxs, labels = topk_idxs.unbind(dim=1)
-    return scores, labels, keep_idxs, None
+    filtered = None
+    if results is not None:
+        if isinstance(results, dict):
+            filtered = {k: v[keep_idxs] for k, v in results.items()}
+        elif isinstance(results, list):
+            filtered = [r[keep_idxs] for r in results]
+        elif torch.is_tensor(results):
+            filtered = results[keep_idxs]
+        else:
+            raise NotImplementedError(f"Only supports dict or list or Tensor, but get {type(results)}.")
+    return scores, labels, keep_idxs, filtered
 
 
 class Integral_average(nn.Module):

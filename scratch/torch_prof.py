@@ -7,6 +7,7 @@ dev=torch.device('cuda:0')
 cfg, model = bench.build_models(dev, 111, None)
 model = model.to(memory_format=torch.channels_last); model.teacher_model.to(memory_format=torch.channels_last)
 model.lazy_log=True
+model.bbox_head.graph_head = False      # op-level attribution: replayed graphs hide the ops
 opt = build_optimizer(model, cfg.optimizer[0])
 data, synth = bench.make_batch(4, cfg.num_prev, 111, dev)
 data["img"]=data["img"].contiguous(memory_format=torch.channels_last)

@@ -22,6 +22,7 @@ takes part in the arithmetic.  What runs is the reference's code:
     python tests/golden/gen_golden.py --bbox2result   # bbox2result_cases.npz
     python tests/golden/gen_golden.py --ragged        # loss_ragged_*.npz
     python tests/golden/gen_golden.py --two-rank      # loss_two_rank_r{0,1}.npz
+    python tests/golden/gen_golden.py --gfl           # gfl_cases.npz (stock GFL head: anchors, ATSS, targets, losses)
 """
 import importlib.util
 import os
@@ -783,7 +784,113 @@ def main_datasplit():
     print("data_split_cases.json:", len(cases), "cases")
 
 
+def load_reference_gfl():
+    """The reference's stock GFL pieces (BASELINE configs[4]): AnchorGenerator, anchor utils, ATSSAssigner,
+    DistancePointBBoxCoder, AnchorHead.get_anchors and GFLHead's target / loss code, loaded by path on top of
+    ``load_reference()``; ConvModule / Scale / BaseDenseHead are dummies (the layers are not run: the fixtures feed
+    cls_scores / bbox_preds)."""
+    ref = load_reference()
+
+    class _Dummy(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+    sys.modules["mmcv"].is_tuple_of = lambda seq, t: isinstance(seq, tuple) and all(isinstance(x, t) for x in seq)
+    cnn = sys.modules["mmcv.cnn"]
+    cnn.ConvModule, cnn.Scale = _Dummy, _Dummy
+    _pkg("mmdet.core.anchor", os.path.join(REF, "mmdet/core/anchor"))
+    _load("mmdet.core.anchor.builder", "mmdet/core/anchor/builder.py")
+    ag = _load("mmdet.core.anchor.anchor_generator", "mmdet/core/anchor/anchor_generator.py")
+    au = _load("mmdet.core.anchor.utils", "mmdet/core/anchor/utils.py")
+    _pkg("mmdet.core.bbox.coder", os.path.join(REF, "mmdet/core/bbox/coder"))
+    _load("mmdet.core.bbox.coder.base_bbox_coder", "mmdet/core/bbox/coder/base_bbox_coder.py")
+    tr = ref["tr"]
+    sys.modules["mmdet.core.bbox.transforms"] = tr
+    dp = _load("mmdet.core.bbox.coder.distance_point_bbox_coder", "mmdet/core/bbox/coder/distance_point_bbox_coder.py")
+    sys.modules["mmdet.core.bbox.iou_calculators"].build_iou_calculator = lambda cfg: ref["iou"].BboxOverlaps2D()
+    atss = _load("mmdet.core.bbox.assigners.atss_assigner", "mmdet/core/bbox/assigners/atss_assigner.py")
+    core, misc = sys.modules["mmdet.core"], ref["misc"]
+    bb = sys.modules["mmdet.core.bbox.builder"]
+    core.anchor_inside_flags, core.images_to_levels, core.unmap = au.anchor_inside_flags, au.images_to_levels, misc.unmap
+    core.build_bbox_coder = bb.build_bbox_coder
+    core.build_prior_generator = sys.modules["mmdet.core.anchor.builder"].build_prior_generator
+    _mod("mmdet.models.dense_heads.base_dense_head", BaseDenseHead=_Dummy)
+    _mod("mmdet.models.dense_heads.dense_test_mixins", BBoxTestMixin=type("BBoxTestMixin", (), {}))
+    ah = _load("mmdet.models.dense_heads.anchor_head", "mmdet/models/dense_heads/anchor_head.py")
+    gh = _load("mmdet.models.dense_heads.gfl_head", "mmdet/models/dense_heads/gfl_head.py")
+    ref.update(ag=ag, au=au, dp=dp, atss=atss, ah=ah, gh=gh)
+    return ref
+
+
+def main_gfl():
+    """gfl_cases.npz: for two batches (one with a padded image and an image without ground truth) the reference's
+    anchors and valid flags, ATSS assignment of image 0, the per-level targets and ``GFLHead.loss`` with gradients."""
+    ref = load_reference_gfl()
+    GH, AH, L_ = ref["gh"].GFLHead, ref["ah"].AnchorHead, ref["losses"]
+    strides = [8, 16, 32, 64, 128]
+    out = {}
+    for tag, (H, W), shapes_img, n_gts, seed in [("a", (128, 160), [(128, 160), (128, 160)], [3, 2], 1),
+                                                  ("b", (160, 224), [(160, 224), (120, 200)], [4, 0], 2)]:
+        g = torch.Generator().manual_seed(seed)
+        B = len(shapes_img)
+        self = types.SimpleNamespace()
+        self.num_classes = self.cls_out_channels = 80
+        self.reg_max, self.use_sigmoid_cls, self.sampling = 16, True, False
+        self.prior_generator = ref["ag"].AnchorGenerator(strides=strides, ratios=[1.0], octave_base_scale=8, scales_per_octave=1)
+        self.bbox_coder = ref["dp"].DistancePointBBoxCoder()
+        self.train_cfg = types.SimpleNamespace(allowed_border=-1, pos_weight=-1, debug=False)
+        self.assigner = ref["atss"].ATSSAssigner(topk=9)
+        self.sampler = ref["ps"].PseudoSampler()
+        self.integral = GH.__dict__ and ref["gh"].Integral(16)
+        self.loss_cls = L_["gfocal_loss"].QualityFocalLoss(use_sigmoid=True, beta=2.0, loss_weight=1.0)
+        self.loss_dfl = L_["gfocal_loss"].DistributionFocalLoss(loss_weight=0.25)
+        self.loss_bbox = L_["iou_loss"].GIoULoss(loss_weight=2.0)
+        for name in ("anchor_center", "loss_single", "loss", "get_targets", "_get_target_single", "get_num_level_anchors_inside"):
+            setattr(self, name, types.MethodType(getattr(GH, name), self))
+        self.get_anchors = types.MethodType(AH.get_anchors, self)
+        fsizes = [(-(-H // s), -(-W // s)) for s in strides]
+        metas = [dict(img_shape=(h, w, 3), pad_shape=(H, W, 3)) for h, w in shapes_img]
+        cls = [(torch.randn(B, 80, fh, fw, generator=g) * 1.5 - 3).requires_grad_(True) for fh, fw in fsizes]
+        box = [torch.randn(B, 68, fh, fw, generator=g).requires_grad_(True) for fh, fw in fsizes]
+        gt_b, gt_l = [], []
+        for (h, w), n in zip(shapes_img, n_gts):
+            xy = torch.rand(n, 2, generator=g) * torch.tensor([0.55 * w, 0.55 * h])
+            sz = torch.rand(n, 2, generator=g) * torch.tensor([0.4 * w, 0.4 * h]) + 12
+            gt_b.append(torch.cat([xy, xy + sz], 1))
+            gt_l.append(torch.randint(0, 80, (n,), generator=g))
+        anchors, flags = self.get_anchors(fsizes, metas, device="cpu")
+        for lvl in range(5):
+            out[f"{tag}/anchors{lvl}"] = anchors[0][lvl].numpy()
+            out[f"{tag}/flags{lvl}_img1"] = flags[1][lvl].numpy()
+        flat = torch.cat(anchors[0])
+        nla = [a.shape[0] for a in anchors[0]]
+        res = self.assigner.assign(flat, nla, gt_b[0], None, gt_l[0])
+        out[f"{tag}/atss_gt_inds"], out[f"{tag}/atss_labels"] = res.gt_inds.numpy(), res.labels.numpy()
+        out[f"{tag}/atss_max_overlaps"] = res.max_overlaps.numpy()
+        losses = self.loss(cls, box, gt_b, gt_l, metas)
+        total = sum(sum(v) for v in losses.values())
+        total.backward()
+        for k, v in losses.items():
+            out[f"{tag}/loss/{k}"] = torch.stack([x.detach() for x in v]).numpy()
+        for lvl in range(5):
+            out[f"{tag}/cls{lvl}"], out[f"{tag}/box{lvl}"] = cls[lvl].detach().numpy(), box[lvl].detach().numpy()
+            out[f"{tag}/gcls{lvl}"], out[f"{tag}/gbox{lvl}"] = cls[lvl].grad.numpy(), box[lvl].grad.numpy()
+        for i in range(B):
+            out[f"{tag}/gt_b{i}"], out[f"{tag}/gt_l{i}"] = gt_b[i].numpy(), gt_l[i].numpy()
+        out[f"{tag}/img_shapes"] = np.array(shapes_img)
+        out[f"{tag}/pad"] = np.array([H, W])
+    # bbox coder known answers
+    pts = torch.tensor([[10., 12.], [40., 8.]])
+    dist = torch.tensor([[3., 4., 5., 6.], [50., 9., 2., 1.]])
+    out["coder/decode"] = ref["dp"].DistancePointBBoxCoder().decode(pts, dist, max_shape=(30, 44)).numpy()
+    out["coder/encode"] = ref["dp"].DistancePointBBoxCoder().encode(pts, torch.tensor([[2., 3., 30., 40.], [0., 0., 45., 20.]]), 16).numpy()
+    np.savez_compressed(os.path.join(OUT, "gfl_cases.npz"), **out)
+    print("wrote gfl_cases.npz:", {k: v.shape for k, v in out.items() if "loss/" in k})
+
+
 if __name__ == "__main__":
+    if "--gfl" in sys.argv:
+        main_gfl()
+        sys.exit(0)
     if "--datasplit" in sys.argv:
         main_datasplit()
     elif "--decode" in sys.argv:

@@ -520,3 +520,84 @@ def test_graphed_student_head_equals_eager():
     assert len(m.bbox_head.__dict__["_head_graphs"]) == 2           # a second signature (dropout p) was captured
     assert all(v == v and abs(v) < 1e4 for v in vals)
     assert len(set(round(v, 6) for v in vals[3:])) == 2, vals       # replays (calls 4, 5) draw different masks
+
+
+def test_gfl_distillation_step_on_gpu_vs_cpu_oracle(oracle_checker):
+    """BASELINE.json configs[4] (GFL R50-FPN, CNN-head distillation path) on the GPU: the trunk's outputs against the
+    CPU run of the same weights, then -- on identical head inputs -- the stock GFL losses (ATSS targets, QFL / DFL /
+    GIoU; pinned to the reference on the CPU by tests/test_gfl.py) and the DSKD feature-map term through the HIP
+    kernel (``dskd_fgkd_fwd`` on the five pyramid levels) against the CPU oracle, values and the gradient that
+    reaches the student's pyramid."""
+    from dskd_amd.gfl_head import GFLHead
+    cfg = Config.fromfile(os.path.join(ROOT, "configs", "dskd_gfl_r50_fpn_40_40.py"))
+    torch.manual_seed(2)
+    m_cpu = build_detector(cfg.model)
+    m_cpu.init_weights()
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():                                  # features far from the N(0, 0.01) initialisation
+        for p in m_cpu.neck.parameters():
+            p.add_(torch.randn(p.shape, generator=g) * 0.05)
+    t = copy.deepcopy(m_cpu)
+    with torch.no_grad():
+        for p in t.parameters():
+            p.add_(torch.randn(p.shape, generator=g) * 2e-2)
+    m_cpu.set_teacher(model=t)
+    m_cpu.LableInPCNTask = {"prev": list(range(40)), "curr": list(range(40, 80)), "next": []}
+    m_gpu = copy.deepcopy(m_cpu).to("cuda:0").train()
+    m_cpu.train()
+    dev, cpu = torch.device("cuda:0"), torch.device("cpu")
+    B, H, W = 2, 192, 256
+    img = torch.randn(B, 3, H, W, generator=g)
+    metas = [dict(img_shape=(H, W, 3), pad_shape=(H, W, 3), scale_factor=1.0) for _ in range(B)]
+    gt_b = [torch.tensor([[10., 12., 90., 100.], [30., 20., 200., 150.]]), torch.tensor([[5., 5., 120., 90.]])]
+    gt_l = [torch.tensor([45, 71]), torch.tensor([79])]
+    t_b = [torch.tensor([[20., 20., 120., 110.], [0., 0., 60., 70.]]), torch.tensor([[40., 40., 200., 160.]])]
+
+    def to(x, d):
+        if torch.is_tensor(x):
+            return x.detach().to(d)
+        if isinstance(x, (list, tuple)):
+            return type(x)(to(y, d) for y in x)
+        if isinstance(x, dict):
+            return {k: to(v, d) for k, v in x.items()}
+        return x
+    # trunk: GPU vs CPU
+    with torch.no_grad():
+        xc = m_cpu.extract_feat(img)
+        oc = m_cpu.bbox_head.forward(xc)
+    xg = m_gpu.extract_feat(img.to(dev))
+    og = m_gpu.bbox_head.forward(xg)
+    for a, b in zip(list(xg) + list(og[0]) + list(og[1]), list(xc) + list(oc[0]) + list(oc[1])):
+        torch.testing.assert_close(a.detach().cpu(), b, rtol=2e-3, atol=2e-4)
+    with torch.no_grad():
+        ft = m_gpu.teacher_model.extract_feat(img.to(dev))
+    ti = dict(neck_feats=ft, pred_bboxes=to(t_b, dev))
+    assert isinstance(m_gpu.bbox_head, GFLHead)
+    # losses on identical head inputs
+    lg = m_gpu.bbox_head.loss(*og, to(gt_b, dev), to(gt_l, dev), metas)
+    fg_g = m_gpu.bbox_head.fg_feature_loss(xg, ti, to(gt_b, dev), metas)
+    xs_c = [x.detach().cpu().requires_grad_(True) for x in xg]
+    native.install_cpu_checker(oracle_checker)
+    try:
+        lc = m_cpu.bbox_head.loss(*to(og, cpu), gt_b, gt_l, metas)
+        fg_c = m_cpu.bbox_head.fg_feature_loss(xs_c, to(ti, cpu), gt_b, metas)
+        gc = torch.autograd.grad(fg_c, xs_c, allow_unused=True)
+    finally:
+        native.install_cpu_checker(None)
+    for k in lc:
+        torch.testing.assert_close(torch.stack([v.detach().cpu() for v in lg[k]]), torch.stack([v.detach() for v in lc[k]]),
+                                   rtol=1e-3, atol=1e-6, msg=lambda s: f"{k}: {s}")
+    assert float(fg_c) > 1e-4
+    torch.testing.assert_close(fg_g.detach().cpu(), fg_c.detach(), rtol=5e-2, atol=1e-6)      # fp32 noise of the CPU evaluation
+    gg = torch.autograd.grad(fg_g, list(xg), allow_unused=True)
+    for a, b in zip(gg, gc):
+        assert (a is None) == (b is None)
+        if a is not None:
+            rel = (a.cpu() - b).norm() / (b.norm() + 1e-12)
+            assert rel < 5e-2, float(rel)
+    # and a whole training step runs on the GPU
+    out = m_gpu.train_step(dict(img=img.to(dev), img_metas=metas, gt_bboxes=to(gt_b, dev), gt_labels=to(gt_l, dev),
+                                teacher_info=dict(ti, head_outs=None, pred_keepid=None, pred_logits=None, pred_scores=None,
+                                                  pred_labels=None)))
+    out["loss"].backward()
+    assert out["log_vars"]["loss_fg_feature"] > 0 and all(v == v for v in out["log_vars"].values())
