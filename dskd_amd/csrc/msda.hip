@@ -1366,6 +1366,268 @@ int launch_fwd_win(const __bf16* value, const float* loc, const float* attn, __b
   return DSKD_OK;
 }
 
+// ------------------------------------------------------------------ backward, grad_loc / grad_attn, windowed (encoder, bf16)
+// The gather half of the backward reads the same 64 corner segments per (query, head) as the forward and is paced by
+// the same texture path (msda_bwd_kernel: 263 us at B=4).  This is the forward's MIXED windowed scheme applied to it:
+// a workgroup owns (image, region of <= 16x16 level-0 pixels, one head), holds that head's value windows of the
+// coarse levels (>= lv0) in LDS and leaves the fine levels on the buffer-load path, so both pipes work side by side.
+//   lane = (query of the pass, 16-B part of the head's 64-B line); per sample the four corner dot products with the
+//   query's grad_out slice are formed per lane over its 8 channels and reduced over the 4 part-lanes with DPP --
+//   the same channels per lane and the same reduction as msda_bwd_kernel<bf16>, hence bit-identical gradients;
+//   the 16 (gx, gy, ga) triples of a (query, head) are parked in LDS and leave as whole 128-B / 64-B runs.
+template <typename T>
+__global__ __launch_bounds__(1024) void msda_bwd_win_kernel(
+    const T* __restrict__ value, const float* __restrict__ loc, const float* __restrict__ attn,
+    const T* __restrict__ grad_out, float* __restrict__ grad_loc, float* __restrict__ grad_attn, ValueGeom g,
+    FwdWinGeom fw, int Nq, int points) {
+  static_assert(sizeof(T) == 2, "windowed gather: bf16 only");
+  constexpr int PIXB = kCh * (int)sizeof(T);     // 64 B: one head of one pixel
+  constexpr int ROWB = kHeads * PIXB;            // 512 B: one pixel, all heads
+  constexpr int LP = 16;
+  extern __shared__ float smem[];
+  char* win = reinterpret_cast<char*>(smem);                                    // [npos + 1][PIXB]
+  const int NW = blockDim.x >> 6;
+  i32x4* s_off_all = reinterpret_cast<i32x4*>(win + (size_t)(fw.npos + 1) * PIXB);   // [NW][16 * kFwdHS]
+  f32x4* s_aux_all = reinterpret_cast<f32x4*>(s_off_all + NW * 16 * kFwdHS);         // {lx, ly, attn, 0}
+  f32x2* s_gl_all = reinterpret_cast<f32x2*>(s_aux_all + NW * 16 * kFwdHS);          // [NW][16 queries][16 samples]
+  float* s_ga_all = reinterpret_cast<float*>(s_gl_all + NW * 16 * LP);               // [NW][16][16]
+  i32x4* s_tab = reinterpret_cast<i32x4*>(s_ga_all + NW * 16 * LP);                  // [4][4] lookup rows
+  int* s_geo = reinterpret_cast<int*>(s_tab + 4 * kMaxLevels);                       // [24] region geometry
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  int vb = xcd_remap(blockIdx.x, gridDim.x);
+  const int h = vb & 7; vb >>= 3;
+  const int rx = vb % g.RX; vb /= g.RX;
+  const int ry = vb % g.RY;
+  const int b = vb / g.RY;
+
+  // Region geometry: as in msda_fwd_win_kernel (same tables, same integer arithmetic).
+  if (wave == 0) {
+    if (lane < 6 * kMaxLevels) {
+      const int l = lane / 6, kind = lane - 6 * l;
+      const bool xaxis = kind == 0 || kind == 1 || kind == 4;
+      int Sl = 1;
+#pragma unroll
+      for (int k = 0; k < kMaxLevels; ++k)
+        if (l == k) Sl = xaxis ? g.W[k] : g.H[k];
+      const int S0 = xaxis ? g.W[0] : g.H[0], E = xaxis ? g.EX : g.EY;
+      const int r = (xaxis ? rx : ry) + ((kind == 1 || kind == 3) ? 1 : 0);
+      const int q = floor_div(2 * E * r * Sl - S0 + (kind < 4 ? 2 * S0 - 1 : 0), 2 * S0);
+      s_geo[lane] = kind < 4 ? (q < 0 ? 0 : (q > Sl ? Sl : q)) : q - kMarginLo;
+    }
+    wave_lds_sync();
+    int tot = 0, mine = 0;
+#pragma unroll
+    for (int k = 0; k < kMaxLevels; ++k) {
+      if (k == lane) mine = tot;
+      if (k < g.levels) tot += (s_geo[6 * k + 1] - s_geo[6 * k]) * (s_geo[6 * k + 3] - s_geo[6 * k + 2]);
+    }
+#pragma unroll
+    for (int l = 0; l < kMaxLevels; ++l)
+      if (lane == l) {
+        const int qxa = s_geo[6 * l], qya = s_geo[6 * l + 2];
+        const int qdx = l < g.levels ? s_geo[6 * l + 1] - qxa : 0;
+        s_tab[4 * l + 0] = i32x4{mine, qxa, qya, qdx};
+        s_tab[4 * l + 1] = i32x4{as_i32(1.0f / (float)(qdx > 0 ? qdx : 1)), g.start[l], g.W[l], g.H[l]};
+        s_tab[4 * l + 2] = i32x4{g.ww[l], g.wh[l], s_geo[6 * l + 4], s_geo[6 * l + 5]};
+        s_tab[4 * l + 3] = i32x4{fw.base[l], tot, 0, 0};
+      }
+  }
+  __syncthreads();
+  int cum[kMaxLevels];
+#pragma unroll
+  for (int l = 0; l < kMaxLevels; ++l) cum[l] = s_tab[4 * l].x;
+  const int nq = s_tab[3].y;
+
+  const T* vbase = value + (size_t)b * Nq * (kHeads * kCh);      // Nq == Nv
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(vbase), 0, Nq * ROWB, 0x00020000);
+  const int part = lane & 3;
+  const int hb = h * PIXB + part * 16;
+
+  // ---- window fill (as in the forward)
+  {
+    constexpr int kFill = 5;
+    const int step = blockDim.x >> 2;
+    for (int p0 = tid >> 2; p0 <= fw.npos; p0 += kFill * step) {
+      u32x4 v[kFill];
+#pragma unroll
+      for (int u = 0; u < kFill; ++u) {
+        const int p = p0 + u * step;
+        int l = fw.lv0;
+#pragma unroll
+        for (int k = 1; k < kMaxLevels; ++k) l += (k > fw.lv0 && p >= fw.base[k]) ? 1 : 0;
+        const i32x4 lb = s_tab[4 * l + 1], lc = s_tab[4 * l + 2];
+        const int rel = p - s_tab[4 * l + 3].x;
+        const int wwl = lc.x;
+        const int wy = (int)(((float)rel + 0.5f) / (float)wwl), wx = rel - wy * wwl;
+        const int gx = lc.z + wx, gy = lc.w + wy;
+        const bool in = p < fw.npos && gx >= 0 && gx < lb.z && gy >= 0 && gy < lb.w;
+        const int goff = in ? (lb.y + gy * lb.z + gx) * ROWB + hb : kOOB;
+        v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff, 0, 0));
+      }
+#pragma unroll
+      for (int u = 0; u < kFill; ++u) {
+        const int p = p0 + u * step;
+        if (p <= fw.npos) *reinterpret_cast<u32x4*>(win + (size_t)p * PIXB + part * 16) = v[u];
+      }
+    }
+  }
+  __syncthreads();
+
+  i32x4* s_off = s_off_all + wave * 16 * kFwdHS;
+  f32x4* s_aux = s_aux_all + wave * 16 * kFwdHS;
+  f32x2* s_gl = s_gl_all + wave * 16 * LP;
+  float* s_ga = s_ga_all + wave * 16 * LP;
+  const int ql = lane >> 2;                  // query of the pass
+  const int zero_slot = fw.npos * PIXB;
+
+  f32x2 n_xy[kMaxLevels];
+  float n_a[kMaxLevels];
+  u32x4 n_go = u32x4{0u, 0u, 0u, 0u};
+  int n_qg = -1;
+  auto fetch = [&](int qb) {
+    const int qi = qb + ql;
+    n_qg = qi < nq ? region_query(s_tab, cum, qi) : -1;
+    if (n_qg >= 0) {
+      const size_t base = (((size_t)b * Nq + n_qg) * kHeads + h) * (size_t)LP + part;
+#pragma unroll
+      for (int l = 0; l < kMaxLevels; ++l) {
+        n_xy[l] = *reinterpret_cast<const f32x2*>(loc + (base + l * points) * 2);
+        n_a[l] = attn[base + l * points];
+      }
+      n_go = *reinterpret_cast<const u32x4*>(grad_out + ((size_t)b * Nq + n_qg) * (kHeads * kCh) + h * kCh + part * 8);
+    }
+  };
+  fetch(wave * 16);
+
+  for (int qbase = wave * 16; qbase < nq; qbase += NW * 16) {
+    const int qg = n_qg;
+    f32x2 c_xy[kMaxLevels];
+    float c_a[kMaxLevels];
+#pragma unroll
+    for (int l = 0; l < kMaxLevels; ++l) { c_xy[l] = n_xy[l]; c_a[l] = n_a[l]; }
+    float go[8];
+    unpack_bf16x8(n_go, go);
+    fetch(qbase + NW * 16);
+
+#pragma unroll
+    for (int lvl = 0; lvl < kMaxLevels; ++lvl) {
+      // ---- stage the 4 points of this level: lane = (query, point)
+      {
+        i32x4 off = i32x4{zero_slot, zero_slot, zero_slot, zero_slot};
+        f32x4 aux = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (qg >= 0) {
+          const f32x2 xy = c_xy[lvl];
+          const i32x4 lb = s_tab[4 * lvl + 1], lc = s_tab[4 * lvl + 2];
+          const int H = lb.w, W = lb.z, st = lb.y;
+          const float x = xy.x * (float)W - 0.5f;
+          const float y = xy.y * (float)H - 0.5f;
+          aux.z = c_a[lvl];
+          if (x > -1.f && y > -1.f && x < (float)W && y < (float)H) {   // as point_params
+            const float xf = floorf(x), yf = floorf(y);
+            const int x0 = (int)xf, y0 = (int)yf;
+            aux.x = x - xf;
+            aux.y = y - yf;
+            const int wwl = lc.x, whl = lc.y;
+            const int wx = x0 - lc.z, wy = y0 - lc.w;
+            if (lvl >= fw.lv0 && wx >= 0 && wx + 1 < wwl && wy >= 0 && wy + 1 < whl) {
+              const int pb = (s_tab[4 * lvl + 3].x + wy * wwl + wx) * PIXB;
+              off = i32x4{pb, pb + PIXB, pb + wwl * PIXB, pb + wwl * PIXB + PIXB};
+            } else {      // left the window: global byte offsets, flagged by the sign bit
+              const bool vx0 = x0 >= 0, vx1 = x0 + 1 <= W - 1;
+              const bool vy0 = y0 >= 0, vy1 = y0 + 1 <= H - 1;
+              const int r00 = (st + y0 * W + x0) * ROWB;
+              off.x = ((vy0 && vx0) ? r00 : kOOB) | kFwdSign;
+              off.y = ((vy0 && vx1) ? r00 + ROWB : kOOB) | kFwdSign;
+              off.z = ((vy1 && vx0) ? r00 + W * ROWB : kOOB) | kFwdSign;
+              off.w = ((vy1 && vx1) ? r00 + W * ROWB + ROWB : kOOB) | kFwdSign;
+            }
+          }
+        }
+        s_off[ql * kFwdHS + part] = off;
+        s_aux[ql * kFwdHS + part] = aux;
+      }
+      wave_lds_sync();
+      const i32x4 lt = s_tab[4 * lvl + 1];
+      const float Wf = (float)lt.z, Hf = (float)lt.w;
+      // ---- consume: lane = (query, 16-B part)
+#pragma unroll 2
+      for (int sl = 0; sl < 4; ++sl) {
+        const i32x4 o = s_off[ql * kFwdHS + sl];
+        u32x4 r0, r1, r2, r3;
+        if (o.x < 0) {
+          r0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (o.x & 0x7FFFFFFF) + hb, 0, 0));
+          r1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (o.y & 0x7FFFFFFF) + hb, 0, 0));
+          r2 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (o.z & 0x7FFFFFFF) + hb, 0, 0));
+          r3 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (o.w & 0x7FFFFFFF) + hb, 0, 0));
+        } else {
+          r0 = *reinterpret_cast<const u32x4*>(win + o.x + part * 16);
+          r1 = *reinterpret_cast<const u32x4*>(win + o.y + part * 16);
+          r2 = *reinterpret_cast<const u32x4*>(win + o.z + part * 16);
+          r3 = *reinterpret_cast<const u32x4*>(win + o.w + part * 16);
+        }
+        float v0[8], v1[8], v2[8], v3[8];
+        unpack_bf16x8(r0, v0);
+        unpack_bf16x8(r1, v1);
+        unpack_bf16x8(r2, v2);
+        unpack_bf16x8(r3, v3);
+        float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          d0 = fmaf(v0[i], go[i], d0);
+          d1 = fmaf(v1[i], go[i], d1);
+          d2 = fmaf(v2[i], go[i], d2);
+          d3 = fmaf(v3[i], go[i], d3);
+        }
+        d0 = group4_sum(d0); d1 = group4_sum(d1); d2 = group4_sum(d2); d3 = group4_sum(d3);
+        if (part == sl) {           // one lane of the group finishes the sample (as msda_bwd_kernel)
+          const f32x4 ax = s_aux[ql * kFwdHS + sl];
+          const float lx = ax.x, ly = ax.y, a = ax.z;
+          const float hx = 1.f - lx, hy = 1.f - ly;
+          const float ga = (hy * hx) * d0 + (hy * lx) * d1 + (ly * hx) * d2 + (ly * lx) * d3;
+          const float gx = Wf * a * (hy * (d1 - d0) + ly * (d3 - d2));
+          const float gy = Hf * a * (hx * (d2 - d0) + lx * (d3 - d1));
+          s_gl[ql * LP + lvl * 4 + sl] = f32x2{gx, gy};
+          s_ga[ql * LP + lvl * 4 + sl] = ga;
+        }
+      }
+      wave_lds_sync();   // the next level's staging overwrites the slots
+    }
+    // ---- write the pass out: 16 queries x 16 samples, whole (query, head) runs
+    {
+      const int nvalid = min(16, nq - qbase);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int idx = it * 64 + lane;          // (query of the pass, sample)
+        const int q2 = idx >> 4, smp = idx & 15;
+        const int qg2 = __shfl(qg, q2 * 4);      // the query's global index lives in its first lane (all lanes take part:
+        if (q2 < nvalid) {                       // a shuffle reads nothing from a lane that sits out a branch)
+          const size_t base = (((size_t)b * Nq + qg2) * kHeads + h) * (size_t)LP + smp;
+          grad_attn[base] = s_ga[q2 * LP + smp];
+          *reinterpret_cast<f32x2*>(grad_loc + base * 2) = s_gl[q2 * LP + smp];
+        }
+      }
+    }
+    wave_lds_sync();
+  }
+}
+
+int launch_bwd_win(const __bf16* value, const float* loc, const float* attn, const __bf16* grad_out, float* grad_loc,
+                   float* grad_attn, const ValueGeom& g, const FwdWinGeom& fw, size_t lds, int B, int Nq, int points,
+                   hipStream_t st) {
+  auto kern = msda_bwd_win_kernel<__bf16>;
+  static const hipError_t attr = hipFuncSetAttribute(
+      (const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+  if (attr != hipSuccess) return fail(DSKD_ERR_LAUNCH, "dskd_msda_bwd: cannot reserve LDS");
+  const dim3 grid((unsigned)(B * g.RY * g.RX * kHeads)), block(fw.waves * 64);
+  hipLaunchKernelGGL(kern, grid, block, lds, st, value, loc, attn, grad_out, grad_loc, grad_attn, g, fw, Nq, points);
+  return DSKD_OK;
+}
+
 int fill_geom(const int64_t* spatial_shapes, const int64_t* level_start, int levels, int Nv,
               LevelGeom* g) {
   int64_t covered = 0;
@@ -1579,7 +1841,28 @@ int msda_bwd_impl(const void* value, const int64_t* spatial_shapes, const int64_
 #define DSKD_BWD_BF16(PH)                                                                                         \
   hipLaunchKernelGGL((msda_bwd_kernel<__bf16, false, PH>), grid, block, 0, st, (const __bf16*)value, loc, attn,   \
                      (const __bf16*)grad_out, grad_value, grad_loc, grad_attn, g, Nv, Nq, LP, points, qpb, bpi)
-      switch (pick_phases(LP, dtype, 4)) {
+      // grad_loc / grad_attn: the mixed windowed gather (levels 2+3 of one head in LDS, bit-identical to the plain
+      // kernel); DSKD_MSDA_BWD_GATHER=plain forces the plain kernel, DSKD_MSDA_FWD_LV0 / _NW are shared A/B knobs
+      bool gathered = false;
+      const char* gv_env = getenv("DSKD_MSDA_BWD_GATHER");
+      if (!(gv_env && gv_env[0] == 'p')) {
+        const char* e_lv0 = getenv("DSKD_MSDA_FWD_LV0");
+        const char* e_nw = getenv("DSKD_MSDA_FWD_NW");
+        int lv0 = e_lv0 ? atoi(e_lv0) : 2;
+        if (lv0 < 0 || lv0 > 3) lv0 = 2;
+        ValueGeom wg;
+        FwdWinGeom fw;
+        size_t wl = 0;
+        if (make_fwd_win_geom(g, levels, points, Nq, lv0, e_nw ? atoi(e_nw) : 8, &wg, &fw, &wl)) {
+          wl += (size_t)fw.waves * 16 * 16 * 12;            // the parked (gx, gy, ga) triples of a pass
+          if (wl <= kMaxLds) {
+            if (int rc = launch_bwd_win((const __bf16*)value, loc, attn, (const __bf16*)grad_out, grad_loc, grad_attn, wg,
+                                        fw, wl, B, Nq, points, st)) return rc;
+            gathered = true;
+          }
+        }
+      }
+      if (!gathered) switch (pick_phases(LP, dtype, 4)) {
         case 4: DSKD_BWD_BF16(4); break;
         case 2: DSKD_BWD_BF16(2); break;
         default: DSKD_BWD_BF16(1); break;

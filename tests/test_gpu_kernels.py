@@ -419,6 +419,36 @@ def test_msda_windowed_forward_is_bit_identical(monkeypatch, shapes, B, sigma, k
     torch.testing.assert_close(win.float().cpu(), want, atol=3e-2, rtol=2e-2)
 
 
+@pytest.mark.parametrize("shapes,B,sigma", [([(25, 42), (13, 21), (7, 11), (4, 6)], 2, 2.0),
+                                            ([(25, 42), (13, 21), (7, 11), (4, 6)], 2, 12.0),     # most samples leave the windows
+                                            ([(40, 70), (20, 35), (10, 18), (5, 9)], 3, 6.0),
+                                            ([(17, 16), (9, 8), (5, 4), (3, 2)], 2, 1.0),
+                                            (SHAPES_FULL, 1, 2.5)])
+@pytest.mark.parametrize("knobs", ["default", (0, 0), (3, 4)])
+def test_msda_windowed_gather_is_bit_identical(monkeypatch, shapes, B, sigma, knobs):
+    """grad_loc / grad_attn of the encoder shape (bf16): the mixed windowed gather (coarse value windows of one head in
+    LDS, msda_bwd_win_kernel) against the plain kernel -- same channels per lane, same DPP reduction, same final
+    arithmetic, so the gradients must carry identical bits, borders / rejected / NaN / far samples included; and the
+    plain kernel's are the oracle's (test_msda_bwd_* above)."""
+    value, loc, attn, go = _encoder_like_inputs(shapes, B, 83, sigma, torch.bfloat16)
+    loc[0, :7] = torch.tensor([-0.2, 0.0, 0.5, 1.0, 1.3, float("nan"), 0.999]).view(7, 1, 1, 1, 1)
+    args = (value.to(DEV), shapes, loc.to(DEV), attn.to(DEV), go.to(DEV))
+    for k in ("DSKD_MSDA_BWD_GATHER", "DSKD_MSDA_FWD_LV0", "DSKD_MSDA_FWD_NW"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("DSKD_MSDA_BWD_GATHER", "plain")
+    _, gl0, ga0 = native.msda_backward_raw(*args)
+    monkeypatch.delenv("DSKD_MSDA_BWD_GATHER")
+    if knobs != "default":
+        monkeypatch.setenv("DSKD_MSDA_FWD_LV0", str(knobs[0]))
+        monkeypatch.setenv("DSKD_MSDA_FWD_NW", str(knobs[1]))
+    _, gl1, ga1 = native.msda_backward_raw(*args)
+    torch.cuda.synchronize()
+    for k in ("DSKD_MSDA_FWD_LV0", "DSKD_MSDA_FWD_NW"):
+        monkeypatch.delenv(k, raising=False)
+    same = lambda a, b: torch.equal(a.nan_to_num(nan=12345.0), b.nan_to_num(nan=12345.0))      # noqa: E731
+    assert same(ga1, ga0) and same(gl1, gl0)
+
+
 # ----------------------------------------------------------------------------- add + dropout + LayerNorm
 def test_dropout_masks_change_between_graph_replays():
     """(seed, offset) are launch arguments and are frozen into a captured hipGraph; the kernels also read
