@@ -191,7 +191,8 @@ def mfma_utilisation(step_fn, dtype):
     t_us, n, total_us, names = 0.0, 0, 0.0, {}
     for e in prof.key_averages():
         dt = float(getattr(e, "self_device_time_total", 0.0) or 0.0)
-        if dt <= 0 or "Memcpy" in e.key or "Memset" in e.key:
+        if dt <= 0 or "Memcpy" in e.key or "Memset" in e.key or e.key.startswith("aten::") or \
+                getattr(e, "device_type", None) != torch.autograd.DeviceType.CUDA:      # device kernels only, not the ops that own them
             continue
         total_us += dt
         if any(pat in e.key for pat in GEMM_CONV_PATTERNS):

@@ -9,6 +9,6 @@ tail -25 gpurun_out/r02_gpu_tests.log
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r02_smoke.log 2>&1; rc=$?
 tail -3 gpurun_out/r02_smoke.log
 [ $rc -eq 0 ] || exit $rc
-DSKD_BENCH_STEPTIMES=1 timeout -k 10 400 python bench.py --steps 20 --no-cpu-baseline > gpurun_out/r02_bench_a.json 2> gpurun_out/r02_bench_a.err; rc=$?
+DSKD_BENCH_STEPTIMES=1 timeout -k 10 400 python bench.py --steps 20 > gpurun_out/r02_bench_a.json 2> gpurun_out/r02_bench_a.err; rc=$?
 tail -5 gpurun_out/r02_bench_a.err; cat gpurun_out/r02_bench_a.json
 exit $rc
