@@ -3,6 +3,8 @@
 ``_freeze_stages`` :613-629, ``train`` / norm_eval :648-659; ``Bottleneck`` :100-303 with
 style='pytorch' = stride on the 3x3 conv).  Dense convolutions run on MIOpen/hipBLASLt (MFMA)
 through PyTorch-ROCm; nothing here is hand-written."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -23,11 +25,60 @@ class FrozenAffineBN(nn.BatchNorm2d):
         return x * scale.to(x.dtype).view(1, -1, 1, 1) + shift.to(x.dtype).view(1, -1, 1, 1)
 
 
+class _Conv1x1Fn(torch.autograd.Function):
+    """1x1 stride-1 convolution on a channels_last bf16 activation whose WEIGHT gradient is a split-K GEMM.
+    MIOpen's weight-gradient algorithms for these shapes accumulate in an f32 workspace: every call comes with a
+    workspace zero fill and a cast kernel (``SubTensorOpWithScalar1d`` / ``SubTensorOpWithCastTensor1d``: ~300 helper
+    launches and 3.9 ms per step at B=4).  With NHWC memory the activation IS the [N*H*W, Cin] matrix, so
+    dW = dY^T X is computed like the tall Linear layers' (transformer._TallLinearFn): token chunks as the batch of one
+    bmm, f32 sum of the partial products.  Forward and dX stay on the library's convolution kernels."""
+
+    @staticmethod
+    def forward(ctx, x, w, chunk):
+        ctx.chunk = chunk
+        ctx.save_for_backward(x, w)
+        return F.conv2d(x, w)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                                                     [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            g2 = g.permute(0, 2, 3, 1).reshape(-1, g.shape[1])          # views: channels_last memory is [N*H*W, C]
+            x2 = x.permute(0, 2, 3, 1).reshape(-1, x.shape[1])
+            nb = x2.shape[0] // ctx.chunk
+            part = torch.bmm(g2.view(nb, ctx.chunk, -1).transpose(1, 2), x2.view(nb, ctx.chunk, -1))
+            gw = part.sum(0, dtype=torch.float32).to(w.dtype).view(w.shape)
+            if w.stride() != gw.stride():
+                gw = gw.as_strided(w.shape, w.stride())
+        return gx, gw, None
+
+
+def _conv1x1_gemm_wgrad(conv, x, w):
+    """The chunk size for :class:`_Conv1x1Fn`, or None when the convolution does not qualify."""
+    if not (x.is_cuda and torch.is_grad_enabled() and w.requires_grad and w.dtype == torch.bfloat16 and x.dtype == w.dtype
+            and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
+            and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)):
+        return None
+    tokens = x.shape[0] * x.shape[2] * x.shape[3]
+    if tokens < 16384:
+        return None
+    from .transformer import _token_chunk
+    return _token_chunk(tokens, w.numel())
+
+
 def _conv_epilogue(conv, x, w, b, relu, identity):
     """Folded convolution WITHOUT bias, then ONE in-place pass for bias (+ identity) (+ ReLU)
     (native.bias_act).  PyTorch's MIOpen path would run the bias add, the residual add and the
     ReLU as separate launches that each stream the whole activation."""
-    y = F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+    chunk = _conv1x1_gemm_wgrad(conv, x, w)
+    if chunk is not None and not os.environ.get("DSKD_CONV_WGRAD_MIOPEN"):
+        y = _Conv1x1Fn.apply(x, w, chunk)
+    else:
+        y = F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
     if b is None and identity is None:
         return F.relu(y, inplace=True) if relu else y
     if not y.is_cuda:                       # host tensors: the same arithmetic with PyTorch ops

@@ -601,3 +601,27 @@ def test_gfl_distillation_step_on_gpu_vs_cpu_oracle(oracle_checker):
                                                   pred_labels=None)))
     out["loss"].backward()
     assert out["log_vars"]["loss_fg_feature"] > 0 and all(v == v for v in out["log_vars"].values())
+
+
+def test_conv1x1_gemm_weight_gradient_on_gpu(monkeypatch):
+    """ResNet 1x1 convolutions take their weight gradient from a split-K GEMM (backbones._Conv1x1Fn) instead of MIOpen's
+    workspace algorithms: same bf16 output, dX and dW (to bf16 accumulation-order noise) as the library path."""
+    import torch.nn as nn
+    from dskd_amd import backbones
+    torch.manual_seed(5)
+    conv = nn.Conv2d(256, 64, 1, bias=False).to("cuda", torch.bfloat16)
+    x = torch.randn(4, 256, 100, 168, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    up = torch.randn(4, 64, 100, 168, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert backbones._conv1x1_gemm_wgrad(conv, x, conv.weight) is not None
+    res = []
+    for force_lib in (False, True):
+        if force_lib:
+            monkeypatch.setenv("DSKD_CONV_WGRAD_MIOPEN", "1")
+        xi = x.clone().requires_grad_(True)
+        y = backbones._conv_epilogue(conv, xi, conv.weight, None, False, None)
+        gx, gw = torch.autograd.grad(y, (xi, conv.weight), up)
+        res.append((y.float(), gx.float(), gw.float()))
+    (y0, gx0, gw0), (y1, gx1, gw1) = res
+    assert torch.equal(y0, y1)
+    assert torch.allclose(gx0, gx1, rtol=2e-2, atol=2e-2 * float(gx1.abs().max()))
+    assert float((gw0 - gw1).abs().max()) <= 2e-2 * float(gw1.abs().max())
