@@ -31,7 +31,9 @@ class _Conv1x1Fn(torch.autograd.Function):
     workspace zero fill and a cast kernel (``SubTensorOpWithScalar1d`` / ``SubTensorOpWithCastTensor1d``: ~300 helper
     launches and 3.9 ms per step at B=4).  With NHWC memory the activation IS the [N*H*W, Cin] matrix, so
     dW = dY^T X is computed like the tall Linear layers' (transformer._TallLinearFn): token chunks as the batch of one
-    bmm, f32 sum of the partial products.  Forward and dX stay on the library's convolution kernels."""
+    bmm, f32 sum of the partial products.  Forward and dX stay on the library's convolution kernels.
+    Measured in the B=4 step (r2, A/B twice): 38.3-38.7 ms with this path against 37.9-38.0 ms with MIOpen's -- the
+    helper launches go, but the bmm + f32 reduction cost more than they did -- so it is OFF unless DSKD_CONV_WGRAD_GEMM=1."""
 
     @staticmethod
     def forward(ctx, x, w, chunk):
@@ -74,8 +76,8 @@ def _conv_epilogue(conv, x, w, b, relu, identity):
     """Folded convolution WITHOUT bias, then ONE in-place pass for bias (+ identity) (+ ReLU)
     (native.bias_act).  PyTorch's MIOpen path would run the bias add, the residual add and the
     ReLU as separate launches that each stream the whole activation."""
-    chunk = _conv1x1_gemm_wgrad(conv, x, w)
-    if chunk is not None and not os.environ.get("DSKD_CONV_WGRAD_MIOPEN"):
+    chunk = _conv1x1_gemm_wgrad(conv, x, w) if os.environ.get("DSKD_CONV_WGRAD_GEMM") else None
+    if chunk is not None:
         y = _Conv1x1Fn.apply(x, w, chunk)
     else:
         y = F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)

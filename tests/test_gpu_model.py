@@ -604,8 +604,9 @@ def test_gfl_distillation_step_on_gpu_vs_cpu_oracle(oracle_checker):
 
 
 def test_conv1x1_gemm_weight_gradient_on_gpu(monkeypatch):
-    """ResNet 1x1 convolutions take their weight gradient from a split-K GEMM (backbones._Conv1x1Fn) instead of MIOpen's
-    workspace algorithms: same bf16 output, dX and dW (to bf16 accumulation-order noise) as the library path."""
+    """Opt-in (DSKD_CONV_WGRAD_GEMM=1; measured slower in the step): ResNet 1x1 convolutions with the weight gradient from
+    a split-K GEMM (backbones._Conv1x1Fn) instead of MIOpen's workspace algorithms: same bf16 output, dX and dW (to bf16
+    accumulation-order noise) as the library path."""
     import torch.nn as nn
     from dskd_amd import backbones
     torch.manual_seed(5)
@@ -616,7 +617,9 @@ def test_conv1x1_gemm_weight_gradient_on_gpu(monkeypatch):
     res = []
     for force_lib in (False, True):
         if force_lib:
-            monkeypatch.setenv("DSKD_CONV_WGRAD_MIOPEN", "1")
+            monkeypatch.delenv("DSKD_CONV_WGRAD_GEMM")
+        else:
+            monkeypatch.setenv("DSKD_CONV_WGRAD_GEMM", "1")
         xi = x.clone().requires_grad_(True)
         y = backbones._conv_epilogue(conv, xi, conv.weight, None, False, None)
         gx, gw = torch.autograd.grad(y, (xi, conv.weight), up)
