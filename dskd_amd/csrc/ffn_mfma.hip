@@ -36,6 +36,10 @@ constexpr int kF = 1024;           // hidden
 constexpr int kTiles = kF / 32;    // hidden tiles
 constexpr int kTileBytes = 32768;  // 16 KB GEMM-1 fragments + 16 KB GEMM-2 fragments
 constexpr int kFragsPerTile = kTileBytes / 16;
+#ifndef DSKD_FFN_RING
+#define DSKD_FFN_RING 8
+#endif
+constexpr int kRing = DSKD_FFN_RING;           // A fragments in flight per wave (32 VGPRs)
 
 // MFMA row slot r of a 32-row A tile carries row pi(r) of the matrix: with the C/D map
 // row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) this makes accumulator register i of lane half h row 16 h + i.
@@ -89,6 +93,22 @@ __device__ __forceinline__ u32x4 philox8(unsigned long long idx, unsigned long l
   return u32x4{c0, c1, c2, c3};
 }
 
+// A fragment reads are written as asm: hipcc sinks an ordinary LDS load down to its use (one register set, ds_read ->
+// s_waitcnt 0 -> MFMA: every MFMA then pays the LDS latency), whatever the source order or sched_group_barrier says.
+// The compiler does not count these reads, so each use is preceded by frag_wait<N>: "at most N younger reads in
+// flight" (LDS returns in order; reads the compiler issues itself only make the wait longer, never shorter).
+__device__ __forceinline__ bf16x8 frag_read(unsigned lds_addr, int byte_offset) {
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(byte_offset));
+  return v;
+}
+__device__ __forceinline__ void frag_wait(bf16x8& v, int younger) {      // `younger`: a constant after unrolling
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(younger));
+}
+__device__ __forceinline__ unsigned lds_offset(const void* p) {
+  return (unsigned)(unsigned long)((const __attribute__((address_space(3))) char*)p);
+}
+
 struct FfnArgs {
   const __bf16* in;      // X (forward) / dY (backward)  [T, 256]
   const __bf16* wp;      // packed weights of this direction [32 tiles][32 KB]
@@ -104,34 +124,68 @@ struct FfnArgs {
   const unsigned long long* epoch;
 };
 
-enum { kFwdTrain = 0, kFwdEval = 1, kBwd = 2 };
+enum { kFwdTrain = 0, kFwdEval = 1, kBwd = 2, kFwdTrainDrop = 3 };   // kFwdTrain: H stored, p = 0
+enum { kFirst = 0, kMid = 1, kMidBeforeLast = 2, kLast = 3 };      // iteration kinds of the skewed tile loop
+template <int V> struct IntTag { static constexpr int value = V; };
 
-template <int MODE, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void ffn_fused_kernel(const FfnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];       // 2 x 32 KB weight tiles | 4 KB b1 as f32
-  float* const s_b1 = reinterpret_cast<float*>(smem + 2 * kTileBytes);
+constexpr int kBufs = 4;           // LDS weight tiles: c - 1 (GEMM-2), c (GEMM-1), c + 1 (prefetch), c + 2 (landing)
+constexpr int kWaves = 4;          // 128 tokens per workgroup, one wave per SIMD (the kernel needs ~300 registers)
+
+__device__ __forceinline__ void vm_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void vm_wait_but2() { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+__device__ __forceinline__ void vm_wait_but4() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+__device__ __forceinline__ void lds_write16(unsigned lds_addr, const bf16x8& v) {
+  asm volatile("ds_write_b128 %0, %1" ::"v"(lds_addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ bf16x8 gload16(const __bf16* p) {
+  bf16x8 v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+// Store under a lane mask without compiler-visible control flow (a branch in the middle of the tile loop would cut
+// the scheduling region that interleaves the MFMAs with everything else).  Called with every lane active; only
+// s_mov, which leaves SCC alone (the compiler may hold a loop condition there across the asm).
+__device__ __forceinline__ void gstore16_masked(__bf16* p, const bf16x8& v, unsigned long long lanes) {
+  unsigned long long saved;
+  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %3\n\tglobal_store_dwordx4 %1, %2, off\n\ts_mov_b64 exec, %0"
+               : "=&s"(saved) : "v"(p), "v"(v), "s"(lanes) : "memory");
+}
+
+// One workgroup = 4 waves x 32 tokens.  Iteration c of the tile loop runs GEMM-1 of hidden tile c and, behind it,
+// GEMM-2 of tile c - 1 with the elementwise step of tile c in the vector slots between those MFMAs (one wave per SIMD:
+// nothing else would fill them).  Weight tiles land in LDS two iterations ahead (LDS-DMA); every iteration starts
+// with "my own DMA of the previous iteration has landed" + one barrier.  All memory instructions of the loop are
+// either builtins with side effects or volatile asm, so they are issued in source order and the counted waits hold.
+template <int MODE_>
+__global__ __launch_bounds__(kWaves * 64) void ffn_fused_kernel(const FfnArgs a) {
+  constexpr int MODE = MODE_ == kFwdTrainDrop ? kFwdTrain : MODE_;
+  extern __shared__ __attribute__((aligned(16))) char smem[];       // 4 x 32 KB weight tiles | 4 KB b1 | 4 x 2 KB
+  float* const s_b1 = reinterpret_cast<float*>(smem + kBufs * kTileBytes);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, h = lane >> 5;
-  const long long tok = (long long)blockIdx.x * (WAVES * 32) + wave * 32 + r;
+  const long long tok0 = (long long)blockIdx.x * (kWaves * 32) + wave * 32;
+  const long long tok = tok0 + r;
   const bool live = tok < a.T;
   const long long tk = live ? tok : a.T - 1;
+  const unsigned lds0 = lds_offset(smem) + lane * 16;
 
-  auto stage = [&](int ht, int buf) {
+  auto stage = [&](int ht) {
     const char* src = reinterpret_cast<const char*>(a.wp) + (size_t)ht * kTileBytes;
-    char* dst = smem + buf * kTileBytes;
+    char* dst = smem + (ht % kBufs) * kTileBytes;
 #pragma unroll
-    for (int p = 0; p < 32 / WAVES; ++p) {
-      const int blk = p * WAVES + wave;                              // 1 KB per wave instruction
+    for (int p = 0; p < 32 / kWaves; ++p) {
+      const int blk = p * kWaves + wave;                             // 1 KB per wave instruction
       __builtin_amdgcn_global_load_lds(
-          reinterpret_cast<const __attribute__((address_space(1))) void*>(src + blk * 1024 + lane * 16),
-          reinterpret_cast<__attribute__((address_space(3))) void*>(dst + blk * 1024), 16, 0, 0);
+          (const __attribute__((address_space(1))) void*)(src + blk * 1024 + lane * 16),
+          (__attribute__((address_space(3))) void*)(dst + blk * 1024), 16, 0, 0);
     }
   };
 
-  stage(0, 0);
+  stage(0);
+  stage(1);
   if (MODE != kBwd)
-    for (int i = threadIdx.x; i < kF; i += WAVES * 64) s_b1[i] = (float)a.b1[i];
+    for (int i = threadIdx.x; i < kF; i += kWaves * 64) s_b1[i] = (float)a.b1[i];
 
   bf16x8 xf[16];                                                     // this lane's half row: k = 128 h + 8 s + j
   {
@@ -146,74 +200,202 @@ __global__ __launch_bounds__(WAVES * 64) void ffn_fused_kernel(const FfnArgs a) 
     for (int i = 0; i < 16; ++i) yacc[ot][i] = 0.f;
 
   unsigned long long offset = 0;
-  if (MODE == kFwdTrain) offset = a.offset + (a.epoch ? *a.epoch : 0ull);
+  constexpr bool drop = MODE_ == kFwdTrainDrop;
+  if (drop) offset = a.offset + (a.epoch ? *a.epoch : 0ull);
+  const long long hrow = tk * kF + 16 * h;                           // + 32 ht: this lane's 16 hidden units of a tile
+
+  // H / g1 tiles ([32 tokens, 32 hidden] per wave and iteration) cross HBM as whole 64-byte rows: in the MFMA layout
+  // a lane owns 2 x 16 bytes of ONE token, so a store instruction would touch 64 different rows 16 bytes at a time
+  // (request-bound: +34 us per launch measured).  A 2 KB per-wave LDS scratch turns the tile: in "memory order" lane
+  // l of instruction i covers bytes 16 (l & 3) .. of token 16 i + (l >> 2), four lanes per row.  Slot rotation
+  // (j + (token >> 2)) & 3 keeps both the b128 writes and the b128 reads conflict-free.
+  const unsigned scr = lds_offset(smem) + kBufs * kTileBytes + kF * 4 + wave * 2048;
+  const unsigned scr_mfma0 = scr + r * 64 + (((2 * h + 0) + (r >> 2)) & 3) * 16;       // chunk 2h of token r
+  const unsigned scr_mfma1 = scr + r * 64 + (((2 * h + 1) + (r >> 2)) & 3) * 16;       // chunk 2h + 1
+  const int mt = lane >> 2, mj = lane & 3;                           // memory order: token 16 i + mt, chunk mj
+  const unsigned scr_mem0 = scr + mt * 64 + ((mj + (mt >> 2)) & 3) * 16;
+  const unsigned scr_mem1 = scr + (16 + mt) * 64 + ((mj + ((16 + mt) >> 2)) & 3) * 16;
+  const long long mtok0 = tok0 + mt, mtok1 = tok0 + 16 + mt;
+  const bool mlive0 = mtok0 < a.T, mlive1 = mtok1 < a.T;
+  const unsigned long long mmask0 = __builtin_amdgcn_ballot_w64(mlive0), mmask1 = __builtin_amdgcn_ballot_w64(mlive1);
+  const long long mrow0 = (mlive0 ? mtok0 : a.T - 1) * kF + 8 * mj, mrow1 = (mlive1 ? mtok1 : a.T - 1) * kF + 8 * mj;
+  const bool wave_full = tok0 + 32 <= a.T;                            // wave-uniform: every store below is issued
+
+  // backward: H tiles in flight in memory order (tile c is needed at iteration c, loaded at iteration c - 2)
+  bf16x8 hraw[3][2];
+  if (MODE == kBwd) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      hraw[t][0] = gload16(a.h_in + mrow0 + 32 * t);
+      hraw[t][1] = gload16(a.h_in + mrow1 + 32 * t);
+    }
+  }
+  vm_wait_all();
+  if (MODE == kBwd) asm volatile("" : "+v"(hraw[0][0]), "+v"(hraw[0][1]), "+v"(hraw[1][0]), "+v"(hraw[1][1]));
   __syncthreads();
 
-  for (int ht = 0; ht < kTiles; ++ht) {
-    if (ht + 1 < kTiles) stage(ht + 1, (ht + 1) & 1);
-    const char* wb = smem + (ht & 1) * kTileBytes + lane * 16;
-    const long long hoff = tk * kF + 32 * ht + 16 * h;               // this lane's 16 hidden units of the tile
-
-    bf16x8 hin[2];
-    if (MODE == kBwd) {
-      hin[0] = *reinterpret_cast<const bf16x8*>(a.h_in + hoff);
-      hin[1] = *reinterpret_cast<const bf16x8*>(a.h_in + hoff + 8);
-    }
-    f32x16 acc;
-    if (MODE != kBwd) {
-      const f32x4* bp = reinterpret_cast<const f32x4*>(s_b1 + 32 * ht + 16 * h);
+  bf16x8 fr[kRing];                                                  // A fragments in flight, slot = position % kRing
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 b = bp[g];
-        acc[4 * g] = b.x; acc[4 * g + 1] = b.y; acc[4 * g + 2] = b.z; acc[4 * g + 3] = b.w;
+  for (int i = 0; i < kRing; ++i) fr[i] = frag_read(lds0, i * 1024);
+  bf16x8 hp[2];                                                      // processed tile c - 1: B operand of GEMM-2
+  hp[0] = hp[1] = bf16x8{};
+
+  auto iteration = [&](auto kind_tag, auto phase_tag, const int c) {
+    constexpr int KIND = decltype(kind_tag)::value;
+    constexpr int PH = decltype(phase_tag)::value;                   // c % 3 (backward: which hin set holds tile c)
+    constexpr bool G1 = KIND != kLast, G2 = KIND != kFirst;
+    constexpr bool NEXT_G1 = KIND == kFirst || KIND == kMid;
+    constexpr int P_END = (G1 ? 16 : 0) + (G2 ? 16 : 0);
+
+    // ---- everything this wave put in flight one iteration ago has landed; then all waves agree
+    // The youngest memory instructions of iteration c - 1 (two H / g1 stores; in the backward also the two H loads
+    // issued before them) may stay in flight.  Edge iterations and waves with dead tokens issue fewer: wait for all.
+    const bool steady = KIND == kMid && c >= 2 && wave_full;
+    if (MODE == kFwdEval || !steady) vm_wait_all();
+    else if (MODE == kFwdTrain) vm_wait_but2();
+    else vm_wait_but4();
+    __builtin_amdgcn_s_barrier();
+#ifndef DSKD_FFN_EXPERIMENT_NOSTAGE
+    if (c + 2 < kTiles) stage(c + 2);
+#endif
+    bf16x8 st[2], hin[2];
+    if (G2 && MODE != kFwdEval) {                                    // tile c - 1 (written to the scratch last iteration)
+      st[0] = frag_read(scr_mem0, 0);
+      st[1] = frag_read(scr_mem1, 0);
+    }
+    if (MODE == kBwd && G1) {                                        // tile c landed two waits ago: memory -> MFMA order
+      asm volatile("" : "+v"(hraw[PH][0]), "+v"(hraw[PH][1]));
+      lds_write16(scr_mem0, hraw[PH][0]);
+      lds_write16(scr_mem1, hraw[PH][1]);
+      hin[0] = frag_read(scr_mfma0, 0);
+      hin[1] = frag_read(scr_mfma1, 0);
+    }
+    if (MODE == kBwd && c + 2 < kTiles) {
+      hraw[(PH + 2) % 3][0] = gload16(a.h_in + mrow0 + 32 * (c + 2));
+      hraw[(PH + 2) % 3][1] = gload16(a.h_in + mrow1 + 32 * (c + 2));
+    }
+
+    const unsigned w1 = lds0 + (c % kBufs) * kTileBytes;                        // GEMM-1 fragments of tile c
+    const unsigned w2 = lds0 + ((c + kBufs - 1) % kBufs) * kTileBytes + 16384;  // GEMM-2 fragments of tile c - 1
+    const unsigned wn = NEXT_G1 ? lds0 + ((c + 1) % kBufs) * kTileBytes : w1 + 16384;   // head of the next iteration
+    auto read_ahead = [&](int p) -> bf16x8 {                         // stream position p of this iteration (constant)
+#ifdef DSKD_FFN_EXPERIMENT_NOREAD
+      return fr[p % kRing];
+#endif
+      if (p < P_END) return (G1 && p < 16) ? frag_read(w1, p * 1024) : frag_read(w2, (p - (G1 ? 16 : 0)) * 1024);
+      return frag_read(wn, (p - P_END) * 1024);
+    };
+
+    f32x16 acc;
+    f32x4 bias[4];
+    u32x4 rnd[2];
+    if (G1) {
+      if (MODE != kBwd) {
+        const unsigned bl = lds_offset(s_b1) + (32 * c + 16 * h) * 4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bias[g]) : "v"(bl), "n"(g * 16));
       }
-    } else {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    }
+      unsigned c0[2], c1[2], c2[2], c3[2], k0 = (unsigned)a.seed, k1 = (unsigned)(a.seed >> 32);
+      if (drop) {
+        const unsigned long long idx = (unsigned long long)((hrow + 32 * c) >> 3);
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const bf16x8 wa = *reinterpret_cast<const bf16x8*>(wb + s * 1024);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xf[s], acc, 0, 0, 0);
+        for (int q = 0; q < 2; ++q) {
+          c0[q] = (unsigned)(idx + q); c1[q] = (unsigned)((idx + q) >> 32);
+          c2[q] = (unsigned)offset; c3[q] = (unsigned)(offset >> 32);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        frag_wait(fr[s % kRing], kRing - 1);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[s % kRing], xf[s], acc, 0, 0, 0);
+        fr[s % kRing] = read_ahead(s + kRing);
+        if (drop && s < 10) {                                        // one Philox round per MFMA slot
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0[q];
+            const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2[q];
+            const unsigned n0 = (unsigned)(p1 >> 32) ^ c1[q] ^ k0, n2 = (unsigned)(p0 >> 32) ^ c3[q] ^ k1;
+            c1[q] = (unsigned)p1; c3[q] = (unsigned)p0; c0[q] = n0; c2[q] = n2;
+          }
+          k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        }
+      }
+      if (drop) {
+        rnd[0] = u32x4{c0[0], c1[0], c2[0], c3[0]};
+        rnd[1] = u32x4{c0[1], c1[1], c2[1], c3[1]};
+      }
+      if (MODE != kBwd)                                               // the bias reads are older than the ring's 8
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(bias[0]), "+v"(bias[1]), "+v"(bias[2]), "+v"(bias[3]) : "n"(kRing < 15 ? kRing : 15));
+      else
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(hin[0]), "+v"(hin[1]) : "n"(kRing < 15 ? kRing : 15));
+    }
+    if (G2 && MODE != kFwdEval) {                                    // H (forward) / g1 (backward) of tile c - 1, whole rows
+      // behind GEMM-1 the two reads are older than the ring's kRing; the last iteration has no GEMM-1 in between
+      asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(st[0]), "+v"(st[1]) : "n"(!G1 ? 0 : kRing < 15 ? kRing : 15));
+      gstore16_masked(a.h_out + mrow0 + 32 * (c - 1), st[0], mmask0);
+      gstore16_masked(a.h_out + mrow1 + 32 * (c - 1), st[1], mmask1);
     }
 
-    bf16x8 hp[2];
-    if (MODE == kBwd) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
+    // elementwise step of tile c, one accumulator register at a time
+    bf16x8 hc[2];
+    auto element = [&](int i) {
+      float v = acc[i];
+      if (MODE == kBwd) {
         const float hv = (float)hin[i >> 3][i & 7];
-        hp[i >> 3][i & 7] = (__bf16)(hv != 0.f ? acc[i] * a.scale : 0.f);
-      }
-    } else if (MODE == kFwdTrain && a.thresh16) {
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const u32x4 rnd = philox8((unsigned long long)(hoff >> 3) + half, a.seed, offset);
-        const unsigned w[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const unsigned field = (w[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
-          const float v = fmaxf(acc[8 * half + k], 0.f);
-          hp[half][k] = (__bf16)(field < a.thresh16 ? 0.f : v * a.scale);
+        v = hv != 0.f ? v * a.scale : 0.f;
+      } else {
+        v = fmaxf(v + bias[i >> 2][i & 3], 0.f);
+        if (drop) {
+          const unsigned w = rnd[i >> 3][(i & 7) >> 1];
+          const unsigned field = (i & 1) ? (w >> 16) : (w & 0xFFFFu);
+          v = field < a.thresh16 ? 0.f : v * a.scale;
         }
+      }
+      hc[i >> 3][i & 7] = (__bf16)v;
+    };
+
+    if (G2) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int p = (G1 ? 16 : 0) + j;
+        frag_wait(fr[p % kRing], (KIND == kLast && P_END - 1 - p < kRing - 1) ? P_END - 1 - p : kRing - 1);
+        yacc[j >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[p % kRing], hp[j & 1], yacc[j >> 1], 0, 0, 0);
+        if (KIND != kLast || p + kRing < P_END) fr[p % kRing] = read_ahead(p + kRing);
+#ifndef DSKD_FFN_EXPERIMENT_NOEPI
+        if (G1 && j >= 2 && j < 10) {                                 // GEMM-1's result is ready two MFMAs later
+          element(2 * (j - 2));
+          element(2 * (j - 2) + 1);
+        }
+#endif
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) hp[i >> 3][i & 7] = (__bf16)fmaxf(acc[i], 0.f);
+      for (int i = 0; i < 16; ++i) element(i);
     }
-    if (MODE != kFwdEval && live) {
-      *reinterpret_cast<bf16x8*>(a.h_out + hoff) = hp[0];
-      *reinterpret_cast<bf16x8*>(a.h_out + hoff + 8) = hp[1];
-    }
-
-#pragma unroll
-    for (int ot = 0; ot < 8; ++ot)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const bf16x8 wa = *reinterpret_cast<const bf16x8*>(wb + 16384 + (ot * 2 + s) * 1024);
-        yacc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, hp[s], yacc[ot], 0, 0, 0);
+#ifdef DSKD_FFN_EXPERIMENT_NOEPI
+    if (G1 && G2) { hc[0] = xf[c & 15]; hc[1] = xf[(c + 1) & 15]; }
+#endif
+    if (G1) {
+      hp[0] = hc[0];
+      hp[1] = hc[1];
+      if (MODE != kFwdEval) {                                         // MFMA -> memory order, read back next iteration
+        lds_write16(scr_mfma0, hc[0]);
+        lds_write16(scr_mfma1, hc[1]);
       }
-    __syncthreads();
+    }
+  };
+
+  iteration(IntTag<kFirst>{}, IntTag<0>{}, 0);
+  for (int c = 1; c + 2 <= kTiles - 2; c += 3) {                      // c = 1 .. 30
+    iteration(IntTag<kMid>{}, IntTag<1>{}, c);
+    iteration(IntTag<kMid>{}, IntTag<2>{}, c + 1);
+    iteration(IntTag<kMid>{}, IntTag<0>{}, c + 2);
   }
+  iteration(IntTag<kMidBeforeLast>{}, IntTag<(kTiles - 1) % 3>{}, kTiles - 1);
+  iteration(IntTag<kLast>{}, IntTag<kTiles % 3>{}, kTiles);
 
   if (live) {
     __bf16* orow = a.out + tok * kD + 16 * h;
@@ -232,31 +414,31 @@ __global__ __launch_bounds__(WAVES * 64) void ffn_fused_kernel(const FfnArgs a) 
   }
 }
 
-int ffn_waves() {
-  static const int w = [] {
-    const char* e = getenv("DSKD_FFN_WAVES");
-    const int v = e ? atoi(e) : 4;
-    return v == 8 ? 8 : 4;
+constexpr size_t kFfnLds = kBufs * kTileBytes + kF * sizeof(float) + kWaves * 2048;
+
+// 140 KB of dynamic LDS needs the attribute on every instantiation; set once, outside any stream capture window the
+// first launch may be in.
+hipError_t ffn_attributes() {
+  static const hipError_t e = [] {
+    const void* fns[] = {reinterpret_cast<const void*>(&ffn_fused_kernel<kFwdTrain>),
+                         reinterpret_cast<const void*>(&ffn_fused_kernel<kFwdEval>),
+                         reinterpret_cast<const void*>(&ffn_fused_kernel<kBwd>),
+                         reinterpret_cast<const void*>(&ffn_fused_kernel<kFwdTrainDrop>)};
+    for (const void* f : fns) {
+      const hipError_t r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfnLds);
+      if (r != hipSuccess) return r;
+    }
+    return hipSuccess;
   }();
-  return w;
+  return e;
 }
 
 template <int MODE>
 int launch_ffn(const FfnArgs& a, hipStream_t st) {
-  const size_t lds = 2 * kTileBytes + kF * sizeof(float);
-  if (ffn_waves() == 8) {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_kernel<MODE, 8>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (attr != hipSuccess) return fail(DSKD_ERR_LAUNCH, "dskd_ffn: LDS attribute: %s", hipGetErrorString(attr));
-    const long long grid = (a.T + 255) / 256;
-    hipLaunchKernelGGL((ffn_fused_kernel<MODE, 8>), dim3((unsigned)grid), dim3(512), lds, st, a);
-  } else {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_kernel<MODE, 4>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (attr != hipSuccess) return fail(DSKD_ERR_LAUNCH, "dskd_ffn: LDS attribute: %s", hipGetErrorString(attr));
-    const long long grid = (a.T + 127) / 128;
-    hipLaunchKernelGGL((ffn_fused_kernel<MODE, 4>), dim3((unsigned)grid), dim3(256), lds, st, a);
-  }
+  const hipError_t attr = ffn_attributes();
+  if (attr != hipSuccess) return fail(DSKD_ERR_LAUNCH, "dskd_ffn: LDS attribute: %s", hipGetErrorString(attr));
+  const long long grid = (a.T + kWaves * 32 - 1) / (kWaves * 32);
+  hipLaunchKernelGGL((ffn_fused_kernel<MODE>), dim3((unsigned)grid), dim3(kWaves * 64), kFfnLds, st, a);
   return check_launch("dskd_ffn");
 }
 
@@ -268,7 +450,10 @@ bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) !=
 using namespace dskd;
 
 extern "C" int64_t dskd_ffn_packed_bytes(int d_model, int hidden) {
-  if (d_model != kD || hidden != kF) return fail(DSKD_ERR_INVALID_ARG, "dskd_ffn: d_model 256 / hidden 1024 only (got %d / %d)", d_model, hidden) < 0 ? -1 : -1;
+  if (d_model != kD || hidden != kF) {
+    fail(DSKD_ERR_INVALID_ARG, "dskd_ffn_packed_bytes: d_model 256 / hidden 1024 only (got %d / %d)", d_model, hidden);
+    return -1;
+  }
   return (int64_t)kTiles * kTileBytes;
 }
 
@@ -280,6 +465,7 @@ extern "C" int dskd_ffn_pack(const void* w1, const void* w2, void* packed_fwd, v
   if (!w1 || !w2 || (!packed_fwd && !packed_bwd)) return fail(DSKD_ERR_INVALID_ARG, "dskd_ffn_pack: null pointer");
   if (misaligned(w1) || misaligned(w2) || misaligned(packed_fwd) || misaligned(packed_bwd))
     return fail(DSKD_ERR_INVALID_ARG, "dskd_ffn_pack: pointers must be 16-byte aligned");
+  (void)ffn_attributes();
   hipLaunchKernelGGL(ffn_pack_kernel, dim3(kTiles * kFragsPerTile / 256, 2), dim3(256), 0, (hipStream_t)stream,
                      (const __bf16*)w1, (const __bf16*)w2, (__bf16*)packed_fwd, (__bf16*)packed_bwd);
   return check_launch("dskd_ffn_pack");
@@ -304,7 +490,8 @@ extern "C" int dskd_ffn_fwd(const void* x, const void* packed_fwd, const void* b
   const unsigned t = (unsigned)((double)p * 65536.0 + 0.5);
   a.thresh16 = p > 0.f ? (t < 1 ? 1u : t) : 0u;
   a.seed = seed; a.offset = offset; a.epoch = reinterpret_cast<const unsigned long long*>(epoch);
-  return h_out ? launch_ffn<kFwdTrain>(a, (hipStream_t)stream) : launch_ffn<kFwdEval>(a, (hipStream_t)stream);
+  if (!h_out) return launch_ffn<kFwdEval>(a, (hipStream_t)stream);
+  return a.thresh16 ? launch_ffn<kFwdTrainDrop>(a, (hipStream_t)stream) : launch_ffn<kFwdTrain>(a, (hipStream_t)stream);
 }
 
 extern "C" int dskd_ffn_bwd(const void* grad_y, const void* h, const void* packed_bwd, void* grad_h, void* grad_x,

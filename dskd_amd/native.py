@@ -41,6 +41,10 @@ _SIGNATURES = {
     "dskd_dropout_fwd": (C.c_int, [_vp, _i64, _f32, C.c_uint64, C.c_uint64, _vp, C.c_int, _vp]),
     "dskd_relu_dropout_bwd": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _i64, C.c_int, _f32, C.c_int, _vp]),
     "dskd_colsum": (C.c_int, [_vp, _vp, C.c_int, _i64, C.c_int, C.c_int, _vp]),
+    "dskd_ffn_packed_bytes": (_i64, [C.c_int, C.c_int]),
+    "dskd_ffn_pack": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "dskd_ffn_fwd": (C.c_int, [_vp] * 6 + [_i64, C.c_int, C.c_int, _f32, C.c_uint64, C.c_uint64, _vp, C.c_int, _vp]),
+    "dskd_ffn_bwd": (C.c_int, [_vp] * 5 + [_i64, C.c_int, C.c_int, _f32, C.c_int, _vp]),
     "dskd_lsap_host": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "dskd_lsap_batched": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "dskd_match_cost": (C.c_int, [_vp] * 7 + [C.c_int] * 3 + [_f32] * 3 + [_vp]),
@@ -499,6 +503,62 @@ def relu_dropout_bwd(g: torch.Tensor, y_dropped: torch.Tensor, p: float, want_co
     if colsum is not None:
         colsum = colsum.sum(0) if copies > 1 else colsum[0]
     return out, colsum
+
+
+FFN_FUSED_DIMS = (256, 1024)      # (d_model, hidden) the MFMA kernels of csrc/ffn_mfma.hip are built for
+
+
+def ffn_pack(w1: torch.Tensor, w2: torch.Tensor, want_bwd: bool = True):
+    """MFMA fragment-order images of the FFN weights (w1 [hidden, d], w2 [d, hidden], bf16, contiguous): the forward
+    image and, with ``want_bwd``, the backward (transposed) one.  Valid until the weights change."""
+    _need_gpu(w1, w2)
+    if w1.dtype != torch.bfloat16 or w2.dtype != torch.bfloat16 or not (w1.is_contiguous() and w2.is_contiguous()):
+        raise NativeError("ffn_pack: contiguous bf16 weights expected")
+    hidden, d = w1.shape
+    if tuple(w2.shape) != (d, hidden):
+        raise NativeError(f"ffn_pack: w2 {tuple(w2.shape)} does not match w1 {tuple(w1.shape)}")
+    nbytes = load().dskd_ffn_packed_bytes(d, hidden)
+    if nbytes < 0:
+        _check(-1, "dskd_ffn_packed_bytes")
+    fwd = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w1.device)
+    bwd = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w1.device) if want_bwd else None
+    rc = load().dskd_ffn_pack(w1.data_ptr(), w2.data_ptr(), fwd.data_ptr(), None if bwd is None else bwd.data_ptr(),
+                              d, hidden, DTYPE_BF16, _stream(w1))
+    _check(rc, "dskd_ffn_pack")
+    return fwd, bwd
+
+
+def ffn_fwd_raw(x: torch.Tensor, packed_fwd: torch.Tensor, b1: torch.Tensor, b2: torch.Tensor, p: float,
+                store_h: bool, hidden: int = 1024):
+    """``y = dropout_p(relu(x w1^T + b1)) w2^T + b2`` on [tokens, d] bf16 in one MFMA launch; returns (y, H) with
+    H = the dropped hidden activation [tokens, hidden] when ``store_h`` (needed by :func:`ffn_bwd_raw`), else None."""
+    _need_gpu(x, packed_fwd)
+    if x.dtype != torch.bfloat16 or not x.is_contiguous() or x.dim() != 2:
+        raise NativeError("ffn_fwd_raw: contiguous [tokens, d] bf16 input expected")
+    if p > 0 and not store_h:
+        raise NativeError("ffn_fwd_raw: dropout needs store_h")
+    tokens, d = x.shape
+    y = torch.empty_like(x)
+    h = torch.empty((tokens, hidden), dtype=x.dtype, device=x.device) if store_h else None
+    seed, offset = _next_drop_key() if p > 0 else (0, 0)
+    rc = load().dskd_ffn_fwd(x.data_ptr(), packed_fwd.data_ptr(), b1.data_ptr(), b2.data_ptr(),
+                             None if h is None else h.data_ptr(), y.data_ptr(), tokens, d, hidden, p, seed, offset,
+                             dropout_epoch(x.device).data_ptr() if p > 0 else None, DTYPE_BF16, _stream(x))
+    _check(rc, "dskd_ffn_fwd")
+    return y, h
+
+
+def ffn_bwd_raw(grad_y: torch.Tensor, h: torch.Tensor, packed_bwd: torch.Tensor, p: float):
+    """(grad_h, grad_x) of :func:`ffn_fwd_raw` given grad_y [tokens, d] and the stored H: one MFMA launch."""
+    _need_gpu(grad_y, h, packed_bwd)
+    grad_y = grad_y.contiguous()
+    tokens, d = grad_y.shape
+    gh = torch.empty_like(h)
+    gx = torch.empty_like(grad_y)
+    rc = load().dskd_ffn_bwd(grad_y.data_ptr(), h.data_ptr(), packed_bwd.data_ptr(), gh.data_ptr(), gx.data_ptr(),
+                             tokens, d, h.shape[1], p, DTYPE_BF16, _stream(grad_y))
+    _check(rc, "dskd_ffn_bwd")
+    return gh, gx
 
 
 COLSUM_WIDTHS = (256, 384, 512, 1024, 2048)

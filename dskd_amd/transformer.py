@@ -14,6 +14,7 @@ projections are plain ``nn.Linear`` -> hipBLASLt/MFMA (bf16 under autocast).
 """
 import copy
 import math
+import os
 import warnings
 
 import torch
@@ -147,6 +148,85 @@ class _FFNInnerFn(torch.autograd.Function):
         if colsum is not None:
             gb = colsum.to(g.dtype)
         return gx, gw, gb, None, None
+
+
+class _FusedFFNFn(torch.autograd.Function):
+    """``dropout_p(relu(x W1^T + b1)) W2^T + b2`` of a very tall bf16 ``x`` as ONE hand-written MFMA kernel per
+    direction (csrc/ffn_mfma.hip): the 1024-wide hidden activation stays on chip between the two GEMMs; it leaves
+    once (H, for the backward) and its gradient once (for dW1 / db1).  Weight gradients stay split-K library GEMMs
+    over token chunks (see :class:`_TallLinearFn`), bias gradients streaming column sums."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, p, chunk):
+        need_bwd = any(ctx.needs_input_grad[:5])
+        pf, pb = native.ffn_pack(w1, w2, want_bwd=need_bwd)
+        y, h = native.ffn_fwd_raw(x, pf, b1, b2, p, store_h=need_bwd, hidden=w1.shape[0])
+        if need_bwd:
+            ctx.save_for_backward(x, h, pb)
+            ctx.p, ctx.chunk, ctx.dt = p, chunk, w1.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, h, pb = ctx.saved_tensors
+        gy = gy.contiguous()
+        gh, gx = native.ffn_bwd_raw(gy, h, pb, ctx.p)
+        nb = x.shape[0] // ctx.chunk
+        gw1 = gb1 = gw2 = gb2 = None
+        if ctx.needs_input_grad[1]:
+            part = torch.bmm(gh.view(nb, ctx.chunk, -1).transpose(1, 2), x.view(nb, ctx.chunk, -1))
+            gw1 = part.sum(0, dtype=torch.float32).to(ctx.dt)
+        if ctx.needs_input_grad[2]:
+            gb1 = native.colsum(gh).to(ctx.dt)
+        if ctx.needs_input_grad[3]:
+            part = torch.bmm(gy.view(nb, ctx.chunk, -1).transpose(1, 2), h.view(nb, ctx.chunk, -1))
+            gw2 = part.sum(0, dtype=torch.float32).to(ctx.dt)
+        if ctx.needs_input_grad[4]:
+            gb2 = native.colsum(gy).to(ctx.dt)
+        return (gx if ctx.needs_input_grad[0] else None), gw1, gb1, gw2, gb2, None, None
+
+
+_FFN_PACKED = {}
+
+
+def _frozen_packed(w1, w2):
+    """Fragment-order image of FROZEN bf16 FFN weights (the teacher's), packed once per weight version."""
+    key = (w1.data_ptr(), w2.data_ptr())
+    ver = (w1._version, w2._version)
+    hit = _FFN_PACKED.get(key)
+    if hit is None or hit[0] != ver:
+        hit = _FFN_PACKED[key] = (ver, native.ffn_pack(w1, w2, want_bwd=False)[0])
+    return hit[1]
+
+
+def ffn_fused_ok(x, w1, w2, b1, b2):
+    """Can csrc/ffn_mfma.hip take this FFN (tall bf16 CUDA tokens, d_model 256 / hidden 1024, both biases)?"""
+    dev = x.device.type
+    if not x.is_cuda or os.environ.get("DSKD_FFN") == "chain" or b1 is None or b2 is None:
+        return False
+    dtype = torch.get_autocast_dtype(dev) if torch.is_autocast_enabled(dev) else x.dtype
+    tokens = x.numel() // max(x.shape[-1], 1)
+    return dtype == torch.bfloat16 and tokens >= 16384 and (w1.shape[1], w1.shape[0]) == native.FFN_FUSED_DIMS \
+        and tuple(w2.shape) == (w1.shape[1], w1.shape[0]) and x.is_contiguous()
+
+
+def ffn_fused(x, w1, b1, w2, b2, p):
+    """The two Linears of the FFN with ReLU + Dropout(p) between them, fused (see :class:`_FusedFFNFn`)."""
+    dev = x.device.type
+    tokens = x.numel() // x.shape[-1]
+    bf = torch.bfloat16
+    x2 = x.reshape(tokens, x.shape[-1]).to(bf)
+    if torch.is_grad_enabled() and (w1.requires_grad or x.requires_grad):
+        chunk = _token_chunk(tokens, w1.numel())
+        if chunk is None:
+            return None
+        with torch.autocast(dev, enabled=False):
+            y = _FusedFFNFn.apply(x2, w1.to(bf).contiguous(), b1.to(bf), w2.to(bf).contiguous(), b2.to(bf), float(p), chunk)
+    else:
+        w1b, w2b = w1.detach().to(bf).contiguous(), w2.detach().to(bf).contiguous()
+        pf = _frozen_packed(w1b, w2b) if not w1.requires_grad else native.ffn_pack(w1b, w2b, want_bwd=False)[0]
+        y, _ = native.ffn_fwd_raw(x2, pf, b1.detach().to(bf), b2.detach().to(bf), 0.0 if not p else float(p), store_h=bool(p))
+    return y.view(*x.shape[:-1], y.shape[-1])
 
 
 def ffn_inner(x, weight, bias, p):
@@ -622,6 +702,18 @@ class FFN(nn.Module):
         ``Dropout(ffn_drop)`` (the fused encoder path applies it inside the LayerNorm launch)."""
         first = self.layers[0]
         rest = list(self.layers)[1:] if final_dropout else list(self.layers)[1:-1]
+        if self.num_fcs == 2 and isinstance(first[1], nn.ReLU) and isinstance(self.layers[1], nn.Linear):
+            # both Linears + ReLU + Dropout in one MFMA kernel per direction when the shape allows
+            lin2 = self.layers[1]
+            frozen = not first[0].weight.requires_grad
+            lp1 = first[0].frozen_lp(x.device.type) if frozen else first[0].lp()
+            lp2 = lin2.frozen_lp(x.device.type) if frozen else lin2.lp()
+            if lp1 is not None and lp2 is not None and ffn_fused_ok(x, lp1[0], lp2[0], lp1[1], lp2[1]):
+                out = ffn_fused(x, lp1[0], lp1[1], lp2[0], lp2[1], first[2].p if first[2].training else 0.0)
+                if out is not None:
+                    for m in rest[1:]:
+                        out = m(out)
+                    return out
         if self.num_fcs == 2 and isinstance(first[1], nn.ReLU) and first[0].weight.requires_grad:
             # Linear + ReLU as one GEMM with a fused epilogue, then the rest of the stack
             w1, b1 = first[0].lp()

@@ -313,6 +313,33 @@ int dskd_relu_dropout_bwd(const void* g, const void* y_dropped, void* out, float
 int dskd_colsum(const void* x, float* colsum, int copies, int64_t rows, int C, int dtype,
                 void* stream);
 
+/* ---------------------------------------------------------------------------
+ * The encoder FFN as one MFMA kernel per direction (bf16; d_model 256, hidden 1024 -- other sizes are refused and the
+ * caller keeps the GEMM chain).  Replaces, for the tall encoder activation, the reference's
+ *   Linear -> ReLU -> Dropout -> Linear        (ext-mmcv FFN.layers, run by mmdet/models/utils/transformer.py:454-483)
+ * and its autograd backward; the trailing Dropout + residual + LayerNorm stay in dskd_add_ln_fwd.
+ *
+ * dskd_ffn_pack     w1 [hidden, d_model], w2 [d_model, hidden] (nn.Linear layout, device) -> the two weight images
+ *                   in MFMA fragment order, dskd_ffn_packed_bytes() each; packed_bwd may be NULL (inference).
+ *                   Call again whenever the weights change (once per optimiser step).
+ * dskd_ffn_fwd      y = (dropout_p(relu(x w1^T + b1))) w2^T + b2       x, y [tokens, d_model]; b1, b2 bf16
+ *                   h_out [tokens, hidden] receives H = dropout_p(relu(.)) for the backward; NULL (p must be 0) skips it.
+ *                   Dropout mask = that of dskd_dropout_fwd on H (Philox4x32-10(seed, offset + *epoch), not stored).
+ * dskd_ffn_bwd      grad_h = (grad_y w2) * [h != 0] / (1 - p)          [tokens, hidden]  (input of the w1 / b1 gradients)
+ *                   grad_x = grad_h w1                                 [tokens, d_model]
+ *                   The weight gradients are plain GEMMs over the tokens: grad_w2 = grad_y^T h, grad_w1 = grad_h^T x,
+ *                   grad_b1 = dskd_colsum(grad_h), grad_b2 = dskd_colsum(grad_y).
+ * All pointers 16-byte aligned.
+ * ------------------------------------------------------------------------- */
+int64_t dskd_ffn_packed_bytes(int d_model, int hidden);
+int dskd_ffn_pack(const void* w1, const void* w2, void* packed_fwd, void* packed_bwd, int d_model, int hidden,
+                  int dtype, void* stream);
+int dskd_ffn_fwd(const void* x, const void* packed_fwd, const void* b1, const void* b2, void* h_out, void* y,
+                 int64_t tokens, int d_model, int hidden, float p, uint64_t seed, uint64_t offset,
+                 const uint64_t* epoch, int dtype, void* stream);
+int dskd_ffn_bwd(const void* grad_y, const void* h, const void* packed_bwd, void* grad_h, void* grad_x,
+                 int64_t tokens, int d_model, int hidden, float p, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -919,3 +919,115 @@ def test_dskd_losses_ignore_out_of_range_keepid():
                                  L, 1.0)
     torch.cuda.synchronize()
     torch.testing.assert_close(bad, ok, rtol=1e-6, atol=0)
+
+
+# --------------------------------------------------------------------------- fused MFMA FFN (csrc/ffn_mfma.hip)
+def _ffn_inputs(T, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(T, 256, generator=g).bfloat16()
+    w1 = (torch.randn(1024, 256, generator=g) / 16).bfloat16()
+    b1 = (torch.randn(1024, generator=g) * 0.1).bfloat16()
+    w2 = (torch.randn(256, 1024, generator=g) / 32).bfloat16()
+    b2 = (torch.randn(256, generator=g) * 0.1).bfloat16()
+    gy = torch.randn(T, 256, generator=g).bfloat16()
+    return x, w1, b1, w2, b2, gy
+
+
+def _close(a, ref, tol):
+    """max |a - ref| <= tol * max |ref|: bf16 results of f32 accumulations, one rounding (2^-9 relative) per element
+    plus accumulation-order noise; 8e-3 of the largest magnitude is ~4 bf16 ulps there."""
+    return float((a.float().cpu() - ref).abs().max()) <= tol * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("T", [1, 200, 4096 + 37])
+def test_ffn_fused_vs_float_reference(T):
+    """dskd_ffn_fwd / dskd_ffn_bwd without dropout against the FFN chain of the reference (ext-mmcv FFN.layers:
+    Linear -> ReLU -> Dropout -> Linear) evaluated in fp32 on the CPU from the same bf16-rounded inputs; ragged token
+    counts (last workgroup / last wave partly or wholly dead)."""
+    x, w1, b1, w2, b2, gy = _ffn_inputs(T)
+    dx, dgy = x.to(DEV), gy.to(DEV)
+    pf, pb = native.ffn_pack(w1.to(DEV), w2.to(DEV))
+    guard = torch.full((T + 64, 1024), 7.0, dtype=torch.bfloat16, device=DEV)      # rows >= T must stay untouched
+    y, h = native.ffn_fwd_raw(dx, pf, b1.to(DEV), b2.to(DEV), 0.0, True)
+    y_eval, none = native.ffn_fwd_raw(dx, pf, b1.to(DEV), b2.to(DEV), 0.0, False)
+    assert none is None and torch.equal(y_eval, y)
+    href = torch.relu(x.float() @ w1.float().t() + b1.float())
+    assert _close(h, href, 8e-3)
+    assert _close(y, h.float().cpu() @ w2.float().t() + b2.float(), 8e-3)
+    gh, gx = native.ffn_bwd_raw(dgy, h, pb, 0.0)
+    ghref = (gy.float() @ w2.float()) * (h.float().cpu() != 0)
+    assert _close(gh, ghref, 8e-3)
+    assert _close(gx, gh.float().cpu() @ w1.float(), 8e-3)
+    assert bool((gh[h == 0] == 0).all())
+    torch.cuda.synchronize()
+    assert bool((guard == 7.0).all())
+
+
+def test_ffn_fused_dropout_is_the_mask_of_dskd_dropout_fwd():
+    """Training forward: the dropped hidden activation equals the GEMM chain's (addmm + ReLU, then dskd_dropout_fwd
+    under the same key) -- identical zero pattern, values to bf16 rounding (the chain rounds twice) -- the rate is p,
+    and the backward scales the surviving gradients by 1 / (1 - p)."""
+    T, p = 20000 + 11, 0.1
+    x, w1, b1, w2, b2, gy = [t.to(DEV) for t in _ffn_inputs(T, seed=3)]
+    pf, pb = native.ffn_pack(w1, w2)
+    _, h0 = native.ffn_fwd_raw(x, pf, b1, b2, 0.0, True)
+    native._drop_calls = 4321
+    y, h = native.ffn_fwd_raw(x, pf, b1, b2, p, True)
+    chain = torch._addmm_activation(b1, x, w1.t())
+    native._drop_calls = 4321
+    native.dropout_(chain, p)
+    assert torch.equal(h != 0, chain != 0)
+    assert float((h.float() - chain.float()).abs().max()) <= 1.6e-2 * float(chain.float().abs().max())
+    active = h0 != 0
+    rate = float(((h == 0) & active).sum()) / float(active.sum())
+    assert abs(rate - p) < 2e-3
+    kept = h != 0
+    assert float((h.float()[kept] - h0.float()[kept] / (1 - p)).abs().max()) <= 1.6e-2 * float(h0.float().abs().max()) / (1 - p)
+    assert _close(y, h.float().cpu() @ w2.float().cpu().t() + b2.float().cpu(), 8e-3)
+    gh, gx = native.ffn_bwd_raw(gy, h, pb, p)
+    ghref = (gy.float().cpu() @ w2.float().cpu()) * (h.float().cpu() != 0) / (1 - p)
+    assert _close(gh, ghref, 8e-3) and _close(gx, gh.float().cpu() @ w1.float().cpu(), 8e-3)
+    native.advance_dropout_epoch(DEV)                                   # what a graph replay does between steps
+    native._drop_calls = 4321
+    _, h2 = native.ffn_fwd_raw(x, pf, b1, b2, p, True)
+    assert not torch.equal(h2 != 0, h != 0)
+
+
+def test_ffn_fused_refuses_other_sizes():
+    w1 = torch.zeros(512, 256, dtype=torch.bfloat16, device=DEV)
+    w2 = torch.zeros(256, 512, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(native.NativeError):
+        native.ffn_pack(w1, w2)
+    x, w1, b1, w2, b2, _ = [t.to(DEV) for t in _ffn_inputs(8)]
+    pf, _ = native.ffn_pack(w1, w2, want_bwd=False)
+    with pytest.raises(native.NativeError):
+        native.ffn_fwd_raw(x, pf, b1, b2, 0.1, False)                   # dropout without H: the backward could not see the mask
+
+
+def test_ffn_module_fused_equals_gemm_chain(monkeypatch):
+    """transformer.FFN on a tall bf16 activation: the fused MFMA path (default) against the library GEMM chain
+    (DSKD_FFN=chain) -- output, input gradient and all four parameter gradients, dropout off."""
+    from dskd_amd.transformer import FFN
+    torch.manual_seed(1)
+    ffn = FFN(256, 1024, ffn_drop=0.0).to(DEV)
+    x = torch.randn(2, 9000, 256, device=DEV)
+    up = torch.randn(2, 9000, 256, device=DEV)
+    res = {}
+    for mode in ("fused", "chain"):
+        if mode == "chain":
+            monkeypatch.setenv("DSKD_FFN", "chain")
+        xi = x.clone().requires_grad_(True)
+        for q in ffn.parameters():
+            q.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = ffn.core(xi, final_dropout=False)
+        out.float().mul(up).sum().backward()
+        res[mode] = [out.float(), xi.grad.float()] + [q.grad.float().clone() for q in ffn.parameters()]
+    assert res["fused"][0].shape == (2, 9000, 256)
+    names = ["out", "dx"] + [n for n, _ in ffn.named_parameters()]
+    for n, a, b in zip(names, res["fused"], res["chain"]):
+        err = float((a - b).abs().max()) / max(float(b.abs().max()), 1e-6)
+        assert err < 2e-2, (n, err)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        monkeypatch.delenv("DSKD_FFN")
+        assert float((ffn.core(x, final_dropout=False).float() - res["fused"][0]).abs().max()) <= 2e-2 * float(res["fused"][0].abs().max())
