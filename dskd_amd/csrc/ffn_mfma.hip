@@ -109,6 +109,14 @@ __device__ __forceinline__ unsigned lds_offset(const void* p) {
   return (unsigned)(unsigned long)((const __attribute__((address_space(3))) char*)p);
 }
 
+// Sum over the 32 lanes of a wave half (= the 32 tokens of the wave, for one accumulator register); the result is valid
+// in lanes 16..31 and 48..63.  DPP only: no LDS crossbar instruction, nothing for the counted waits to trip over.
+__device__ __forceinline__ float half_wave_sum(float v) {
+  v = row16_sum(v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
+  return v;                                                          // 0x142 = row_bcast:15 into rows 1 and 3
+}
+
 struct FfnArgs {
   const __bf16* in;      // X (forward) / dY (backward)  [T, 256]
   const __bf16* wp;      // packed weights of this direction [32 tiles][32 KB]
@@ -122,6 +130,8 @@ struct FfnArgs {
   unsigned thresh16;     // drop when the 16-bit field < thresh16 (0: no dropout)
   unsigned long long seed, offset;
   const unsigned long long* epoch;
+  float* colsum;         // backward: [copies, 1024] f32, += column sums of g1 (= grad of b1); may be null
+  int copies;
 };
 
 enum { kFwdTrain = 0, kFwdEval = 1, kBwd = 2, kFwdTrainDrop = 3 };   // kFwdTrain: H stored, p = 0
@@ -135,7 +145,7 @@ __device__ __forceinline__ void vm_wait_all() { asm volatile("s_waitcnt vmcnt(0)
 __device__ __forceinline__ void vm_wait_but2() { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
 __device__ __forceinline__ void vm_wait_but4() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
 __device__ __forceinline__ void lds_write16(unsigned lds_addr, const bf16x8& v) {
-  asm volatile("ds_write_b128 %0, %1" ::"v"(lds_addr), "v"(v) : "memory");
+  asm volatile("ds_write_b128 %0, %1\n\ts_nop 2" ::"v"(lds_addr), "v"(v) : "memory");     // as for gstore16_masked
 }
 __device__ __forceinline__ bf16x8 gload16(const __bf16* p) {
   bf16x8 v;
@@ -147,7 +157,10 @@ __device__ __forceinline__ bf16x8 gload16(const __bf16* p) {
 // s_mov, which leaves SCC alone (the compiler may hold a loop condition there across the asm).
 __device__ __forceinline__ void gstore16_masked(__bf16* p, const bf16x8& v, unsigned long long lanes) {
   unsigned long long saved;
-  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %3\n\tglobal_store_dwordx4 %1, %2, off\n\ts_mov_b64 exec, %0"
+  // s_nop: a store of more than 64 bits reads its data registers over several cycles, and the compiler, which pads
+  // nothing around asm, may overwrite them in the very next instruction (seen: the last lanes' fourth dword lost).
+  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %3\n\tglobal_store_dwordx4 %1, %2, off\n\ts_nop 2\n\t"
+               "s_mov_b64 exec, %0"
                : "=&s"(saved) : "v"(p), "v"(v), "s"(lanes) : "memory");
 }
 
@@ -159,7 +172,7 @@ __device__ __forceinline__ void gstore16_masked(__bf16* p, const bf16x8& v, unsi
 template <int MODE_>
 __global__ __launch_bounds__(kWaves * 64) void ffn_fused_kernel(const FfnArgs a) {
   constexpr int MODE = MODE_ == kFwdTrainDrop ? kFwdTrain : MODE_;
-  extern __shared__ __attribute__((aligned(16))) char smem[];       // 4 x 32 KB weight tiles | 4 KB b1 | 4 x 2 KB
+  extern __shared__ __attribute__((aligned(16))) char smem[];       // 4 x 32 KB weight tiles | 4 KB b1 | 4 x 2 KB turn scratch | 4 x 4 KB column sums
   float* const s_b1 = reinterpret_cast<float*>(smem + kBufs * kTileBytes);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -220,6 +233,11 @@ __global__ __launch_bounds__(kWaves * 64) void ffn_fused_kernel(const FfnArgs a)
   const unsigned long long mmask0 = __builtin_amdgcn_ballot_w64(mlive0), mmask1 = __builtin_amdgcn_ballot_w64(mlive1);
   const long long mrow0 = (mlive0 ? mtok0 : a.T - 1) * kF + 8 * mj, mrow1 = (mlive1 ? mtok1 : a.T - 1) * kF + 8 * mj;
   const bool wave_full = tok0 + 32 <= a.T;                            // wave-uniform: every store below is issued
+  // backward, grad of b1: per-wave row of 1024 column sums (each hidden unit is written once per tile loop)
+  const unsigned csrow = lds_offset(smem) + kBufs * kTileBytes + kF * 4 + kWaves * 2048 + wave * (kF * 4) + 16 * h * 4;
+  float gs_prev[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) gs_prev[i] = 0.f;
 
   // backward: H tiles in flight in memory order (tile c is needed at iteration c, loaded at iteration c - 2)
   bf16x8 hraw[3][2];
@@ -312,6 +330,9 @@ __global__ __launch_bounds__(kWaves * 64) void ffn_fused_kernel(const FfnArgs a)
         frag_wait(fr[s % kRing], kRing - 1);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[s % kRing], xf[s], acc, 0, 0, 0);
         fr[s % kRing] = read_ahead(s + kRing);
+        if (MODE == kBwd && G2) gs_prev[s] = half_wave_sum(gs_prev[s]);   // column sums of tile c - 1 (96 vector
+                                                                          // instructions; pinning them to the MFMA slots
+                                                                          // with sched_barrier measured 3 % slower)
         if (drop && s < 10) {                                        // one Philox round per MFMA slot
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
@@ -339,6 +360,23 @@ __global__ __launch_bounds__(kWaves * 64) void ffn_fused_kernel(const FfnArgs a)
       gstore16_masked(a.h_out + mrow1 + 32 * (c - 1), st[1], mmask1);
     }
 
+    if (MODE == kBwd && G2) {
+      if (!G1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gs_prev[i] = half_wave_sum(gs_prev[i]);
+      }
+      {                                                               // lanes 16 and 48 hold the totals of h = 0 / 1
+        unsigned long long saved;
+        const f32x4 q0 = {gs_prev[0], gs_prev[1], gs_prev[2], gs_prev[3]}, q1 = {gs_prev[4], gs_prev[5], gs_prev[6], gs_prev[7]};
+        const f32x4 q2 = {gs_prev[8], gs_prev[9], gs_prev[10], gs_prev[11]}, q3 = {gs_prev[12], gs_prev[13], gs_prev[14], gs_prev[15]};
+        const unsigned dst = csrow + 32 * (c - 1) * 4;
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %6\n\t"
+                     "ds_write_b128 %1, %2\n\tds_write_b128 %1, %3 offset:16\n\t"
+                     "ds_write_b128 %1, %4 offset:32\n\tds_write_b128 %1, %5 offset:48\n\ts_nop 2\n\ts_mov_b64 exec, %0"
+                     : "=&s"(saved) : "v"(dst), "v"(q0), "v"(q1), "v"(q2), "v"(q3), "s"(0x0001000000010000ull) : "memory");
+      }
+    }
+
     // elementwise step of tile c, one accumulator register at a time
     bf16x8 hc[2];
     auto element = [&](int i) {
@@ -346,6 +384,7 @@ __global__ __launch_bounds__(kWaves * 64) void ffn_fused_kernel(const FfnArgs a)
       if (MODE == kBwd) {
         const float hv = (float)hin[i >> 3][i & 7];
         v = hv != 0.f ? v * a.scale : 0.f;
+        gs_prev[i] = live ? v : 0.f;                                  // read (as tile c - 1) in the next iteration
       } else {
         v = fmaxf(v + bias[i >> 2][i & 3], 0.f);
         if (drop) {
@@ -397,6 +436,23 @@ __global__ __launch_bounds__(kWaves * 64) void ffn_fused_kernel(const FfnArgs a)
   iteration(IntTag<kMidBeforeLast>{}, IntTag<(kTiles - 1) % 3>{}, kTiles - 1);
   iteration(IntTag<kLast>{}, IntTag<kTiles % 3>{}, kTiles);
 
+  if (MODE == kBwd) {                                                 // grad of b1: 4 wave rows -> one atomic per column
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (a.colsum) {
+      const float* rows = reinterpret_cast<const float*>(smem + kBufs * kTileBytes + kF * 4 + kWaves * 2048);
+      float* dst = a.colsum + (size_t)(blockIdx.x % a.copies) * kF;
+#pragma unroll
+      for (int q = 0; q < kF / (kWaves * 64); ++q) {
+        const int col = q * (kWaves * 64) + threadIdx.x;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) t += rows[w * kF + col];
+        atomicAdd(dst + col, t);
+      }
+    }
+  }
+
   if (live) {
     __bf16* orow = a.out + tok * kD + 16 * h;
 #pragma unroll
@@ -414,7 +470,7 @@ __global__ __launch_bounds__(kWaves * 64) void ffn_fused_kernel(const FfnArgs a)
   }
 }
 
-constexpr size_t kFfnLds = kBufs * kTileBytes + kF * sizeof(float) + kWaves * 2048;
+constexpr size_t kFfnLds = kBufs * kTileBytes + kF * sizeof(float) + kWaves * 2048 + kWaves * kF * sizeof(float);   // 156 KB
 
 // 140 KB of dynamic LDS needs the attribute on every instantiation; set once, outside any stream capture window the
 // first launch may be in.
@@ -495,7 +551,8 @@ extern "C" int dskd_ffn_fwd(const void* x, const void* packed_fwd, const void* b
 }
 
 extern "C" int dskd_ffn_bwd(const void* grad_y, const void* h, const void* packed_bwd, void* grad_h, void* grad_x,
-                            int64_t tokens, int d_model, int hidden, float p, int dtype, void* stream) {
+                            float* grad_b1, int copies, int64_t tokens, int d_model, int hidden, float p, int dtype,
+                            void* stream) {
   if (dtype != DSKD_DTYPE_BF16) return fail(DSKD_ERR_INVALID_ARG, "dskd_ffn_bwd: bf16 only");
   if (d_model != kD || hidden != kF)
     return fail(DSKD_ERR_INVALID_ARG, "dskd_ffn_bwd: d_model 256 / hidden 1024 only (got %d / %d)", d_model, hidden);
@@ -504,8 +561,10 @@ extern "C" int dskd_ffn_bwd(const void* grad_y, const void* h, const void* packe
   if (misaligned(grad_y) || misaligned(h) || misaligned(packed_bwd) || misaligned(grad_h) || misaligned(grad_x))
     return fail(DSKD_ERR_INVALID_ARG, "dskd_ffn_bwd: pointers must be 16-byte aligned");
   if (!(p >= 0.f) || p >= 1.f) return fail(DSKD_ERR_INVALID_ARG, "dskd_ffn_bwd: p=%f", p);
+  if (grad_b1 && copies < 1) return fail(DSKD_ERR_INVALID_ARG, "dskd_ffn_bwd: copies < 1");
   if (tokens == 0) return DSKD_OK;
   FfnArgs a{};
+  a.colsum = grad_b1; a.copies = copies;
   a.in = (const __bf16*)grad_y; a.wp = (const __bf16*)packed_bwd; a.h_in = (const __bf16*)h;
   a.h_out = (__bf16*)grad_h; a.out = (__bf16*)grad_x; a.T = tokens; a.scale = 1.0f / (1.0f - p);
   return launch_ffn<kBwd>(a, (hipStream_t)stream);

@@ -44,7 +44,7 @@ _SIGNATURES = {
     "dskd_ffn_packed_bytes": (_i64, [C.c_int, C.c_int]),
     "dskd_ffn_pack": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_ffn_fwd": (C.c_int, [_vp] * 6 + [_i64, C.c_int, C.c_int, _f32, C.c_uint64, C.c_uint64, _vp, C.c_int, _vp]),
-    "dskd_ffn_bwd": (C.c_int, [_vp] * 5 + [_i64, C.c_int, C.c_int, _f32, C.c_int, _vp]),
+    "dskd_ffn_bwd": (C.c_int, [_vp] * 6 + [C.c_int, _i64, C.c_int, C.c_int, _f32, C.c_int, _vp]),
     "dskd_lsap_host": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "dskd_lsap_batched": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "dskd_match_cost": (C.c_int, [_vp] * 7 + [C.c_int] * 3 + [_f32] * 3 + [_vp]),
@@ -548,16 +548,22 @@ def ffn_fwd_raw(x: torch.Tensor, packed_fwd: torch.Tensor, b1: torch.Tensor, b2:
     return y, h
 
 
-def ffn_bwd_raw(grad_y: torch.Tensor, h: torch.Tensor, packed_bwd: torch.Tensor, p: float):
-    """(grad_h, grad_x) of :func:`ffn_fwd_raw` given grad_y [tokens, d] and the stored H: one MFMA launch."""
+def ffn_bwd_raw(grad_y: torch.Tensor, h: torch.Tensor, packed_bwd: torch.Tensor, p: float, want_colsum: bool = False):
+    """(grad_h, grad_x[, column sums of grad_h in f32 = grad of b1]) of :func:`ffn_fwd_raw` given grad_y [tokens, d]
+    and the stored H: one MFMA launch."""
     _need_gpu(grad_y, h, packed_bwd)
     grad_y = grad_y.contiguous()
     tokens, d = grad_y.shape
     gh = torch.empty_like(h)
     gx = torch.empty_like(grad_y)
+    copies = _colsum_copies(tokens)
+    cs = zeros((copies, h.shape[1]), torch.float32, h.device) if want_colsum else None
     rc = load().dskd_ffn_bwd(grad_y.data_ptr(), h.data_ptr(), packed_bwd.data_ptr(), gh.data_ptr(), gx.data_ptr(),
-                             tokens, d, h.shape[1], p, DTYPE_BF16, _stream(grad_y))
+                             None if cs is None else cs.data_ptr(), copies, tokens, d, h.shape[1], p, DTYPE_BF16,
+                             _stream(grad_y))
     _check(rc, "dskd_ffn_bwd")
+    if want_colsum:
+        return gh, gx, (cs.sum(0) if copies > 1 else cs[0])
     return gh, gx
 
 

@@ -170,14 +170,14 @@ class _FusedFFNFn(torch.autograd.Function):
     def backward(ctx, gy):
         x, h, pb = ctx.saved_tensors
         gy = gy.contiguous()
-        gh, gx = native.ffn_bwd_raw(gy, h, pb, ctx.p)
+        gh, gx, cs = native.ffn_bwd_raw(gy, h, pb, ctx.p, want_colsum=True)
         nb = x.shape[0] // ctx.chunk
         gw1 = gb1 = gw2 = gb2 = None
         if ctx.needs_input_grad[1]:
             part = torch.bmm(gh.view(nb, ctx.chunk, -1).transpose(1, 2), x.view(nb, ctx.chunk, -1))
             gw1 = part.sum(0, dtype=torch.float32).to(ctx.dt)
         if ctx.needs_input_grad[2]:
-            gb1 = native.colsum(gh).to(ctx.dt)
+            gb1 = cs.to(ctx.dt)
         if ctx.needs_input_grad[3]:
             part = torch.bmm(gy.view(nb, ctx.chunk, -1).transpose(1, 2), h.view(nb, ctx.chunk, -1))
             gw2 = part.sum(0, dtype=torch.float32).to(ctx.dt)

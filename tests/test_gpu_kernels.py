@@ -954,10 +954,14 @@ def test_ffn_fused_vs_float_reference(T):
     href = torch.relu(x.float() @ w1.float().t() + b1.float())
     assert _close(h, href, 8e-3)
     assert _close(y, h.float().cpu() @ w2.float().t() + b2.float(), 8e-3)
-    gh, gx = native.ffn_bwd_raw(dgy, h, pb, 0.0)
+    gh, gx, cs = native.ffn_bwd_raw(dgy, h, pb, 0.0, want_colsum=True)
     ghref = (gy.float() @ w2.float()) * (h.float().cpu() != 0)
     assert _close(gh, ghref, 8e-3)
     assert _close(gx, gh.float().cpu() @ w1.float(), 8e-3)
+    csref = ghref.sum(0)                                               # grad of b1: f32 sums of the unrounded gradient
+    assert float((cs.cpu() - csref).abs().max()) <= 2e-3 * float(ghref.abs().sum(0).max()) + 1e-6
+    gh2, gx2 = native.ffn_bwd_raw(dgy, h, pb, 0.0)                      # without the column sums: same tensors
+    assert torch.equal(gh2, gh) and torch.equal(gx2, gx)
     assert bool((gh[h == 0] == 0).all())
     torch.cuda.synchronize()
     assert bool((guard == 7.0).all())
