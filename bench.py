@@ -167,7 +167,8 @@ def cpu_baseline(seed, num_prev, batch=1, timed=3):
 
 
 GEMM_CONV_PATTERNS = ("Cijk_", "ck::", "_ZN2ck", "igemm_", "miopen", "MIOpen", "gemm_xdl", "xdlops", "wrw_", "naive_conv",
-                      "attn_fwd", "bwd_kernel_dk_dv", "bwd_kernel_dq")
+                      "attn_fwd", "bwd_kernel_dk_dv", "bwd_kernel_dq", "ffn_fused_kernel")
+OWN_MFMA_KERNEL = "ffn_fused_kernel"      # csrc/ffn_mfma.hip: the hand-written MFMA kernel on the path
 MFMA_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 
 
@@ -181,14 +182,16 @@ def mfma_utilisation(step_fn, dtype):
 
     def addmm_act_flop(self_shape, a_shape, b_shape, *args, out_shape=None, **kwargs):   # bias + [m,k] x [k,n] + activation
         return 2 * a_shape[0] * a_shape[1] * b_shape[1]
+    own0 = native.ffn_flops_launched()
     with FlopCounterMode(display=False, custom_mapping={torch.ops.aten._addmm_activation: addmm_act_flop}) as fc:
         step_fn()
     torch.cuda.synchronize()
-    flops = float(fc.get_total_flops())
+    own_flops = float(native.ffn_flops_launched() - own0)          # the fused FFN launches are not aten ops
+    flops = float(fc.get_total_flops()) + own_flops
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
         step_fn()
         torch.cuda.synchronize()
-    t_us, n, total_us, names = 0.0, 0, 0.0, {}
+    t_us, n, total_us, names, own_us, own_n = 0.0, 0, 0.0, {}, 0.0, 0
     for e in prof.key_averages():
         dt = float(getattr(e, "self_device_time_total", 0.0) or 0.0)
         if dt <= 0 or "Memcpy" in e.key or "Memset" in e.key or e.key.startswith("aten::") or \
@@ -199,17 +202,27 @@ def mfma_utilisation(step_fn, dtype):
             t_us += dt
             n += e.count
             names[e.key[:48]] = names.get(e.key[:48], 0.0) + dt
+            if OWN_MFMA_KERNEL in e.key:
+                own_us += dt
+                own_n += e.count
     if t_us <= 0:
         return None
+    own = None
+    if own_us > 0:
+        own = {"kernel": "dskd::ffn_fused_kernel (csrc/ffn_mfma.hip; forward, training forward, backward)", "launches": own_n,
+               "flops_TFLOP": round(own_flops / 1e12, 3), "kernel_ms": round(own_us / 1e3, 2),
+               "achieved_TFLOPs": round(own_flops / (own_us * 1e-6) / 1e12, 1),
+               "frac": round(own_flops / (own_us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
     top = sorted(names.items(), key=lambda kv: -kv[1])[:4]
     tflops = flops / (t_us * 1e-6) / 1e12
     peak = MFMA_PEAK_TFLOPS if dtype == "bf16" else MFMA_PEAK_TFLOPS / 16      # fp32: no MFMA-rate claim, reported for scale
     return {"flops_per_step": round(flops / 1e12, 3), "unit": "TFLOP", "gemm_conv_kernel_ms": round(t_us / 1e3, 2),
             "gemm_conv_launches": n, "all_kernel_ms": round(total_us / 1e3, 2), "achieved_TFLOPs": round(tflops, 1),
             "peak_TFLOPs": peak, "frac": round(tflops / peak, 4),
-            "counted": "aten mm/addmm/bmm/convolution/sdpa, forward + backward, teacher + student (FlopCounterMode); time "
-                       "= device time of the hipBLASLt / CK / MIOpen / attention kernels in one profiled eager step",
-            "top_kernels_ms": {k: round(v / 1e3, 2) for k, v in top}}
+            "counted": "aten mm/addmm/bmm/convolution/sdpa (FlopCounterMode) + the fused FFN launches (4 * tokens * 256 * 1024 "
+                       "each), forward + backward, teacher + student; time = device time of the hipBLASLt / CK / MIOpen / "
+                       "attention / ffn_fused kernels in one profiled eager step",
+            "top_kernels_ms": {k: round(v / 1e3, 2) for k, v in top}, "hand_written": own}
 
 
 def main():

@@ -109,13 +109,31 @@ __device__ __forceinline__ unsigned lds_offset(const void* p) {
   return (unsigned)(unsigned long)((const __attribute__((address_space(3))) char*)p);
 }
 
-// Sum over the 32 lanes of a wave half (= the 32 tokens of the wave, for one accumulator register); the result is valid
-// in lanes 16..31 and 48..63.  DPP only: no LDS crossbar instruction, nothing for the counted waits to trip over.
-__device__ __forceinline__ float half_wave_sum(float v) {
-  v = row16_sum(v);
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
-  return v;                                                          // 0x142 = row_bcast:15 into rows 1 and 3
+// Sums over the 32 lanes of a wave half (= the 32 tokens of the wave) of 16 registers at once, one DPP step per call
+// (steps 0..4; after step 4 the totals sit in lanes 16..31 and 48..63).  Written as asm: left to the compiler the 80
+// adds are SLP-packed into v_pk_add_f32, which cannot take a DPP operand, and every step becomes v_mov_b32_dpp + add.
+// Sixteen independent registers per block keep dependent DPP reads 16 instructions apart (a DPP read needs two wait
+// states behind the write of its source; s_nop 1 covers the instruction in front of the block).
+#define DSKD_DPP16(CTRL)                                                                                              \
+  asm("s_nop 1\n\t"                                                                                                   \
+      "v_add_f32_dpp %0, %0, %0 " CTRL "\n\tv_add_f32_dpp %1, %1, %1 " CTRL "\n\tv_add_f32_dpp %2, %2, %2 " CTRL "\n\t"  \
+      "v_add_f32_dpp %3, %3, %3 " CTRL "\n\tv_add_f32_dpp %4, %4, %4 " CTRL "\n\tv_add_f32_dpp %5, %5, %5 " CTRL "\n\t"  \
+      "v_add_f32_dpp %6, %6, %6 " CTRL "\n\tv_add_f32_dpp %7, %7, %7 " CTRL "\n\tv_add_f32_dpp %8, %8, %8 " CTRL "\n\t"  \
+      "v_add_f32_dpp %9, %9, %9 " CTRL "\n\tv_add_f32_dpp %10, %10, %10 " CTRL "\n\tv_add_f32_dpp %11, %11, %11 " CTRL "\n\t" \
+      "v_add_f32_dpp %12, %12, %12 " CTRL "\n\tv_add_f32_dpp %13, %13, %13 " CTRL "\n\tv_add_f32_dpp %14, %14, %14 " CTRL "\n\t" \
+      "v_add_f32_dpp %15, %15, %15 " CTRL                                                                            \
+      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),   \
+        "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]))
+__device__ __forceinline__ void half_wave_sum16_step(float (&v)[16], int step) {
+  switch (step) {
+    case 0: DSKD_DPP16("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1"); break;
+    case 1: DSKD_DPP16("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1"); break;
+    case 2: DSKD_DPP16("row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1"); break;
+    case 3: DSKD_DPP16("row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1"); break;
+    default: DSKD_DPP16("row_bcast:15 row_mask:0xa bank_mask:0xf"); break;
+  }
 }
+#undef DSKD_DPP16
 
 struct FfnArgs {
   const __bf16* in;      // X (forward) / dY (backward)  [T, 256]
@@ -238,6 +256,7 @@ __global__ __launch_bounds__(kWaves * 64) void ffn_fused_kernel(const FfnArgs a)
   float gs_prev[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) gs_prev[i] = 0.f;
+  const float lscale = live ? a.scale : 0.f;
 
   // backward: H tiles in flight in memory order (tile c is needed at iteration c, loaded at iteration c - 2)
   bf16x8 hraw[3][2];
@@ -327,18 +346,17 @@ __global__ __launch_bounds__(kWaves * 64) void ffn_fused_kernel(const FfnArgs a)
       }
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
-        frag_wait(fr[s % kRing], kRing - 1);
+        frag_wait(fr[s % kRing], kRing - 1);       // (one wait per TWO fragments measured 3-8 % slower: it halves the ring)
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[s % kRing], xf[s], acc, 0, 0, 0);
         fr[s % kRing] = read_ahead(s + kRing);
-        if (MODE == kBwd && G2) gs_prev[s] = half_wave_sum(gs_prev[s]);   // column sums of tile c - 1 (96 vector
-                                                                          // instructions; pinning them to the MFMA slots
-                                                                          // with sched_barrier measured 3 % slower)
+        if (MODE == kBwd && G2 && s % 3 == 0 && s < 15) half_wave_sum16_step(gs_prev, s / 3);   // column sums, tile c - 1
         if (drop && s < 10) {                                        // one Philox round per MFMA slot
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
             const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0[q];
             const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2[q];
-            const unsigned n0 = (unsigned)(p1 >> 32) ^ c1[q] ^ k0, n2 = (unsigned)(p0 >> 32) ^ c3[q] ^ k1;
+            const unsigned n0 = __builtin_amdgcn_bitop3_b32((unsigned)(p1 >> 32), c1[q], k0, 0x96);   // three-way xor
+            const unsigned n2 = __builtin_amdgcn_bitop3_b32((unsigned)(p0 >> 32), c3[q], k1, 0x96);
             c1[q] = (unsigned)p1; c3[q] = (unsigned)p0; c0[q] = n0; c2[q] = n2;
           }
           k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -363,7 +381,7 @@ __global__ __launch_bounds__(kWaves * 64) void ffn_fused_kernel(const FfnArgs a)
     if (MODE == kBwd && G2) {
       if (!G1) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) gs_prev[i] = half_wave_sum(gs_prev[i]);
+        for (int st5 = 0; st5 < 5; ++st5) half_wave_sum16_step(gs_prev, st5);
       }
       {                                                               // lanes 16 and 48 hold the totals of h = 0 / 1
         unsigned long long saved;
@@ -383,8 +401,8 @@ __global__ __launch_bounds__(kWaves * 64) void ffn_fused_kernel(const FfnArgs a)
       float v = acc[i];
       if (MODE == kBwd) {
         const float hv = (float)hin[i >> 3][i & 7];
-        v = hv != 0.f ? v * a.scale : 0.f;
-        gs_prev[i] = live ? v : 0.f;                                  // read (as tile c - 1) in the next iteration
+        v = hv != 0.f ? v * lscale : 0.f;                             // lscale = 0 in lanes without a token
+        gs_prev[i] = v;                                               // read (as tile c - 1) in the next iteration
       } else {
         v = fmaxf(v + bias[i >> 2][i & 3], 0.f);
         if (drop) {

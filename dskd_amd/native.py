@@ -506,6 +506,14 @@ def relu_dropout_bwd(g: torch.Tensor, y_dropped: torch.Tensor, p: float, want_co
 
 
 FFN_FUSED_DIMS = (256, 1024)      # (d_model, hidden) the MFMA kernels of csrc/ffn_mfma.hip are built for
+_ffn_flops = 0
+
+
+def ffn_flops_launched() -> int:
+    """FLOPs of the fused FFN launches enqueued from Python so far (two GEMMs of 2 * tokens * d * hidden per launch);
+    bench.py's MFMA-utilisation probe reads the difference over one eager step."""
+    return _ffn_flops
+
 
 
 def ffn_pack(w1: torch.Tensor, w2: torch.Tensor, want_bwd: bool = True):
@@ -545,6 +553,8 @@ def ffn_fwd_raw(x: torch.Tensor, packed_fwd: torch.Tensor, b1: torch.Tensor, b2:
                              None if h is None else h.data_ptr(), y.data_ptr(), tokens, d, hidden, p, seed, offset,
                              dropout_epoch(x.device).data_ptr() if p > 0 else None, DTYPE_BF16, _stream(x))
     _check(rc, "dskd_ffn_fwd")
+    global _ffn_flops
+    _ffn_flops += 4 * tokens * d * hidden
     return y, h
 
 
@@ -562,6 +572,8 @@ def ffn_bwd_raw(grad_y: torch.Tensor, h: torch.Tensor, packed_bwd: torch.Tensor,
                              None if cs is None else cs.data_ptr(), copies, tokens, d, h.shape[1], p, DTYPE_BF16,
                              _stream(grad_y))
     _check(rc, "dskd_ffn_bwd")
+    global _ffn_flops
+    _ffn_flops += 4 * tokens * d * h.shape[1]
     if want_colsum:
         return gh, gx, (cs.sum(0) if copies > 1 else cs[0])
     return gh, gx

@@ -6,5 +6,5 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 rm -rf /tmp/prof_bench
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -o bench -- python bench.py --steps 10 --no-cpu-baseline --no-mfma-probe > gpurun_out/bd_bench.json 2> gpurun_out/bd_bench.err || { tail -5 gpurun_out/bd_bench.err; exit 1; }
-python scratch/step_breakdown.py "$(find /tmp/prof_bench -name '*kernel_trace.csv' | head -1)" 90 > gpurun_out/bd_step_breakdown.txt 2>&1
-head -60 gpurun_out/bd_step_breakdown.txt
+python scratch/step_breakdown.py "$(find /tmp/prof_bench -name "*kernel_trace.csv" | head -1)" 60 > gpurun_out/bd_step_breakdown.txt 2>&1
+tail -48 gpurun_out/bd_step_breakdown.txt

@@ -40,3 +40,14 @@ cov += cur_e - cur_s
 print(f"union of kernel intervals {cov/1e6:.1f} ms of wall {(en-st)/1e6:.1f} ms -> GPU idle {(en-st-cov)/1e6:.1f} ms")
 for q, v in qs.items():
     print(f"  queue {q}: {len(v)} kernels, busy {sum(e_-s_ for s_,e_ in v)/1e6:.1f} ms, span {(max(e_ for _,e_ in v)-min(s_ for s_,_ in v))/1e6:.1f} ms")
+# hipBLASLt GEMMs of the step by (kernel, grid): count, average and total time
+g = collections.defaultdict(lambda: [0, 0])
+for r in step:
+    n = r['Kernel_Name']
+    if n.startswith('Cijk'):
+        mt = n[n.index('_MT'):][:16] if '_MT' in n else ''
+        key = (n[:24] + mt, r.get('Grid_Size', r.get('Grid_Size_X', '?')))
+        g[key][0] += int(r['End_Timestamp']) - int(r['Start_Timestamp']); g[key][1] += 1
+print("GEMM groups (name, grid): total ms, count, avg us")
+for k, (t, c) in sorted(g.items(), key=lambda kv: -kv[1][0])[:40]:
+    print(f"{t/1e6:7.2f} ms {c:4d} {t/c/1e3:8.1f} us  {k[0]}  grid={k[1]}")

@@ -28,5 +28,5 @@ with open('gpurun_out/torch_prof_cpu.txt','w') as f:
 evs = prof.key_averages(group_by_input_shape=True)
 rows = sorted(evs, key=lambda e: -getattr(e, "self_device_time_total", 0))
 with open('gpurun_out/torch_prof_tsv.txt', 'w') as f:
-    for e in rows[:140]:
+    for e in rows[:600]:
         f.write(f"{e.key[:60]}\t{e.self_device_time_total/1e3:.3f}ms\t{e.count}\t{str(e.input_shapes)[:160]}\n")
