@@ -150,6 +150,7 @@ struct FfnArgs {
   const unsigned long long* epoch;
   float* colsum;         // backward: [copies, 1024] f32, += column sums of g1 (= grad of b1); may be null
   int copies;
+  const __bf16* acc_in;  // backward: [T, 256] added to dX in the epilogue (another gradient of the same x); may be null
 };
 
 enum { kFwdTrain = 0, kFwdEval = 1, kBwd = 2, kFwdTrainDrop = 3 };   // kFwdTrain: H stored, p = 0
@@ -480,6 +481,7 @@ __global__ __launch_bounds__(kWaves * 64) void ffn_fused_kernel(const FfnArgs a)
       for (int i = 0; i < 16; ++i) {
         float v = yacc[ot][i];
         if (MODE != kBwd) v += (float)a.b2[32 * ot + 16 * h + i];
+        else if (a.acc_in) v += (float)a.acc_in[tok * kD + 16 * h + 32 * ot + i];
         o[i >> 3][i & 7] = (__bf16)v;
       }
       *reinterpret_cast<bf16x8*>(orow + 32 * ot) = o[0];
@@ -569,8 +571,8 @@ extern "C" int dskd_ffn_fwd(const void* x, const void* packed_fwd, const void* b
 }
 
 extern "C" int dskd_ffn_bwd(const void* grad_y, const void* h, const void* packed_bwd, void* grad_h, void* grad_x,
-                            float* grad_b1, int copies, int64_t tokens, int d_model, int hidden, float p, int dtype,
-                            void* stream) {
+                            const void* grad_x_add, float* grad_b1, int copies, int64_t tokens, int d_model, int hidden,
+                            float p, int dtype, void* stream) {
   if (dtype != DSKD_DTYPE_BF16) return fail(DSKD_ERR_INVALID_ARG, "dskd_ffn_bwd: bf16 only");
   if (d_model != kD || hidden != kF)
     return fail(DSKD_ERR_INVALID_ARG, "dskd_ffn_bwd: d_model 256 / hidden 1024 only (got %d / %d)", d_model, hidden);
@@ -582,7 +584,8 @@ extern "C" int dskd_ffn_bwd(const void* grad_y, const void* h, const void* packe
   if (grad_b1 && copies < 1) return fail(DSKD_ERR_INVALID_ARG, "dskd_ffn_bwd: copies < 1");
   if (tokens == 0) return DSKD_OK;
   FfnArgs a{};
-  a.colsum = grad_b1; a.copies = copies;
+  if (misaligned(grad_x_add)) return fail(DSKD_ERR_INVALID_ARG, "dskd_ffn_bwd: pointers must be 16-byte aligned");
+  a.colsum = grad_b1; a.copies = copies; a.acc_in = (const __bf16*)grad_x_add;
   a.in = (const __bf16*)grad_y; a.wp = (const __bf16*)packed_bwd; a.h_in = (const __bf16*)h;
   a.h_out = (__bf16*)grad_h; a.out = (__bf16*)grad_x; a.T = tokens; a.scale = 1.0f / (1.0f - p);
   return launch_ffn<kBwd>(a, (hipStream_t)stream);

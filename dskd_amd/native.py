@@ -44,7 +44,7 @@ _SIGNATURES = {
     "dskd_ffn_packed_bytes": (_i64, [C.c_int, C.c_int]),
     "dskd_ffn_pack": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_ffn_fwd": (C.c_int, [_vp] * 6 + [_i64, C.c_int, C.c_int, _f32, C.c_uint64, C.c_uint64, _vp, C.c_int, _vp]),
-    "dskd_ffn_bwd": (C.c_int, [_vp] * 6 + [C.c_int, _i64, C.c_int, C.c_int, _f32, C.c_int, _vp]),
+    "dskd_ffn_bwd": (C.c_int, [_vp] * 7 + [C.c_int, _i64, C.c_int, C.c_int, _f32, C.c_int, _vp]),
     "dskd_lsap_host": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "dskd_lsap_batched": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "dskd_match_cost": (C.c_int, [_vp] * 7 + [C.c_int] * 3 + [_f32] * 3 + [_vp]),
@@ -558,9 +558,10 @@ def ffn_fwd_raw(x: torch.Tensor, packed_fwd: torch.Tensor, b1: torch.Tensor, b2:
     return y, h
 
 
-def ffn_bwd_raw(grad_y: torch.Tensor, h: torch.Tensor, packed_bwd: torch.Tensor, p: float, want_colsum: bool = False):
+def ffn_bwd_raw(grad_y: torch.Tensor, h: torch.Tensor, packed_bwd: torch.Tensor, p: float, want_colsum: bool = False,
+                add_to_gx: Optional[torch.Tensor] = None):
     """(grad_h, grad_x[, column sums of grad_h in f32 = grad of b1]) of :func:`ffn_fwd_raw` given grad_y [tokens, d]
-    and the stored H: one MFMA launch."""
+    and the stored H: one MFMA launch.  ``add_to_gx`` [tokens, d] bf16 is added to grad_x in the kernel's epilogue."""
     _need_gpu(grad_y, h, packed_bwd)
     grad_y = grad_y.contiguous()
     tokens, d = grad_y.shape
@@ -568,7 +569,11 @@ def ffn_bwd_raw(grad_y: torch.Tensor, h: torch.Tensor, packed_bwd: torch.Tensor,
     gx = torch.empty_like(grad_y)
     copies = _colsum_copies(tokens)
     cs = zeros((copies, h.shape[1]), torch.float32, h.device) if want_colsum else None
+    if add_to_gx is not None and (add_to_gx.dtype != grad_y.dtype or add_to_gx.shape != grad_y.shape or
+                                  not add_to_gx.is_contiguous()):
+        raise NativeError("ffn_bwd_raw: add_to_gx must be a contiguous bf16 [tokens, d] tensor")
     rc = load().dskd_ffn_bwd(grad_y.data_ptr(), h.data_ptr(), packed_bwd.data_ptr(), gh.data_ptr(), gx.data_ptr(),
+                             None if add_to_gx is None else add_to_gx.data_ptr(),
                              None if cs is None else cs.data_ptr(), copies, tokens, d, h.shape[1], p, DTYPE_BF16,
                              _stream(grad_y))
     _check(rc, "dskd_ffn_bwd")

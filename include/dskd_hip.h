@@ -326,7 +326,9 @@ int dskd_colsum(const void* x, float* colsum, int copies, int64_t rows, int C, i
  *                   h_out [tokens, hidden] receives H = dropout_p(relu(.)) for the backward; NULL (p must be 0) skips it.
  *                   Dropout mask = that of dskd_dropout_fwd on H (Philox4x32-10(seed, offset + *epoch), not stored).
  * dskd_ffn_bwd      grad_h = (grad_y w2) * [h != 0] / (1 - p)          [tokens, hidden]  (input of the w1 / b1 gradients)
- *                   grad_x = grad_h w1                                 [tokens, d_model]
+ *                   grad_x = grad_h w1 (+ grad_x_add)                  [tokens, d_model]; grad_x_add [tokens, d_model] bf16 or
+ *                                             NULL: another gradient of the same x (the residual branch of the following
+ *                                             LayerNorm), added in the epilogue instead of by a separate pass
  *                   grad_b1[k % copies][:] += column sums of grad_h over workgroup k's tokens  (f32 [copies, hidden],
  *                                             zeroed by the caller, summed over copies by the caller; NULL to skip)
  *                   The weight gradients are plain GEMMs over the tokens: grad_w2 = grad_y^T h, grad_w1 = grad_h^T x;
@@ -340,7 +342,8 @@ int dskd_ffn_fwd(const void* x, const void* packed_fwd, const void* b1, const vo
                  int64_t tokens, int d_model, int hidden, float p, uint64_t seed, uint64_t offset,
                  const uint64_t* epoch, int dtype, void* stream);
 int dskd_ffn_bwd(const void* grad_y, const void* h, const void* packed_bwd, void* grad_h, void* grad_x,
-                 float* grad_b1, int copies, int64_t tokens, int d_model, int hidden, float p, int dtype, void* stream);
+                 const void* grad_x_add, float* grad_b1, int copies, int64_t tokens, int d_model, int hidden, float p,
+                 int dtype, void* stream);
 
 #ifdef __cplusplus
 }

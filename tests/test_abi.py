@@ -58,7 +58,7 @@ def test_argument_validation_returns_error_codes():
     assert lib.dskd_ffn_packed_bytes(256, 1024) == 32 * 32768
     assert lib.dskd_ffn_packed_bytes(256, 2048) == -1 and b"hidden 1024" in lib.dskd_last_error()
     assert lib.dskd_ffn_fwd(1, 1, 1, 1, None, 1, 4, 128, 1024, 0.0, 0, 0, None, 1, None) == -1
-    assert lib.dskd_ffn_bwd(16, 16, 16, 16, 16, None, 1, 4, 256, 1024, 1.5, 1, None) == -1 and b"p=" in lib.dskd_last_error()
+    assert lib.dskd_ffn_bwd(16, 16, 16, 16, 16, None, None, 1, 4, 256, 1024, 1.5, 1, None) == -1 and b"p=" in lib.dskd_last_error()
 
 
 def test_lsap_host_entry_matches_scipy():

@@ -1035,3 +1035,36 @@ def test_ffn_module_fused_equals_gemm_chain(monkeypatch):
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         monkeypatch.delenv("DSKD_FFN")
         assert float((ffn.core(x, final_dropout=False).float() - res["fused"][0]).abs().max()) <= 2e-2 * float(res["fused"][0].abs().max())
+
+
+def test_ffn_block_node_equals_two_nodes():
+    """transformer.ffn_block: LayerNorm(x + FFN(x)) as ONE autograd node (the residual gradient is added inside the FFN
+    backward kernel) against the same sub-layer as two nodes (fused FFN, then native.add_layer_norm), where autograd
+    adds the two gradients of x itself: outputs identical, every gradient equal to bf16 rounding."""
+    import torch.nn as nn
+    from dskd_amd.transformer import FFN, ffn_block
+    torch.manual_seed(2)
+    ffn = FFN(256, 1024, ffn_drop=0.0).to(DEV)
+    norm = nn.LayerNorm(256).to(DEV)
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5)
+        norm.bias.uniform_(-0.2, 0.2)
+    x = torch.randn(2, 9000, 256, device=DEV).bfloat16()
+    up = torch.randn(2, 9000, 256, device=DEV)
+    params = list(ffn.parameters()) + list(norm.parameters())
+    res = []
+    for one_node in (True, False):
+        xi = x.clone().requires_grad_(True)
+        for q in params:
+            q.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            if one_node:
+                out = ffn_block(xi, ffn, norm, 0.0)
+                assert out is not None
+            else:
+                out, _ = native.add_layer_norm(ffn.core(xi, final_dropout=False), xi, norm, p=0.0)
+        out.float().mul(up).sum().backward()
+        res.append([out.detach().float(), xi.grad.float()] + [q.grad.float().clone() for q in params])
+    assert torch.equal(res[0][0], res[1][0])
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert float((a - b).abs().max()) <= 1e-2 * float(b.abs().max())
