@@ -45,6 +45,9 @@ _SIGNATURES = {
     "dskd_ffn_pack": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_ffn_fwd": (C.c_int, [_vp] * 6 + [_i64, C.c_int, C.c_int, _f32, C.c_uint64, C.c_uint64, _vp, C.c_int, _vp]),
     "dskd_ffn_bwd": (C.c_int, [_vp] * 7 + [C.c_int, _i64, C.c_int, C.c_int, _f32, C.c_int, _vp]),
+    "dskd_gn_workspace": (_i64, [C.c_int, _i64]),
+    "dskd_gn_fwd": (C.c_int, [_vp] * 6 + [C.c_int, _i64, C.c_int, C.c_int, _i64, _i64, _f32, C.c_int, _vp]),
+    "dskd_gn_bwd": (C.c_int, [_vp] * 7 + [C.c_int, C.c_int, _i64, C.c_int, C.c_int, _i64, _i64, _i64, C.c_int, _vp]),
     "dskd_lsap_host": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "dskd_lsap_batched": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "dskd_match_cost": (C.c_int, [_vp] * 7 + [C.c_int] * 3 + [_f32] * 3 + [_vp]),
@@ -603,6 +606,70 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
     rc = load().dskd_colsum(x.data_ptr(), out.data_ptr(), copies, rows, Cc, DTYPE_BF16, _stream(x))
     _check(rc, "dskd_colsum")
     return out.sum(0) if copies > 1 else out[0]
+
+
+# --------------------------------------------------------------------------- GroupNorm of the neck
+def _cl_rows(t: torch.Tensor):
+    """Batch stride (elements) if ``t`` [B, C, H, W] is laid out as [b][h][w][c] rows with any batch stride, else None."""
+    B, Cc, H, W = t.shape
+    if t.stride(1) == 1 and t.stride(3) == Cc and t.stride(2) == W * Cc and t.stride(0) % 8 == 0 and \
+            t.data_ptr() % 16 == 0:
+        return t.stride(0)
+    return None
+
+
+class _GroupNormCLFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps):
+        dt = {torch.float32: DTYPE_F32, torch.bfloat16: DTYPE_BF16}[x.dtype]
+        B, Cc, H, W = x.shape
+        y = torch.empty_like(x)                       # preserve_format: channels_last
+        train = any(ctx.needs_input_grad[:3])
+        sums = torch.empty(load().dskd_gn_workspace(B, H * W) // 8, dtype=torch.float64, device=x.device)
+        stats = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
+        gamma_f, beta_f = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        rc = load().dskd_gn_fwd(x.data_ptr(), gamma_f.data_ptr(), beta_f.data_ptr(), y.data_ptr(), sums.data_ptr(),
+                                stats.data_ptr(), B, H * W, Cc, groups, x.stride(0), y.stride(0), eps, dt, _stream(x))
+        _check(rc, "dskd_gn_fwd")
+        if train:
+            ctx.save_for_backward(x, stats, gamma_f)
+            ctx.meta = (dt, groups, gamma.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats, gamma_f = ctx.saved_tensors
+        dt, groups, gdtype = ctx.meta
+        B, Cc, H, W = x.shape
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        dy_bs = _cl_rows(dy)
+        if dy_bs is None:
+            dy = dy.contiguous(memory_format=torch.channels_last)
+            dy_bs = dy.stride(0)
+        dx = torch.empty_like(x)
+        copies = _colsum_copies(B * H * W)
+        sums = zeros((B, groups, 2), torch.float64, x.device)
+        dgb = zeros((copies, 2, Cc), torch.float32, x.device)
+        rc = load().dskd_gn_bwd(x.data_ptr(), dy.data_ptr(), stats.data_ptr(), gamma_f.data_ptr(), dx.data_ptr(),
+                                sums.data_ptr(), dgb.data_ptr(), copies, B, H * W, Cc, groups, x.stride(0), dy_bs,
+                                dx.stride(0), dt, _stream(x))
+        _check(rc, "dskd_gn_bwd")
+        dgb = dgb.sum(0) if copies > 1 else dgb[0]
+        return dx, dgb[0].to(gdtype), dgb[1].to(gdtype), None, None
+
+
+def group_norm_cl_ok(x: torch.Tensor, gn: torch.nn.GroupNorm) -> bool:
+    """Can csrc/gn.hip take this GroupNorm call (CUDA, channels_last rows, 256 channels in 32 groups, affine)?"""
+    return (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16) and gn.affine
+            and gn.num_channels == 256 and gn.num_groups == 32 and x.shape[1] == 256 and x.numel() > 0
+            and not os.environ.get("DSKD_GN_ATEN") and _cl_rows(x) == x.shape[1] * x.shape[2] * x.shape[3])
+
+
+def group_norm_cl(x: torch.Tensor, gn: torch.nn.GroupNorm) -> torch.Tensor:
+    """``gn(x)`` for a channels_last [B, 256, H, W] activation in two streaming passes each way; the result has x's
+    dtype and memory format (under autocast: bf16 in, bf16 out -- ATen would cast to f32, copy to NCHW and back)."""
+    return _GroupNormCLFunction.apply(x, gn.weight, gn.bias, gn.num_groups, float(gn.eps))
 
 
 # --------------------------------------------------------------------------- conv epilogue

@@ -4,6 +4,7 @@ convs on the last map.  Sub-module names follow ext-mmcv ``ConvModule`` (``conv`
 so reference checkpoints load."""
 import torch.nn as nn
 
+from . import native
 from .builder import NECKS
 
 
@@ -26,7 +27,9 @@ class ConvModule(nn.Module):
 
     def forward(self, x):
         x = self.conv(x)
-        if self.norm_name:
+        if self.norm_name == "gn" and native.group_norm_cl_ok(x, self.gn):
+            x = native.group_norm_cl(x, self.gn)          # channels_last GroupNorm(32, 256): csrc/gn.hip
+        elif self.norm_name:
             x = getattr(self, self.norm_name)(x)
         if self.activate is not None:
             x = self.activate(x)

@@ -345,6 +345,28 @@ int dskd_ffn_bwd(const void* grad_y, const void* h, const void* packed_bwd, void
                  const void* grad_x_add, float* grad_b1, int copies, int64_t tokens, int d_model, int hidden, float p,
                  int dtype, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * GroupNorm(32 groups, 256 channels) on a channels_last activation -- the norm of every ChannelMapper level
+ * (mmdet/models/necks/channel_mapper.py:10-100: ext-mmcv ConvModule(conv, GN)); replaces F.group_norm and, under
+ * autocast, the f32 casts and layout copies around it.  Other channel / group counts are refused.
+ *   x, y, grad_y, grad_x   device, [B, HW, 256] rows (= a [B, 256, H, W] tensor in channels_last memory), f32 | bf16,
+ *                          each with its own batch stride in elements (a level's slice of a concatenated token tensor
+ *                          is a valid y / grad_y); 16-byte aligned
+ *   gamma, beta            device f32 [256]
+ *   sums                   forward: device scratch of dskd_gn_workspace(B, HW) bytes (partial moments, summed in a
+ *                          fixed order: the forward is deterministic); backward: device f64 [B, 32, 2], ZEROED by the caller
+ *   stats                  device f32 [B, 32, 2] = {mean, rstd}: written by the forward, read by the backward
+ *   grad_gamma_beta        device f32 [copies, 2, 256], zeroed by the caller: [k][0] += partial grad_gamma, [k][1] +=
+ *                          partial grad_beta (copies as in dskd_add_ln_bwd)
+ * ------------------------------------------------------------------------- */
+int64_t dskd_gn_workspace(int B, int64_t HW);
+int dskd_gn_fwd(const void* x, const float* gamma, const float* beta, void* y, double* sums, float* stats, int B,
+                int64_t HW, int C, int groups, int64_t x_batch_stride, int64_t y_batch_stride, float eps, int dtype,
+                void* stream);
+int dskd_gn_bwd(const void* x, const void* grad_y, const float* stats, const float* gamma, void* grad_x, double* sums,
+                float* grad_gamma_beta, int copies, int B, int64_t HW, int C, int groups, int64_t x_batch_stride,
+                int64_t gy_batch_stride, int64_t gx_batch_stride, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

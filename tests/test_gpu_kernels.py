@@ -1068,3 +1068,45 @@ def test_ffn_block_node_equals_two_nodes():
     assert torch.equal(res[0][0], res[1][0])
     for a, b in zip(res[0][1:], res[1][1:]):
         assert float((a - b).abs().max()) <= 1e-2 * float(b.abs().max())
+
+
+# --------------------------------------------------------------------------- GroupNorm of the neck (csrc/gn.hip)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("hw", [(100, 167), (13, 21), (1, 3)])
+def test_group_norm_cl_vs_torch(dtype, hw):
+    """dskd_gn_fwd / dskd_gn_bwd on a channels_last activation against F.group_norm + autograd evaluated in fp32 on the CPU
+    from the same (rounded) inputs: output, input gradient, affine gradients; the incoming gradient is a level's slice of a
+    concatenated token tensor (own batch stride), as the encoder's backward hands it over.  Tolerance: f32 1e-4 of the
+    largest magnitude (summation order), bf16 1.6e-2 (two bf16 ulps: the result and the incoming gradient are rounded)."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    H, W = hw
+    B = 2
+    g = torch.Generator().manual_seed(7)
+    x = (torch.randn(B, 256, H, W, generator=g) * (1 + torch.arange(256).view(1, 256, 1, 1) % 5) + 0.5).to(dtype)
+    gn = nn.GroupNorm(32, 256)
+    with torch.no_grad():
+        gn.weight.copy_(torch.rand(256, generator=g) + 0.5)
+        gn.bias.copy_(torch.randn(256, generator=g) * 0.3)
+    extra = 37                                           # rows of "other levels" around this one in the token tensor
+    up_tok = torch.randn(B, H * W + extra, 256, generator=g).to(dtype)
+    up = up_tok[:, 5:5 + H * W].transpose(1, 2).reshape(B, 256, H, W)          # logical NCHW view of the slice
+    xr = x.float().requires_grad_(True)
+    yr = F.group_norm(xr, 32, gn.weight, gn.bias, gn.eps)
+    gxr, gwr, gbr = torch.autograd.grad(yr, (xr, gn.weight, gn.bias), up.float())
+
+    gnd = nn.GroupNorm(32, 256).to(DEV)
+    gnd.load_state_dict(gn.state_dict())
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    assert native.group_norm_cl_ok(xd, gnd)
+    y = native.group_norm_cl(xd, gnd)
+    assert y.dtype == dtype and y.is_contiguous(memory_format=torch.channels_last)
+    upd_tok = up_tok.to(DEV)
+    upd = upd_tok[:, 5:5 + H * W].transpose(1, 2).unflatten(2, (H, W))         # channels_last rows with a batch stride
+    gx, gw, gb = torch.autograd.grad(y, (xd, gnd.weight, gnd.bias), upd)
+    tol = 1e-4 if dtype == torch.float32 else 1.6e-2
+    for name, a, r in (("y", y, yr.detach()), ("dx", gx, gxr), ("dgamma", gw, gwr), ("dbeta", gb, gbr)):
+        err = float((a.float().cpu() - r).abs().max())
+        assert err <= tol * float(r.abs().max()) + 1e-6, (name, err, float(r.abs().max()))
+    with torch.no_grad():                                # inference (the frozen teacher): no statistics saved
+        assert torch.equal(native.group_norm_cl(xd.detach(), gnd), y)
