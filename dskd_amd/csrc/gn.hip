@@ -78,20 +78,30 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
   }
 }
 
-// stats[b][g] = {mean, rstd} (f32) from the partial sums, chunk by chunk in order.  grid B, 32 threads.
-__global__ __launch_bounds__(32) void gn_finalize_kernel(const double* __restrict__ part, float* __restrict__ stats,
+// stats[b][g] = {mean, rstd} (f32) from the partial sums in a FIXED order: thread (j, g) adds chunks j, j + 8, ... and
+// the eight partial results are added in order of j.  grid B, 256 threads (a single thread per group walking all
+// chunks is a chain of ~130 dependent L2 loads: 16 us).
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ part, float* __restrict__ stats,
                                                          int chunks, long long HW, float eps) {
-  const int g = threadIdx.x, b = blockIdx.x;
+  __shared__ double s_acc[kRows][kG][2];
+  const int g = threadIdx.x & 31, j = threadIdx.x >> 5, b = blockIdx.x;
   double s = 0.0, ss = 0.0;
-  for (int c = 0; c < chunks; ++c) {
+  for (int c = j; c < chunks; c += kRows) {
     s += part[(((size_t)b * chunks + c) * kG + g) * 2];
     ss += part[(((size_t)b * chunks + c) * kG + g) * 2 + 1];
   }
-  const double n = (double)HW * kCpg, mean = s / n;
-  double var = ss / n - mean * mean;
-  var = var > 0.0 ? var : 0.0;
-  stats[((size_t)b * kG + g) * 2] = (float)mean;
-  stats[((size_t)b * kG + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  s_acc[j][g][0] = s; s_acc[j][g][1] = ss;
+  __syncthreads();
+  if (j == 0) {
+    s = 0.0; ss = 0.0;
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) { s += s_acc[r][g][0]; ss += s_acc[r][g][1]; }
+    const double n = (double)HW * kCpg, mean = s / n;
+    double var = ss / n - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    stats[((size_t)b * kG + g) * 2] = (float)mean;
+    stats[((size_t)b * kG + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
 }
 
 // y in x's dtype and layout.
@@ -208,6 +218,34 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
+// out[b][c][p] (f32, NCHW planes) = x[b][p][c] (channels_last rows, f32 | bf16): the layout + dtype the feature-map
+// distillation kernel (fgkd.hip) reads.  ATen does this as a strided copy plus a cast (82 + 40 us for the level-0 map);
+// here 32 pixels x 256 channels go through LDS: 512-byte rows in, 128-byte runs out.  grid (ceil(HW / 32), B).
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_f32_kernel(const T* __restrict__ x, float* __restrict__ out,
+                                                               long long HW, long long x_bs) {
+  __shared__ float tile[kC][33];
+  const int g = threadIdx.x & 31, row = threadIdx.x >> 5, b = blockIdx.y;
+  const long long p0 = (long long)blockIdx.x * 32;
+  const T* xb = x + (size_t)b * x_bs + g * kCpg;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pl = row + 8 * i;
+    if (p0 + pl < HW) {
+      float v[8];
+      load8<T>(xb + (p0 + pl) * kC, v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) tile[g * kCpg + k][pl] = v[k];
+    }
+  }
+  __syncthreads();
+  float* ob = out + (size_t)b * kC * HW + p0;
+  if (p0 + g < HW) {
+#pragma unroll 8
+    for (int c = row; c < kC; c += 8) ob[(size_t)c * HW + g] = tile[c][g];
+  }
+}
+
 int gn_span(long long HW) { return HW >= 8192 ? 128 : 64; }
 
 bool bad_ptr(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
@@ -216,6 +254,23 @@ bool bad_ptr(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0;
 }  // namespace dskd
 
 using namespace dskd;
+
+extern "C" int dskd_nhwc_to_nchw_f32(const void* x, float* out, int B, int64_t HW, int C, int64_t x_batch_stride,
+                                     int dtype, void* stream) {
+  if (C != kC) return fail(DSKD_ERR_INVALID_ARG, "dskd_nhwc_to_nchw_f32: 256 channels only (got %d)", C);
+  if (!x || !out || B < 0 || HW < 0) return fail(DSKD_ERR_INVALID_ARG, "dskd_nhwc_to_nchw_f32: null pointer or negative size");
+  if (bad_ptr(x) || x_batch_stride % 8) return fail(DSKD_ERR_INVALID_ARG, "dskd_nhwc_to_nchw_f32: x must be 16-byte aligned rows");
+  if (dtype != DSKD_DTYPE_F32 && dtype != DSKD_DTYPE_BF16) return fail(DSKD_ERR_INVALID_ARG, "dskd_nhwc_to_nchw_f32: dtype");
+  if (B == 0 || HW == 0) return DSKD_OK;
+  const dim3 grid((unsigned)((HW + 31) / 32), (unsigned)B);
+  if (dtype == DSKD_DTYPE_BF16)
+    hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, out,
+                       (long long)HW, (long long)x_batch_stride);
+  else
+    hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, out,
+                       (long long)HW, (long long)x_batch_stride);
+  return check_launch("dskd_nhwc_to_nchw_f32");
+}
 
 extern "C" int64_t dskd_gn_workspace(int B, int64_t HW) {
   if (B < 0 || HW < 0) return -1;
@@ -239,12 +294,12 @@ extern "C" int dskd_gn_fwd(const void* x, const float* gamma, const float* beta,
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DSKD_DTYPE_BF16) {
     hipLaunchKernelGGL(gn_stats_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16*)x, sums, (long long)HW, (long long)x_batch_stride, span);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)B), dim3(32), 0, st, sums, stats, (int)grid.x, (long long)HW, eps);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)B), dim3(256), 0, st, sums, stats, (int)grid.x, (long long)HW, eps);
     hipLaunchKernelGGL(gn_apply_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16*)x, stats, gamma, beta, (__bf16*)y,
                        (long long)HW, (long long)x_batch_stride, (long long)y_batch_stride, span);
   } else {
     hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), 0, st, (const float*)x, sums, (long long)HW, (long long)x_batch_stride, span);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)B), dim3(32), 0, st, sums, stats, (int)grid.x, (long long)HW, eps);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)B), dim3(256), 0, st, sums, stats, (int)grid.x, (long long)HW, eps);
     hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, stats, gamma, beta, (float*)y,
                        (long long)HW, (long long)x_batch_stride, (long long)y_batch_stride, span);
   }

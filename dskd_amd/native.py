@@ -46,6 +46,7 @@ _SIGNATURES = {
     "dskd_ffn_fwd": (C.c_int, [_vp] * 6 + [_i64, C.c_int, C.c_int, _f32, C.c_uint64, C.c_uint64, _vp, C.c_int, _vp]),
     "dskd_ffn_bwd": (C.c_int, [_vp] * 7 + [C.c_int, _i64, C.c_int, C.c_int, _f32, C.c_int, _vp]),
     "dskd_gn_workspace": (_i64, [C.c_int, _i64]),
+    "dskd_nhwc_to_nchw_f32": (C.c_int, [_vp, _vp, C.c_int, _i64, C.c_int, _i64, C.c_int, _vp]),
     "dskd_gn_fwd": (C.c_int, [_vp] * 6 + [C.c_int, _i64, C.c_int, C.c_int, _i64, _i64, _f32, C.c_int, _vp]),
     "dskd_gn_bwd": (C.c_int, [_vp] * 7 + [C.c_int, C.c_int, _i64, C.c_int, C.c_int, _i64, _i64, _i64, C.c_int, _vp]),
     "dskd_lsap_host": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
@@ -659,6 +660,23 @@ class _GroupNormCLFunction(torch.autograd.Function):
         return dx, dgb[0].to(gdtype), dgb[1].to(gdtype), None, None
 
 
+def nchw_f32(t: torch.Tensor) -> torch.Tensor:
+    """``t.detach().contiguous().float()`` of a [B, C, H, W] map; one transposing launch when ``t`` is a 256-channel
+    channels_last f32 | bf16 CUDA tensor (what the neck's GroupNorm kernel hands over), ATen otherwise."""
+    t = t.detach()
+    if t.is_cuda and t.dim() == 4 and t.shape[1] == 256 and t.dtype in (torch.float32, torch.bfloat16) and t.numel() > 0 \
+            and not t.is_contiguous():
+        bs = _cl_rows(t)
+        if bs is not None:
+            B, Cc, H, W = t.shape
+            out = torch.empty((B, Cc, H, W), dtype=torch.float32, device=t.device)
+            dt = DTYPE_F32 if t.dtype == torch.float32 else DTYPE_BF16
+            _check(load().dskd_nhwc_to_nchw_f32(t.data_ptr(), out.data_ptr(), B, H * W, Cc, bs, dt, _stream(t)),
+                   "dskd_nhwc_to_nchw_f32")
+            return out
+    return t.contiguous().float()
+
+
 def group_norm_cl_ok(x: torch.Tensor, gn: torch.nn.GroupNorm) -> bool:
     """Can csrc/gn.hip take this GroupNorm call (CUDA, channels_last rows, 256 channels in 32 groups, affine)?"""
     return (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16) and gn.affine
@@ -840,8 +858,8 @@ def fgkd_loss(feats_s: List[torch.Tensor], feats_t: List[torch.Tensor], boxes: L
     levels = len(feats_s)
     B, Cc = feats_s[0].shape[:2]
     N, D = hs_s.shape
-    fs = [t.detach().contiguous().float() for t in feats_s]
-    ft = [t.detach().contiguous().float() for t in feats_t]
+    fs = [nchw_f32(t) for t in feats_s]
+    ft = [nchw_f32(t) for t in feats_t]
     shapes = []
     for t in fs:
         shapes += [t.shape[2], t.shape[3]]

@@ -360,6 +360,10 @@ int dskd_ffn_bwd(const void* grad_y, const void* h, const void* packed_bwd, void
  *                          partial grad_beta (copies as in dskd_add_ln_bwd)
  * ------------------------------------------------------------------------- */
 int64_t dskd_gn_workspace(int B, int64_t HW);
+/* out [B, 256, HW] f32 (NCHW planes) = x [B, HW, 256] (channels_last rows, f32 | bf16): layout + dtype of the feature maps
+ * dskd_fgkd_fwd reads, from the layout the neck produces. */
+int dskd_nhwc_to_nchw_f32(const void* x, float* out, int B, int64_t HW, int C, int64_t x_batch_stride, int dtype,
+                          void* stream);
 int dskd_gn_fwd(const void* x, const float* gamma, const float* beta, void* y, double* sums, float* stats, int B,
                 int64_t HW, int C, int groups, int64_t x_batch_stride, int64_t y_batch_stride, float eps, int dtype,
                 void* stream);

@@ -51,3 +51,10 @@ for r in step:
 print("GEMM groups (name, grid): total ms, count, avg us")
 for k, (t, c) in sorted(g.items(), key=lambda kv: -kv[1][0])[:40]:
     print(f"{t/1e6:7.2f} ms {c:4d} {t/c/1e3:8.1f} us  {k[0]}  grid={k[1]}")
+# the longest individual launches of ATen's generic (strided / casting) elementwise kernel
+mu = [(int(r['End_Timestamp']) - int(r['Start_Timestamp']), r.get('Grid_Size', '?'), r['Kernel_Name'][60:200]) for r in step
+      if 'manual_unroll' in r['Kernel_Name']]
+mu.sort(reverse=True)
+print("elementwise_kernel_manual_unroll, longest launches: us, grid, functor")
+for t, gsz, n in mu[:30]:
+    print(f"{t/1e3:8.1f} us  grid={gsz:>10s}  {n}")

@@ -1110,3 +1110,14 @@ def test_group_norm_cl_vs_torch(dtype, hw):
         assert err <= tol * float(r.abs().max()) + 1e-6, (name, err, float(r.abs().max()))
     with torch.no_grad():                                # inference (the frozen teacher): no statistics saved
         assert torch.equal(native.group_norm_cl(xd.detach(), gnd), y)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_nchw_f32_of_channels_last_maps(dtype):
+    """native.nchw_f32 (dskd_nhwc_to_nchw_f32): exactly ``t.contiguous().float()`` for channels_last maps, ragged sizes."""
+    for H, W in ((100, 167), (13, 21), (1, 1), (3, 11)):
+        t = torch.randn(2, 256, H, W, device=DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+        out = native.nchw_f32(t)
+        assert out.is_contiguous() and out.dtype == torch.float32 and torch.equal(out, t.contiguous().float())
+    t = torch.randn(2, 256, 5, 7, device=DEV)                          # already NCHW: ATen path, same result
+    assert torch.equal(native.nchw_f32(t), t)
