@@ -15,6 +15,7 @@ import torch.nn as nn
 
 from .builder import DETECTORS, build_backbone, build_head, build_neck
 from .dist import allreduce_scalars
+from .utils import no_gc_during_capture
 
 
 def _tensors(obj):
@@ -87,7 +88,7 @@ class TeacherAhead:
                 g = torch.cuda.CUDAGraph()
                 # thread_local: other threads of the process (RCCL watchdog under DDP) keep making HIP
                 # calls while this thread captures
-                with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local"):
+                with no_gc_during_capture(), torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local"):
                     feats, outs = self._forward(static, img_metas, amp_dtype)
                 g.replay()
                 entries.append(dict(graph=g, img=static, feats=feats, outs=outs))

@@ -43,6 +43,7 @@ import torch
 import torch.distributed as dist
 
 from .dist import get_dist_info
+from .utils import no_gc_during_capture
 
 
 class GraphedDistillStep:
@@ -213,7 +214,7 @@ class GraphedDistillStep:
     def _capture(self, data, inject):
         torch.cuda.synchronize()
         gT = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gT):
+        with no_gc_during_capture(), torch.cuda.graph(gT):
             feats, outs = self._teacher(data)
         gT.replay()                             # capture does not execute: produce real outputs
         det = dict(self._decode(outs, data), **inject)
@@ -229,18 +230,18 @@ class GraphedDistillStep:
                 if id(p) not in fset:
                     p.grad = None               # head gradients are allocated inside graph S
         gF = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gF):
+        with no_gc_during_capture(), torch.cuda.graph(gF):
             torch._foreach_zero_(fgrads)
             xs_raw = self._student_feats(data)
         xs = [f.detach().requires_grad_(True) for f in xs_raw]
         gS = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gS):
+        with no_gc_during_capture(), torch.cuda.graph(gS):
             loss, keys, flat_logs = self._head_fwd_bwd(data, xs, feats, outs, det)
         gF.replay()
         gS.replay()
         torch.autograd.backward(xs_raw, [x.grad for x in xs], retain_graph=True)
         gU = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gU):
+        with no_gc_during_capture(), torch.cuda.graph(gU):
             self._update()                      # the first real update happens on the next replay
         torch.cuda.synchronize()
         from .utils import const_cache_snapshot

@@ -250,16 +250,13 @@ def ffn_block(x, ffn, norm, p_tail):
     return out.view(x.shape)
 
 
-_FFN_PACKED = {}
-
-
-def _frozen_packed(w1, w2):
-    """Fragment-order image of FROZEN bf16 FFN weights (the teacher's), packed once per weight version."""
-    key = (w1.data_ptr(), w2.data_ptr())
-    ver = (w1._version, w2._version)
-    hit = _FFN_PACKED.get(key)
+def _frozen_packed(owner, w1, w2):
+    """Fragment-order image of FROZEN bf16 FFN weights (the teacher's), packed once per weight version and kept ON the
+    owning module (a global keyed by data_ptr could hand out another model's image when the allocator reuses an address)."""
+    ver = (w1.data_ptr(), w2.data_ptr(), w1._version, w2._version)
+    hit = owner.__dict__.get("_ffn_packed")
     if hit is None or hit[0] != ver:
-        hit = _FFN_PACKED[key] = (ver, native.ffn_pack(w1, w2, want_bwd=False)[0])
+        hit = owner.__dict__["_ffn_packed"] = (ver, native.ffn_pack(w1, w2, want_bwd=False)[0], w1, w2)
     return hit[1]
 
 
@@ -274,8 +271,9 @@ def ffn_fused_ok(x, w1, w2, b1, b2):
         and tuple(w2.shape) == (w1.shape[1], w1.shape[0]) and x.is_contiguous()
 
 
-def ffn_fused(x, w1, b1, w2, b2, p):
-    """The two Linears of the FFN with ReLU + Dropout(p) between them, fused (see :class:`_FusedFFNFn`)."""
+def ffn_fused(x, w1, b1, w2, b2, p, owner=None):
+    """The two Linears of the FFN with ReLU + Dropout(p) between them, fused (see :class:`_FusedFFNFn`).  ``owner``: the
+    module that keeps the packed image of frozen weights."""
     dev = x.device.type
     tokens = x.numel() // x.shape[-1]
     bf = torch.bfloat16
@@ -288,7 +286,8 @@ def ffn_fused(x, w1, b1, w2, b2, p):
             y = _FusedFFNFn.apply(x2, w1.to(bf).contiguous(), b1.to(bf), w2.to(bf).contiguous(), b2.to(bf), float(p), chunk)
     else:
         w1b, w2b = w1.detach().to(bf).contiguous(), w2.detach().to(bf).contiguous()
-        pf = _frozen_packed(w1b, w2b) if not w1.requires_grad else native.ffn_pack(w1b, w2b, want_bwd=False)[0]
+        pf = _frozen_packed(owner, w1b, w2b) if (owner is not None and not w1.requires_grad) \
+            else native.ffn_pack(w1b, w2b, want_bwd=False)[0]
         y, _ = native.ffn_fwd_raw(x2, pf, b1.detach().to(bf), b2.detach().to(bf), 0.0 if not p else float(p), store_h=bool(p))
     return y.view(*x.shape[:-1], y.shape[-1])
 
@@ -773,7 +772,7 @@ class FFN(nn.Module):
             lp1 = first[0].frozen_lp(x.device.type) if frozen else first[0].lp()
             lp2 = lin2.frozen_lp(x.device.type) if frozen else lin2.lp()
             if lp1 is not None and lp2 is not None and ffn_fused_ok(x, lp1[0], lp2[0], lp1[1], lp2[1]):
-                out = ffn_fused(x, lp1[0], lp1[1], lp2[0], lp2[1], first[2].p if first[2].training else 0.0)
+                out = ffn_fused(x, lp1[0], lp1[1], lp2[0], lp2[1], first[2].p if first[2].training else 0.0, owner=self)
                 if out is not None:
                     for m in rest[1:]:
                         out = m(out)

@@ -1,6 +1,9 @@
 """Small host-side helpers."""
 from collections import OrderedDict
 
+import contextlib
+import gc
+
 import torch
 
 _CONST_CACHE = OrderedDict()
@@ -31,6 +34,22 @@ def const_cache_snapshot():
     the graph's owner keeps this list alive (the LRU may otherwise evict and free them)."""
     return list(_CONST_CACHE.values())
 
+
+
+@contextlib.contextmanager
+def no_gc_during_capture():
+    """Python's cyclic garbage collector must not run inside a hipGraph capture: collecting an older, unreachable
+    CUDAGraph (or anything else whose destructor makes a HIP call that is illegal while a stream is capturing) aborts
+    the process -- seen once the test suite had grown enough garbage for a collection to land inside the capture.
+    ``torch.cuda.graph`` collects BEFORE the capture begins; this keeps the collector off until it ends."""
+    was = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 class GraphedFunction:
     """A pure tensor function ``fn(*tensors) -> tuple of tensors`` replayed as two hipGraphs
@@ -85,13 +104,13 @@ class GraphedFunction:
         trace = (lambda m: print("[graph]", m, flush=True)) if _os.environ.get("DSKD_GRAPH_TRACE") else (lambda m: None)
         trace("warm-up done")
         self.fwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.fwd, stream=side, capture_error_mode=mode):
+        with no_gc_during_capture(), torch.cuda.graph(self.fwd, stream=side, capture_error_mode=mode):
             self.static_out = run()
         trace("forward captured")
         self.out_grad = [o.requires_grad for o in self.static_out]
         self.static_go = [torch.zeros_like(o) for o in self.static_out]
         self.bwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.bwd, pool=self.fwd.pool(), stream=side, capture_error_mode=mode):
+        with no_gc_during_capture(), torch.cuda.graph(self.bwd, pool=self.fwd.pool(), stream=side, capture_error_mode=mode):
             self.static_gi = torch.autograd.grad([o for o, r in zip(self.static_out, self.out_grad) if r],
                                                  [every[i] for i in self.grad_idx],
                                                  [g for g, r in zip(self.static_go, self.out_grad) if r], allow_unused=True)

@@ -494,6 +494,10 @@ def test_graphed_student_head_equals_eager():
         out["loss"].backward()
         return out["log_vars"], {n: p.grad.detach().float().clone() for n, p in m.named_parameters() if p.grad is not None}
 
+    # One untested call first: the libraries choose their convolution / GEMM algorithms on the first call of a shape,
+    # and that call's result can differ in the last bits from every later one -- enough to flip an assignment near-tie
+    # of this untrained detector (seen once, 2 % on one decoder layer's loss_cls, in a full-suite run).
+    run(torch.randn(2, 3, 192, 256, generator=g).to(dev), False)
     for step in range(6):
         img = torch.randn(2, 3, 192, 256, generator=g).to(dev)
         lg, gg = run(img, True)               # eager for the first two calls, then captured and replayed
