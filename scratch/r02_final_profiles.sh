@@ -23,3 +23,5 @@ for r in rows:
 PY
 timeout -k 10 500 python bench.py --steps 10 --dtype fp32 --no-cpu-baseline --no-mfma-probe > gpurun_out/r02_bench_fp32.json 2> gpurun_out/r02_bench_fp32.err || exit 1
 cut -c1-220 gpurun_out/r02_bench_fp32.json
+timeout -k 10 400 python bench.py --steps 10 --backbone gfl_r50 --no-cpu-baseline --no-mfma-probe > gpurun_out/r02_bench_gfl_r50.json 2> gpurun_out/r02_bench_gfl.err || exit 1
+cut -c1-200 gpurun_out/r02_bench_gfl_r50.json
