@@ -58,3 +58,14 @@ mu.sort(reverse=True)
 print("elementwise_kernel_manual_unroll, longest launches: us, grid, functor")
 for t, gsz, n in mu[:30]:
     print(f"{t/1e3:8.1f} us  grid={gsz:>10s}  {n}")
+# the longest individual ATen launches of the step (any kernel of at::native)
+at = [(int(r['End_Timestamp']) - int(r['Start_Timestamp']), r['Kernel_Name']) for r in step if 'at::native' in r['Kernel_Name']]
+at.sort(reverse=True)
+print("ATen kernels, longest launches: us, name (functor part)")
+import re
+for t, n in at[:60]:
+    short = re.sub(r"at::native::|\(anonymous namespace\)::|std::array<char\*, \d+ul>|at::TensorIteratorBase&", "", n)
+    print(f"{t/1e3:8.1f} us  {short[:170]}")
+tot = sum(t for t, _ in at)
+big = sum(t for t, _ in at if t >= 15000)
+print(f"ATen total {tot/1e6:.2f} ms in {len(at)} launches; launches >= 15 us: {big/1e6:.2f} ms in {sum(1 for t,_ in at if t>=15000)}")
