@@ -430,6 +430,7 @@ class _AddLNFunction(torch.autograd.Function):
         if train:
             ctx.save_for_backward(z, stats, gamma_f)
         ctx.meta = (dt, rows, D, p, seed, offset, None if pos is None else tuple(pos.shape), gamma.dtype, want_q)
+        ctx.pos_dtype = None if pos is None else pos.dtype
         return y, q
 
     @staticmethod
@@ -456,7 +457,10 @@ class _AddLNFunction(torch.autograd.Function):
             pos_rows = 1
             for d_ in pos_shape[:-1]:
                 pos_rows *= d_
-            dpos = dq.view(rows // pos_rows, pos_rows, D).sum(0, dtype=torch.float32).view(pos_shape)
+            if pos_rows == rows and dq.dtype == ctx.pos_dtype:
+                dpos = dq.view(pos_shape)          # nothing to sum: hand the gradient over as it is (a view, no pass)
+            else:
+                dpos = dq.view(rows // pos_rows, pos_rows, D).sum(0, dtype=torch.float32).view(pos_shape)
         return (dres if dh is None else dh), dres, dgb[0].to(gdtype), dgb[1].to(gdtype), dpos, None, None, None
 
 

@@ -1037,12 +1037,15 @@ def test_ffn_module_fused_equals_gemm_chain(monkeypatch):
         assert float((ffn.core(x, final_dropout=False).float() - res["fused"][0]).abs().max()) <= 2e-2 * float(res["fused"][0].abs().max())
 
 
-def test_ffn_block_node_equals_two_nodes():
-    """transformer.ffn_block: LayerNorm(x + FFN(x)) as ONE autograd node (the residual gradient is added inside the FFN
-    backward kernel) against the same sub-layer as two nodes (fused FFN, then native.add_layer_norm), where autograd
-    adds the two gradients of x itself: outputs identical, every gradient equal to bf16 rounding."""
+@pytest.mark.parametrize("with_q", [False, True])
+def test_ffn_block_node_equals_two_nodes(with_q, monkeypatch):
+    """transformer.ffn_block: LayerNorm(x + FFN(x)) (and q = y + pos for the next layer) as ONE autograd node (the
+    residual gradient is added inside the FFN backward kernel) against the same sub-layer as two nodes (fused FFN, then
+    native.add_layer_norm), where autograd adds the two gradients of x itself: outputs identical, every gradient equal to
+    bf16 rounding."""
     import torch.nn as nn
     from dskd_amd.transformer import FFN, ffn_block
+    monkeypatch.setenv("DSKD_FFN", "block")                           # opt-in path (not faster in the step)
     torch.manual_seed(2)
     ffn = FFN(256, 1024, ffn_drop=0.0).to(DEV)
     norm = nn.LayerNorm(256).to(DEV)
@@ -1050,21 +1053,31 @@ def test_ffn_block_node_equals_two_nodes():
         norm.weight.uniform_(0.5, 1.5)
         norm.bias.uniform_(-0.2, 0.2)
     x = torch.randn(2, 9000, 256, device=DEV).bfloat16()
+    pos0 = torch.randn(2, 9000, 256, device=DEV)
     up = torch.randn(2, 9000, 256, device=DEV)
+    upq = torch.randn(2, 9000, 256, device=DEV)
     params = list(ffn.parameters()) + list(norm.parameters())
     res = []
     for one_node in (True, False):
         xi = x.clone().requires_grad_(True)
-        for q in params:
-            q.grad = None
+        pos = pos0.clone().requires_grad_(True) if with_q else None
+        for q_ in params:
+            q_.grad = None
         with torch.autocast("cuda", dtype=torch.bfloat16):
             if one_node:
-                out = ffn_block(xi, ffn, norm, 0.0)
-                assert out is not None
+                blk = ffn_block(xi, ffn, norm, 0.0, pos=pos, want_q=with_q)
+                assert blk is not None
+                out, q = blk
             else:
-                out, _ = native.add_layer_norm(ffn.core(xi, final_dropout=False), xi, norm, p=0.0)
-        out.float().mul(up).sum().backward()
-        res.append([out.detach().float(), xi.grad.float()] + [q.grad.float().clone() for q in params])
+                out, q = native.add_layer_norm(ffn.core(xi, final_dropout=False), xi, norm, p=0.0, pos=pos, want_q=with_q)
+        loss = out.float().mul(up).sum()
+        if with_q:
+            loss = loss + q.float().mul(upq).sum()
+        else:
+            assert q is None
+        loss.backward()
+        res.append([out.detach().float(), xi.grad.float()] + [q_.grad.float().clone() for q_ in params]
+                   + ([q.detach().float(), pos.grad.float()] if with_q else []))
     assert torch.equal(res[0][0], res[1][0])
     for a, b in zip(res[0][1:], res[1][1:]):
         assert float((a - b).abs().max()) <= 1e-2 * float(b.abs().max())
