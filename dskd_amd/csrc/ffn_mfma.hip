@@ -490,6 +490,122 @@ __global__ __launch_bounds__(kWaves * 64) void ffn_fused_kernel(const FfnArgs a)
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// y[T, N] = x[T, 256] W^T (+ bias) for a very tall x and N = 32 .. 512 outputs (the encoder's 256 -> 256 / 384 Linear
+// layers and their dX GEMMs): GEMM-1 of the loop above alone.  hipBLASLt runs these at 43 us for [88 892, 256] x
+// [256, 256] (2.1 TB/s of the 91 MB it must move); here the wave's X rows sit in registers for all output tiles, the
+// packed weight tiles (16 KB each) stream through a four-deep LDS ring and an output tile leaves as two 16-byte
+// stores per lane.  Memory-bound; ~150 registers, so two workgroups share a CU and cover each other's load phases.
+constexpr int kLinTileBytes = 16384;
+constexpr int kLinBufs = 4;
+
+// fragment f (16 bytes) of out tile ot: k-step s, lane (r, h), element j = W[32 ot + pi(r)][128 h + 8 s + j]
+// (transposed: W[128 h + 8 s + j][32 ot + pi(r)] -- the dX GEMM reads the same weight the other way round)
+__global__ __launch_bounds__(256) void lin256_pack_kernel(const __bf16* __restrict__ W, __bf16* __restrict__ packed, int N,
+                                                         int transposed) {
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= (N / 32) * 1024) return;
+  const int ot = f >> 10, q = f & 1023, lane = q & 63, s = q >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int row = 32 * ot + pi_row(r), k0 = 128 * h + 8 * s;
+  bf16x8 v;
+  if (!transposed) {
+    v = *reinterpret_cast<const bf16x8*>(W + (size_t)row * kD + k0);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = W[(size_t)(k0 + j) * N + row];
+  }
+  *reinterpret_cast<bf16x8*>(packed + (size_t)f * 8) = v;
+}
+
+struct LinArgs {
+  const __bf16* x;       // [T, 256]
+  const __bf16* wp;      // packed weight tiles [N / 32][16 KB]
+  const __bf16* bias;    // [N] or null
+  __bf16* y;             // [T, N]
+  long long T;
+  int N, relu;
+};
+
+__global__ __launch_bounds__(kWaves * 64, 2) void lin256_kernel(const LinArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];       // 4 x 16 KB weight tiles | N floats of bias
+  float* const s_b = reinterpret_cast<float*>(smem + kLinBufs * kLinTileBytes);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const long long tok0 = (long long)blockIdx.x * (kWaves * 32) + wave * 32;
+  const long long tok = tok0 + r;
+  const bool live = tok < a.T;
+  const long long tk = live ? tok : a.T - 1;
+  const bool wave_full = tok0 + 32 <= a.T;
+  const unsigned long long lmask = __builtin_amdgcn_ballot_w64(live);
+  const unsigned lds0 = lds_offset(smem) + lane * 16;
+  const int ntiles = a.N >> 5;
+
+  auto stage = [&](int t) {
+    const char* src = reinterpret_cast<const char*>(a.wp) + (size_t)t * kLinTileBytes;
+    char* dst = smem + (t % kLinBufs) * kLinTileBytes;
+#pragma unroll
+    for (int p = 0; p < 16 / kWaves; ++p) {
+      const int blk = p * kWaves + wave;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(src + blk * 1024 + lane * 16),
+          (__attribute__((address_space(3))) void*)(dst + blk * 1024), 16, 0, 0);
+    }
+  };
+  stage(0);
+  if (ntiles > 1) stage(1);
+  for (int i = threadIdx.x; i < a.N; i += kWaves * 64) s_b[i] = a.bias ? (float)a.bias[i] : 0.f;
+  bf16x8 xf[16];
+  {
+    const __bf16* xrow = a.x + tk * kD + 128 * h;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(xrow + 8 * s);
+  }
+  vm_wait_all();
+  __syncthreads();
+
+  bf16x8 fr[kRing];
+#pragma unroll
+  for (int i = 0; i < kRing; ++i) fr[i] = frag_read(lds0, i * 1024);
+  __bf16* const yrow = a.y + tk * a.N + 16 * h;
+
+  for (int t = 0; t < ntiles; ++t) {
+    // my DMA of the previous iteration has landed (its two stores may stay in flight), then all waves agree
+    if (t >= 1 && wave_full) vm_wait_but2(); else vm_wait_all();
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < ntiles) stage(t + 2);
+    const unsigned w1 = lds0 + (t % kLinBufs) * kLinTileBytes;
+    const unsigned wn = lds0 + ((t + 1) % kLinBufs) * kLinTileBytes;
+    const bool more = t + 1 < ntiles;
+    f32x4 bias[4];
+    const unsigned bl = lds_offset(s_b) + (32 * t + 16 * h) * 4;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bias[g]) : "v"(bl), "n"(g * 16));
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      frag_wait(fr[s % kRing], kRing - 1);     // after the last tile the ring is not refilled: fewer reads are younger
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[s % kRing], xf[s], acc, 0, 0, 0);
+      if (s + kRing < 16) fr[s % kRing] = frag_read(w1, (s + kRing) * 1024);
+      else if (more) fr[s % kRing] = frag_read(wn, (s + kRing - 16) * 1024);
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(bias[0]), "+v"(bias[1]), "+v"(bias[2]), "+v"(bias[3]) : "n"(kRing));
+    bf16x8 o[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float v = acc[i] + bias[i >> 2][i & 3];
+      if (a.relu) v = fmaxf(v, 0.f);
+      o[i >> 3][i & 7] = (__bf16)v;
+    }
+    gstore16_masked(yrow + 32 * t, o[0], lmask);
+    gstore16_masked(yrow + 32 * t + 8, o[1], lmask);
+  }
+}
+
 constexpr size_t kFfnLds = kBufs * kTileBytes + kF * sizeof(float) + kWaves * 2048 + kWaves * kF * sizeof(float);   // 156 KB
 
 // 140 KB of dynamic LDS needs the attribute on every instantiation; set once, outside any stream capture window the
@@ -589,4 +705,41 @@ extern "C" int dskd_ffn_bwd(const void* grad_y, const void* h, const void* packe
   a.in = (const __bf16*)grad_y; a.wp = (const __bf16*)packed_bwd; a.h_in = (const __bf16*)h;
   a.h_out = (__bf16*)grad_h; a.out = (__bf16*)grad_x; a.T = tokens; a.scale = 1.0f / (1.0f - p);
   return launch_ffn<kBwd>(a, (hipStream_t)stream);
+}
+
+extern "C" int64_t dskd_lin256_packed_bytes(int N) {
+  if (N < 32 || N > 512 || N % 32) {
+    fail(DSKD_ERR_INVALID_ARG, "dskd_lin256: N must be a multiple of 32 in [32, 512] (got %d)", N);
+    return -1;
+  }
+  return (int64_t)(N / 32) * kLinTileBytes;
+}
+
+extern "C" int dskd_lin256_pack(const void* w, void* packed, int N, int K, int transposed, int dtype, void* stream) {
+  if (dtype != DSKD_DTYPE_BF16) return fail(DSKD_ERR_INVALID_ARG, "dskd_lin256_pack: bf16 only");
+  if (K != kD || dskd_lin256_packed_bytes(N) < 0) return fail(DSKD_ERR_INVALID_ARG, "dskd_lin256_pack: K must be 256, N a multiple of 32 <= 512 (got K=%d N=%d)", K, N);
+  if (!w || !packed || misaligned(w) || misaligned(packed)) return fail(DSKD_ERR_INVALID_ARG, "dskd_lin256_pack: null or misaligned pointer");
+  const int frags = (N / 32) * 1024;
+  hipLaunchKernelGGL(lin256_pack_kernel, dim3((frags + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const __bf16*)w,
+                     (__bf16*)packed, N, transposed);
+  return check_launch("dskd_lin256_pack");
+}
+
+extern "C" int dskd_lin256_fwd(const void* x, const void* packed, const void* bias, void* y, int64_t tokens, int N, int K,
+                               int relu, int dtype, void* stream) {
+  if (dtype != DSKD_DTYPE_BF16) return fail(DSKD_ERR_INVALID_ARG, "dskd_lin256_fwd: bf16 only");
+  if (K != kD || dskd_lin256_packed_bytes(N) < 0) return fail(DSKD_ERR_INVALID_ARG, "dskd_lin256_fwd: K must be 256, N a multiple of 32 <= 512 (got K=%d N=%d)", K, N);
+  if (!x || !packed || !y || tokens < 0) return fail(DSKD_ERR_INVALID_ARG, "dskd_lin256_fwd: null pointer or negative token count");
+  if (misaligned(x) || misaligned(packed) || misaligned(y)) return fail(DSKD_ERR_INVALID_ARG, "dskd_lin256_fwd: pointers must be 16-byte aligned");
+  if (tokens == 0) return DSKD_OK;
+  const size_t lds = kLinBufs * kLinTileBytes + (size_t)N * sizeof(float);
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&lin256_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLinBufs * kLinTileBytes + 512 * 4);
+  if (attr != hipSuccess) return fail(DSKD_ERR_LAUNCH, "dskd_lin256_fwd: LDS attribute: %s", hipGetErrorString(attr));
+  LinArgs a{};
+  a.x = (const __bf16*)x; a.wp = (const __bf16*)packed; a.bias = (const __bf16*)bias; a.y = (__bf16*)y;
+  a.T = tokens; a.N = N; a.relu = relu;
+  const long long grid = (tokens + kWaves * 32 - 1) / (kWaves * 32);
+  hipLaunchKernelGGL(lin256_kernel, dim3((unsigned)grid), dim3(kWaves * 64), lds, (hipStream_t)stream, a);
+  return check_launch("dskd_lin256_fwd");
 }

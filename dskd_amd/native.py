@@ -45,6 +45,9 @@ _SIGNATURES = {
     "dskd_ffn_pack": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_ffn_fwd": (C.c_int, [_vp] * 6 + [_i64, C.c_int, C.c_int, _f32, C.c_uint64, C.c_uint64, _vp, C.c_int, _vp]),
     "dskd_ffn_bwd": (C.c_int, [_vp] * 7 + [C.c_int, _i64, C.c_int, C.c_int, _f32, C.c_int, _vp]),
+    "dskd_lin256_packed_bytes": (_i64, [C.c_int]),
+    "dskd_lin256_pack": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "dskd_lin256_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_gn_workspace": (_i64, [C.c_int, _i64]),
     "dskd_nhwc_to_nchw_f32": (C.c_int, [_vp, _vp, C.c_int, _i64, C.c_int, _i64, C.c_int, _vp]),
     "dskd_gn_fwd": (C.c_int, [_vp] * 6 + [C.c_int, _i64, C.c_int, C.c_int, _i64, _i64, _f32, C.c_int, _vp]),
@@ -611,6 +614,46 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
     rc = load().dskd_colsum(x.data_ptr(), out.data_ptr(), copies, rows, Cc, DTYPE_BF16, _stream(x))
     _check(rc, "dskd_colsum")
     return out.sum(0) if copies > 1 else out[0]
+
+
+# --------------------------------------------------------------------------- tall Linear with 256 inputs (MFMA kernel)
+def lin256_ok(x: torch.Tensor, n_out: int, k_in: int) -> bool:
+    """Can csrc/ffn_mfma.hip::lin256_kernel take ``x [tokens, 256] @ W^T`` (tall contiguous bf16 CUDA input, 256 inputs,
+    32..512 outputs in steps of 32)?"""
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and k_in == 256 and x.shape[1] == 256
+            and n_out % 32 == 0 and 32 <= n_out <= 512 and x.shape[0] >= 16384 and x.is_contiguous()
+            and x.data_ptr() % 16 == 0 and not os.environ.get("DSKD_LIN256_OFF"))
+
+
+def lin256_pack(w: torch.Tensor, transposed: bool = False) -> torch.Tensor:
+    """Fragment-order image of a bf16 weight: ``w`` [N, 256] (nn.Linear layout), or with ``transposed`` ``w`` [256, N]
+    whose TRANSPOSE is the layer (the input-gradient GEMM ``g @ w`` of a [256, 256] Linear)."""
+    _need_gpu(w)
+    if w.dtype != torch.bfloat16 or not w.is_contiguous() or w.dim() != 2:
+        raise NativeError("lin256_pack: contiguous 2-D bf16 weight expected")
+    n, k = (w.shape[1], w.shape[0]) if transposed else (w.shape[0], w.shape[1])
+    nbytes = load().dskd_lin256_packed_bytes(n)
+    if nbytes < 0 or k != 256:
+        raise NativeError(f"lin256_pack: unsupported shape {tuple(w.shape)} (transposed={transposed})")
+    packed = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w.device)
+    _check(load().dskd_lin256_pack(w.data_ptr(), packed.data_ptr(), n, k, 1 if transposed else 0, DTYPE_BF16, _stream(w)),
+           "dskd_lin256_pack")
+    return packed
+
+
+def lin256(x: torch.Tensor, packed: torch.Tensor, n_out: int, bias: Optional[torch.Tensor] = None, relu: bool = False):
+    """``act(x @ W^T + bias)`` with ``packed`` = :func:`lin256_pack` of W; x [tokens, 256] bf16 -> [tokens, n_out] bf16."""
+    _need_gpu(x, packed)
+    tokens = x.shape[0]
+    y = torch.empty((tokens, n_out), dtype=x.dtype, device=x.device)
+    if bias is not None and (bias.dtype != torch.bfloat16 or not bias.is_contiguous()):
+        bias = bias.to(torch.bfloat16).contiguous()
+    rc = load().dskd_lin256_fwd(x.data_ptr(), packed.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(),
+                                tokens, n_out, 256, 1 if relu else 0, DTYPE_BF16, _stream(x))
+    _check(rc, "dskd_lin256_fwd")
+    global _ffn_flops
+    _ffn_flops += 2 * tokens * 256 * n_out
+    return y
 
 
 # --------------------------------------------------------------------------- GroupNorm of the neck

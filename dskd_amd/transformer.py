@@ -89,7 +89,10 @@ class _TallLinearFn(torch.autograd.Function):
         ctx.chunk, ctx.relu = chunk, relu
         ctx.has_bias = bias is not None
         assert x.dim() == 2           # the caller flattens: the output must not be a view
-        if relu and bias is not None and x.is_cuda:
+        if native.lin256_ok(x, weight.shape[0], weight.shape[1]) and weight.dtype == x.dtype and weight.is_contiguous():
+            # 256 inputs, tall: the hand-written MFMA kernel (memory-bound; hipBLASLt takes ~1.7x as long)
+            y = native.lin256(x, native.lin256_pack(weight), weight.shape[0], bias, relu)
+        elif relu and bias is not None and x.is_cuda:
             y = torch._addmm_activation(bias, x, weight.t())     # bias + ReLU in the GEMM epilogue
         else:
             y = F.linear(x, weight, bias)
@@ -107,7 +110,11 @@ class _TallLinearFn(torch.autograd.Function):
         x2 = x.reshape(-1, x.shape[-1])
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = (g2 @ weight).view(x.shape)
+            if weight.shape[0] == 256 and native.lin256_ok(g2, weight.shape[1], weight.shape[0]) and \
+                    weight.dtype == g2.dtype and weight.is_contiguous():
+                gx = native.lin256(g2, native.lin256_pack(weight, transposed=True), weight.shape[1]).view(x.shape)
+            else:
+                gx = (g2 @ weight).view(x.shape)
         if ctx.needs_input_grad[1]:
             if ctx.chunk is None:
                 gw = g2.t() @ x2
@@ -452,7 +459,7 @@ class Linear(nn.Linear):
     def forward(self, x):
         lp = self.frozen_lp(x.device.type)
         if lp is not None:
-            return F.linear(x, lp[0], lp[1])
+            return tall_linear(x, lp[0], lp[1])       # frozen: F.linear, or the packed MFMA kernel for tall 256-wide inputs
         w, b = self.lp()
         return tall_linear(x, w, b)
 
@@ -479,6 +486,21 @@ def tall_linear(x, weight, bias, relu=False):
                 x2 = x2.to(weight.dtype)
             y = _TallLinearFn.apply(x2, weight, bias, chunk, relu)
         return y.view(*lead, y.shape[-1])
+    if x.is_cuda and not weight.requires_grad and not (torch.is_grad_enabled() and x.requires_grad) and \
+            weight.dtype == torch.bfloat16 and weight.dim() == 2 and weight.is_contiguous():
+        x2 = x.reshape(tokens, x.shape[-1]) if tokens > 0 else None
+        if x2 is not None and x2.dtype != weight.dtype and torch.is_autocast_enabled(dev):
+            x2 = x2.to(weight.dtype)
+        if x2 is not None and native.lin256_ok(x2, weight.shape[0], weight.shape[1]):
+            # frozen weights (the teacher): packed once per weight version, kept on the weight tensor itself
+            hit = weight.__dict__.get("_dskd_lin256") if hasattr(weight, "__dict__") else None
+            if hit is None or hit[0] != weight._version:
+                hit = (weight._version, native.lin256_pack(weight))
+                try:
+                    weight._dskd_lin256 = hit
+                except Exception:
+                    pass
+            return native.lin256(x2, hit[1], weight.shape[0], bias, relu).view(*x.shape[:-1], weight.shape[0])
     y = F.linear(x, weight, bias)
     return torch.relu_(y) if relu else y
 

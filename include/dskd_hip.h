@@ -346,6 +346,20 @@ int dskd_ffn_bwd(const void* grad_y, const void* h, const void* packed_bwd, void
                  int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * y[tokens, N] = act(x[tokens, 256] w^T + bias) for a very tall x (bf16; K = 256, N a multiple of 32 up to 512): the
+ * encoder's 256 -> 256 / 384 nn.Linear layers (value_proj, output_proj, sampling_offsets | attention_weights of ext-mmcv
+ * MultiScaleDeformableAttention) and, with the weight packed transposed, their input-gradient GEMMs, as one hand-written
+ * MFMA kernel (csrc/ffn_mfma.hip: GEMM-1 of the FFN loop).  Memory-bound; hipBLASLt takes 43 us for 88 892 tokens.
+ *   dskd_lin256_pack   w [N, 256] (nn.Linear layout) -> fragment-order image of dskd_lin256_packed_bytes(N) bytes;
+ *                      transposed != 0: w is [256, N] and the image is that of w^T  (dX = grad_y w for a [256, 256] w)
+ *   dskd_lin256_fwd    bias bf16 [N] or NULL; relu != 0 applies max(., 0)
+ * ------------------------------------------------------------------------- */
+int64_t dskd_lin256_packed_bytes(int N);
+int dskd_lin256_pack(const void* w, void* packed, int N, int K, int transposed, int dtype, void* stream);
+int dskd_lin256_fwd(const void* x, const void* packed, const void* bias, void* y, int64_t tokens, int N, int K, int relu,
+                    int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------
  * GroupNorm(32 groups, 256 channels) on a channels_last activation -- the norm of every ChannelMapper level
  * (mmdet/models/necks/channel_mapper.py:10-100: ext-mmcv ConvModule(conv, GN)); replaces F.group_norm and, under
  * autocast, the f32 casts and layout copies around it.  Other channel / group counts are refused.

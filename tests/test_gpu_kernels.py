@@ -1134,3 +1134,50 @@ def test_nchw_f32_of_channels_last_maps(dtype):
         assert out.is_contiguous() and out.dtype == torch.float32 and torch.equal(out, t.contiguous().float())
     t = torch.randn(2, 256, 5, 7, device=DEV)                          # already NCHW: ATen path, same result
     assert torch.equal(native.nchw_f32(t), t)
+
+
+# --------------------------------------------------------------------------- tall Linear with 256 inputs (lin256_kernel)
+@pytest.mark.parametrize("T,N", [(16384 + 77, 256), (20000, 384), (16384, 32), (17000, 512)])
+def test_lin256_vs_float_reference(T, N):
+    """dskd_lin256_fwd (and the transposed pack used for dX) against x @ W^T + b evaluated in fp32 on the CPU from the same
+    bf16 inputs; ragged token counts; with and without bias / ReLU.  Tolerance 8e-3 of the largest magnitude."""
+    g = torch.Generator().manual_seed(N)
+    x = torch.randn(T, 256, generator=g).bfloat16()
+    w = (torch.randn(N, 256, generator=g) / 16).bfloat16()
+    b = (torch.randn(N, generator=g) * 0.1).bfloat16()
+    dx, dw, db = x.to(DEV), w.to(DEV), b.to(DEV)
+    assert native.lin256_ok(dx, N, 256)
+    pk = native.lin256_pack(dw)
+    guard = torch.full((64, N), 3.0, dtype=torch.bfloat16, device=DEV)
+    y = native.lin256(dx, pk, N, db, relu=False)
+    ref = x.float() @ w.float().t() + b.float()
+    assert _close(y, ref, 8e-3)
+    yr = native.lin256(dx, pk, N, None, relu=True)
+    assert _close(yr, torch.relu(x.float() @ w.float().t()), 8e-3) and bool((yr >= 0).all())
+    if N == 256:                                                        # dX = g @ W through the transposed image
+        pkt = native.lin256_pack(dw, transposed=True)
+        gx = native.lin256(dx, pkt, 256)
+        assert _close(gx, x.float() @ w.float(), 8e-3)
+    torch.cuda.synchronize()
+    assert bool((guard == 3.0).all())
+
+
+def test_tall_linear_autograd_uses_the_mfma_kernel_and_matches_the_library(monkeypatch):
+    """transformer.tall_linear on a tall 256-wide bf16 activation: lin256 path (default) against the hipBLASLt path
+    (DSKD_LIN256_OFF=1) -- output, dX, dW, db."""
+    from dskd_amd.transformer import tall_linear
+    torch.manual_seed(4)
+    x = torch.randn(2, 9000, 256, device=DEV).bfloat16()
+    w = (torch.randn(256, 256, device=DEV) / 16).bfloat16()
+    b = (torch.randn(256, device=DEV) * 0.1).bfloat16()
+    up = torch.randn(2, 9000, 256, device=DEV).bfloat16()
+    res = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("DSKD_LIN256_OFF", "1")
+        xi, wi, bi = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = tall_linear(xi, wi, bi)
+        gx, gw, gb = torch.autograd.grad(y, (xi, wi, bi), up)
+        res.append([t.float() for t in (y.detach(), gx, gw, gb)])
+    for a, r in zip(*res):
+        assert float((a - r).abs().max()) <= 1.6e-2 * float(r.abs().max())
