@@ -37,6 +37,7 @@ _SIGNATURES = {
     "dskd_add_ln_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, _f32, _f32,
                                    C.c_uint64, C.c_uint64, _vp, C.c_int, _vp]),
     "dskd_add_ln_bwd": (C.c_int, [_vp] * 9 + [C.c_int, _i64, C.c_int, _f32, C.c_uint64, C.c_uint64, _vp, C.c_int, _vp]),
+    "dskd_add_pos": (C.c_int, [_vp, _vp, _vp, _i64, _i64, C.c_int, C.c_int, _vp]),
     "dskd_bias_act": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_dropout_fwd": (C.c_int, [_vp, _i64, _f32, C.c_uint64, C.c_uint64, _vp, C.c_int, _vp]),
     "dskd_relu_dropout_bwd": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _i64, C.c_int, _f32, C.c_int, _vp]),
@@ -465,6 +466,39 @@ class _AddLNFunction(torch.autograd.Function):
             else:
                 dpos = dq.view(rows // pos_rows, pos_rows, D).sum(0, dtype=torch.float32).view(pos_shape)
         return (dres if dh is None else dh), dres, dgb[0].to(gdtype), dgb[1].to(gdtype), dpos, None, None, None
+
+
+class _AddPosFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pos):
+        x = x.contiguous()
+        pos_f = pos.detach().float().contiguous()
+        D = x.shape[-1]
+        rows, pos_rows = x.numel() // D, pos_f.numel() // D
+        q = torch.empty_like(x)
+        _check(load().dskd_add_pos(x.data_ptr(), pos_f.data_ptr(), q.data_ptr(), rows, pos_rows, D, DTYPE_BF16, _stream(x)),
+               "dskd_add_pos")
+        ctx.meta = (tuple(pos.shape), pos.dtype, rows, pos_rows, D)
+        return q
+
+    @staticmethod
+    def backward(ctx, dq):
+        pos_shape, pos_dtype, rows, pos_rows, D = ctx.meta
+        dpos = None
+        if ctx.needs_input_grad[1]:
+            dpos = dq.to(pos_dtype).view(pos_shape) if pos_rows == rows else \
+                dq.reshape(rows // pos_rows, pos_rows, D).sum(0, dtype=torch.float32).to(pos_dtype).view(pos_shape)
+        return (dq if ctx.needs_input_grad[0] else None), dpos
+
+
+def add_pos(x: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:
+    """``(x + pos).to(x.dtype)`` for a bf16 CUDA token tensor ``x`` [..., D] and a float positional table ``pos`` whose
+    rows repeat over the leading dimension (or match it) -- one streaming pass; anything else goes through ATen."""
+    D = x.shape[-1]
+    if x.is_cuda and x.dtype == torch.bfloat16 and pos.is_floating_point() and pos.shape[-1] == D and D % 8 == 0 \
+            and pos.numel() > 0 and x.numel() % pos.numel() == 0 and x.numel() > 0:
+        return _AddPosFunction.apply(x, pos)
+    return (x + pos).to(x.dtype)
 
 
 def add_layer_norm(h: torch.Tensor, res: torch.Tensor, norm: torch.nn.LayerNorm, p: float = 0.0,

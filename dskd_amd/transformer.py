@@ -1049,7 +1049,7 @@ class DetrTransformerEncoder(TransformerLayerSequence):
             return None
         x = query.to(dtype)
         pos = query_pos.float()
-        q = (x + pos).to(dtype)
+        q = native.add_pos(x, pos)                  # one pass; ATen: generic mixed-dtype add (120 us) + cast
         last = len(self.layers) - 1
         for i, layer in enumerate(self.layers):
             att, ffn = layer.attentions[0], layer.ffns[0]

@@ -281,6 +281,10 @@ int dskd_add_ln_bwd(const void* dy, const void* dq, const void* z, const float* 
                     const float* gamma, void* dres, void* dh, float* dgamma, float* dbeta,
                     int copies, int64_t rows, int D, float drop_p, uint64_t seed, uint64_t offset,
                     const uint64_t* epoch, int dtype, void* stream);
+/* q = bf16(x + pos[r % pos_rows]): x, q device [rows, D] bf16, pos device f32 [pos_rows, D]; D % 8 == 0 -- the first
+ * encoder layer's `query + query_pos` (ext-mmcv MultiScaleDeformableAttention.forward), later ones come from
+ * dskd_add_ln_fwd(want q). */
+int dskd_add_pos(const void* x, const float* pos, void* q, int64_t rows, int64_t pos_rows, int D, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
  * In-place epilogue of a folded convolution:  x = act(x + bias[c] (+ identity))

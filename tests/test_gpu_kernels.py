@@ -1181,3 +1181,19 @@ def test_tall_linear_autograd_uses_the_mfma_kernel_and_matches_the_library(monke
         res.append([t.float() for t in (y.detach(), gx, gw, gb)])
     for a, r in zip(*res):
         assert float((a - r).abs().max()) <= 1.6e-2 * float(r.abs().max())
+
+
+def test_add_pos_equals_the_mixed_dtype_add():
+    """native.add_pos (dskd_add_pos): bit-identical to ``(x + pos).to(bf16)`` with pos in f32, full and broadcast tables,
+    and the same gradients."""
+    x = torch.randn(2, 3001, 256, device=DEV).bfloat16()
+    for pos in (torch.randn(2, 3001, 256, device=DEV), torch.randn(1, 3001, 256, device=DEV)):
+        xi, pi = x.clone().requires_grad_(True), pos.clone().requires_grad_(True)
+        q = native.add_pos(xi, pi)
+        ref = (x.float() + pos).to(torch.bfloat16)
+        assert torch.equal(q, ref)
+        up = torch.randn_like(q)
+        gx, gp = torch.autograd.grad(q, (xi, pi), up)
+        assert torch.equal(gx, up) and gp.shape == pos.shape
+        refp = up.float() if pos.shape[0] == 2 else up.float().sum(0, keepdim=True)
+        assert float((gp - refp).abs().max()) <= 1e-6 * float(refp.abs().max()) + 1e-6
