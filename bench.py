@@ -167,8 +167,8 @@ def cpu_baseline(seed, num_prev, batch=1, timed=3):
 
 
 GEMM_CONV_PATTERNS = ("Cijk_", "ck::", "_ZN2ck", "igemm_", "miopen", "MIOpen", "gemm_xdl", "xdlops", "wrw_", "naive_conv",
-                      "attn_fwd", "bwd_kernel_dk_dv", "bwd_kernel_dq", "ffn_fused_kernel")
-OWN_MFMA_KERNEL = "ffn_fused_kernel"      # csrc/ffn_mfma.hip: the hand-written MFMA kernel on the path
+                      "attn_fwd", "bwd_kernel_dk_dv", "bwd_kernel_dq", "ffn_fused_kernel", "lin256_kernel")
+OWN_MFMA_KERNELS = ("ffn_fused_kernel", "lin256_kernel")      # csrc/ffn_mfma.hip: the hand-written MFMA kernels on the path
 MFMA_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 
 
@@ -202,14 +202,15 @@ def mfma_utilisation(step_fn, dtype):
             t_us += dt
             n += e.count
             names[e.key[:48]] = names.get(e.key[:48], 0.0) + dt
-            if OWN_MFMA_KERNEL in e.key:
+            if any(k in e.key for k in OWN_MFMA_KERNELS):
                 own_us += dt
                 own_n += e.count
     if t_us <= 0:
         return None
     own = None
     if own_us > 0:
-        own = {"kernel": "dskd::ffn_fused_kernel (csrc/ffn_mfma.hip; forward, training forward, backward)", "launches": own_n,
+        own = {"kernel": "dskd::ffn_fused_kernel (encoder FFN: forward, training forward, backward) + dskd::lin256_kernel (tall "
+                         "256-input Linear layers and their dX), csrc/ffn_mfma.hip", "launches": own_n,
                "flops_TFLOP": round(own_flops / 1e12, 3), "kernel_ms": round(own_us / 1e3, 2),
                "achieved_TFLOPs": round(own_flops / (own_us * 1e-6) / 1e12, 1),
                "frac": round(own_flops / (own_us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
@@ -219,9 +220,10 @@ def mfma_utilisation(step_fn, dtype):
     return {"flops_per_step": round(flops / 1e12, 3), "unit": "TFLOP", "gemm_conv_kernel_ms": round(t_us / 1e3, 2),
             "gemm_conv_launches": n, "all_kernel_ms": round(total_us / 1e3, 2), "achieved_TFLOPs": round(tflops, 1),
             "peak_TFLOPs": peak, "frac": round(tflops / peak, 4),
-            "counted": "aten mm/addmm/bmm/convolution/sdpa (FlopCounterMode) + the fused FFN launches (4 * tokens * 256 * 1024 "
-                       "each), forward + backward, teacher + student; time = device time of the hipBLASLt / CK / MIOpen / "
-                       "attention / ffn_fused kernels in one profiled eager step",
+            "counted": "aten mm/addmm/bmm/convolution/sdpa (FlopCounterMode) + the hand-written MFMA launches (fused FFN: 4 * "
+                       "tokens * 256 * 1024 each; lin256: 2 * tokens * 256 * N), forward + backward, teacher + student; time = "
+                       "device time of the hipBLASLt / CK / MIOpen / attention / ffn_fused / lin256 kernels in one profiled "
+                       "eager step",
             "top_kernels_ms": {k: round(v / 1e3, 2) for k, v in top}, "hand_written": own}
 
 
