@@ -494,10 +494,17 @@ __global__ __launch_bounds__(kWaves * 64) void ffn_fused_kernel(const FfnArgs a)
 // y[T, N] = x[T, 256] W^T (+ bias) for a very tall x and N = 32 .. 512 outputs (the encoder's 256 -> 256 / 384 Linear
 // layers and their dX GEMMs): GEMM-1 of the loop above alone.  hipBLASLt runs these at 43 us for [88 892, 256] x
 // [256, 256] (2.1 TB/s of the 91 MB it must move); here the wave's X rows sit in registers for all output tiles, the
-// packed weight tiles (16 KB each) stream through a four-deep LDS ring and an output tile leaves as two 16-byte
-// stores per lane.  Memory-bound; ~150 registers, so two workgroups share a CU and cover each other's load phases.
+// packed weight tiles (16 KB each) stream through a three-deep LDS ring and an output tile leaves as two 16-byte
+// stores per lane.  Memory-bound; ~150 registers and 49 KB of LDS, so three workgroups share a CU and cover each other's
+// load phases (three buffers: tile t in use, t + 1 read ahead, t + 2 landing; 4 buffers / 2 workgroups measured 27.8 vs 24.8 us).
 constexpr int kLinTileBytes = 16384;
-constexpr int kLinBufs = 4;
+#ifndef DSKD_LIN_BUFS
+#define DSKD_LIN_BUFS 3
+#endif
+#ifndef DSKD_LIN_OCC
+#define DSKD_LIN_OCC 3
+#endif
+constexpr int kLinBufs = DSKD_LIN_BUFS;
 
 // fragment f (16 bytes) of out tile ot: k-step s, lane (r, h), element j = W[32 ot + pi(r)][128 h + 8 s + j]
 // (transposed: W[128 h + 8 s + j][32 ot + pi(r)] -- the dX GEMM reads the same weight the other way round)
@@ -527,8 +534,8 @@ struct LinArgs {
   int N, relu;
 };
 
-__global__ __launch_bounds__(kWaves * 64, 2) void lin256_kernel(const LinArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];       // 4 x 16 KB weight tiles | N floats of bias
+__global__ __launch_bounds__(kWaves * 64, DSKD_LIN_OCC) void lin256_kernel(const LinArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];       // kLinBufs x 16 KB weight tiles | N floats of bias
   float* const s_b = reinterpret_cast<float*>(smem + kLinBufs * kLinTileBytes);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
