@@ -15,14 +15,16 @@
 // (K = those 32 hidden units, 8 output tiles x 2 MFMAs), which sums over exactly that register index -- no LDS
 // round trip and no lane movement (cdna_hip_programming.md, "An accumulator tile as the next MFMA's operand").
 // The A operands are the weights, pre-packed once per step into MFMA fragment order (ffn_pack_kernel: 2 x 1 MB) so
-// that a workgroup stages a tile's 32 KB with sixteen-byte LDS-DMA loads (global_load_lds), double buffered, one
-// barrier per tile.  Rows of an A tile are permuted (pi below) so that a lane's 16 accumulator registers are 16
-// CONSECUTIVE hidden units / output features: H, g1, Y, dX are read and written as 32-byte runs per lane
-// (64 bytes per token with the partner lane), plain row-major tensors for the weight-gradient GEMMs that follow.
+// that a workgroup stages a tile's 32 KB with sixteen-byte LDS-DMA loads (global_load_lds) two tiles ahead into four
+// buffers, one barrier per tile.  Rows of an A tile are permuted (pi below) so that a lane's 16 accumulator registers
+// are 16 CONSECUTIVE hidden units / output features: H, g1, Y, dX are plain row-major tensors for the
+// weight-gradient GEMMs that follow (H / g1 are turned through a small LDS scratch into whole 64-byte rows).
 //
 // MFMA work per launch 93 GFLOP (37 us at the 2.5 PFLOP/s dense peak); HBM 272 MB forward / 454 MB backward.
 // Dropout is the mask of dskd_dropout_fwd (Philox4x32-10 on element index / 8, 16-bit fields), never stored: the
-// backward reads it off H like dskd_relu_dropout_bwd.
+// backward reads it off H like dskd_relu_dropout_bwd.  Measured, floor analysis, what was tried: DESIGN.md 4.2c.
+// -DDSKD_FFN_EXPERIMENT_NOSTAGE / _NOREAD / _NOEPI and -DDSKD_FFN_RING=n are TIMING-ONLY ablation builds (wrong
+// results by construction; scratch/r02_ffn_profiles.sh); the second half of the file is lin256_kernel, GEMM-1 alone.
 #include "common.h"
 
 namespace dskd {
