@@ -410,6 +410,18 @@ def advance_dropout_epoch(device) -> None:
     dropout_epoch(device).add_(1 << 32)
 
 
+def _pos_f32(pos):
+    """The f32 table the kernels read for a positional input.  A caller that keeps the table in the compute dtype as the
+    AUTOGRAD input (so that its gradient can be handed back without a cast or a summing pass) attaches the f32 values as
+    ``pos._dskd_f32``; otherwise one cast per call."""
+    if pos is None:
+        return None
+    f = getattr(pos, "_dskd_f32", None)
+    if f is not None and f.shape == pos.shape and f.dtype == torch.float32 and f.is_contiguous():
+        return f
+    return pos.detach().float().contiguous()
+
+
 class _AddLNFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, res, gamma, beta, pos, eps, p, want_q):
@@ -422,7 +434,7 @@ class _AddLNFunction(torch.autograd.Function):
         z = torch.empty_like(h) if train else None
         stats = torch.empty((rows, 2), dtype=torch.float32, device=h.device) if train else None
         gamma_f, beta_f = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
-        pos_f = pos.detach().float().contiguous() if pos is not None else None
+        pos_f = _pos_f32(pos)
         seed, offset = _next_drop_key() if p > 0 else (0, 0)
         rc = load().dskd_add_ln_fwd(
             h.data_ptr(), res.data_ptr(), None if pos_f is None else pos_f.data_ptr(),
@@ -472,7 +484,7 @@ class _AddPosFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, pos):
         x = x.contiguous()
-        pos_f = pos.detach().float().contiguous()
+        pos_f = _pos_f32(pos)
         D = x.shape[-1]
         rows, pos_rows = x.numel() // D, pos_f.numel() // D
         q = torch.empty_like(x)
@@ -486,8 +498,10 @@ class _AddPosFunction(torch.autograd.Function):
         pos_shape, pos_dtype, rows, pos_rows, D = ctx.meta
         dpos = None
         if ctx.needs_input_grad[1]:
-            dpos = dq.to(pos_dtype).view(pos_shape) if pos_rows == rows else \
-                dq.reshape(rows // pos_rows, pos_rows, D).sum(0, dtype=torch.float32).to(pos_dtype).view(pos_shape)
+            if pos_rows == rows:
+                dpos = (dq if dq.dtype == pos_dtype else dq.to(pos_dtype)).view(pos_shape)
+            else:
+                dpos = dq.reshape(rows // pos_rows, pos_rows, D).sum(0, dtype=torch.float32).to(pos_dtype).view(pos_shape)
         return (dq if ctx.needs_input_grad[0] else None), dpos
 
 

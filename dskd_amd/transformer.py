@@ -1049,6 +1049,13 @@ class DetrTransformerEncoder(TransformerLayerSequence):
             return None
         x = query.to(dtype)
         pos = query_pos.float()
+        if dtype != torch.float32 and query_pos.requires_grad:
+            # The table enters autograd in the compute dtype (its gradient -- one [tokens, 256] tensor per layer, summed
+            # over the layers for the level embeddings -- is then handed back and accumulated in bf16: no f32 cast /
+            # summing pass per layer); the kernels read the f32 values attached to it.
+            pos_in = query_pos.to(dtype)
+            pos_in._dskd_f32 = pos.detach()
+            pos = pos_in
         q = native.add_pos(x, pos)                  # one pass; ATen: generic mixed-dtype add (120 us) + cast
         last = len(self.layers) - 1
         for i, layer in enumerate(self.layers):
