@@ -320,13 +320,15 @@ class ResNet(nn.Module):
         if not pairs or not torch.is_grad_enabled():
             return []
         dtype = torch.get_autocast_dtype(x.device.type) if torch.is_autocast_enabled(x.device.type) else x.dtype
-        key = (tuple(b.running_var._version for _, b, _ in pairs), dtype, x.device)
+        key = (tuple(b.running_var._version for _, b, _ in pairs), dtype, x.device, tuple(c.weight.stride() for c, _, _ in pairs))
         if getattr(self, "_fold_key", None) != key:      # BN statistics are frozen: constants
             scales, biases = [], []
             with torch.no_grad():
                 for c, b, _ in pairs:
                     sc = b.weight * torch.rsqrt(b.running_var + b.eps)
-                    scales.append(sc.view(-1, 1, 1, 1).expand_as(c.weight).contiguous())
+                    # same strides as the weight (channels_last models): a stride mismatch sends torch._foreach_mul down
+                    # its per-tensor slow path -- ~80 single launches per step instead of 6
+                    scales.append(torch.empty_like(c.weight).copy_(sc.view(-1, 1, 1, 1).expand_as(c.weight)))
                     biases.append((b.bias - b.running_mean * sc).to(dtype))
             self._fold_key, self._fold_const = key, (scales, biases)
         scales, biases = self._fold_const
