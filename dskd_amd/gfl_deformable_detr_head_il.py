@@ -46,8 +46,9 @@ def filter_scores_and_topk(scores, score_thr, topk, results=None):
     """/root/reference/mmdet/core/utils/misc.py:119-165: ``results`` (a dict of per-row tensors, a tensor or None) is
     gathered with the kept row indices."""
     valid_mask = scores > score_thr
-    scores = scores[valid_mask]
     valid_idxs = torch.nonzero(valid_mask)
+    # scores[valid_mask] in the same (row-major) order, without the second nonzero pass boolean indexing runs itself
+    scores = scores[valid_idxs[:, 0], valid_idxs[:, 1]] if scores.dim() == 2 else scores[valid_mask]
     num_topk = min(topk, valid_idxs.size(0))
     scores, idxs = scores.sort(descending=True)
     scores = scores[:num_topk]
