@@ -109,7 +109,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        T* __restrict__ y, long long HW, long long x_bs, long long y_bs,
-                                                       int span) {
+                                                       int span, int relu) {
   const int g = threadIdx.x & 31, row = threadIdx.x >> 5, b = blockIdx.y;
   const float mean = stats[((size_t)b * kG + g) * 2], rstd = stats[((size_t)b * kG + g) * 2 + 1];
   float ga[8], be[8];
@@ -125,7 +125,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     float v[8];
     load8<T>(xb + p * kC, v);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = v[k] * ga[k] + be[k];
+    for (int k = 0; k < 8; ++k) {
+      v[k] = v[k] * ga[k] + be[k];
+      if (relu) v[k] = fmaxf(v[k], 0.f);
+    }
     store8<T>(yb + p * kC, v);
   }
 }
@@ -134,15 +137,20 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 template <typename T>
 __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                            const float* __restrict__ stats,
-                                                           const float* __restrict__ gamma, double* __restrict__ S,
-                                                           float* __restrict__ dgb, int copies, long long HW,
-                                                           long long x_bs, long long dy_bs, int span) {
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           double* __restrict__ S, float* __restrict__ dgb, int copies,
+                                                           long long HW, long long x_bs, long long dy_bs, int span,
+                                                           int relu) {
   __shared__ float s_part[kRows][kC][2];
   const int g = threadIdx.x & 31, row = threadIdx.x >> 5, b = blockIdx.y;
   const float mean = stats[((size_t)b * kG + g) * 2], rstd = stats[((size_t)b * kG + g) * 2 + 1];
-  float ga[8];
+  float ga[8], fa[8], fb[8];                            // fa, fb: the forward's y = x fa + fb (the ReLU mask is its sign)
 #pragma unroll
-  for (int k = 0; k < 8; ++k) ga[k] = gamma[g * kCpg + k];
+  for (int k = 0; k < 8; ++k) {
+    ga[k] = gamma[g * kCpg + k];
+    fa[k] = ga[k] * rstd;
+    fb[k] = (relu ? beta[g * kCpg + k] : 0.f) - mean * fa[k];
+  }
   const long long p0 = (long long)blockIdx.x * span, p1 = p0 + span < HW ? p0 + span : HW;
   const T* xb = x + (size_t)b * x_bs + g * kCpg;
   const T* db = dy + (size_t)b * dy_bs + g * kCpg;
@@ -156,6 +164,7 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const T* __restrict__
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const float xh = (v[k] - mean) * rstd;
+      if (relu && !(v[k] * fa[k] + fb[k] > 0.f)) d[k] = 0.f;
       dg[k] += d[k] * xh;
       dbt[k] += d[k];
     }
@@ -191,16 +200,21 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const T* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                            const float* __restrict__ stats,
-                                                           const float* __restrict__ gamma, const double* __restrict__ S,
-                                                           T* __restrict__ dx, long long HW, long long x_bs,
-                                                           long long dy_bs, long long dx_bs, int span) {
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const double* __restrict__ S, T* __restrict__ dx, long long HW,
+                                                           long long x_bs, long long dy_bs, long long dx_bs, int span,
+                                                           int relu) {
   const int g = threadIdx.x & 31, row = threadIdx.x >> 5, b = blockIdx.y;
   const float mean = stats[((size_t)b * kG + g) * 2], rstd = stats[((size_t)b * kG + g) * 2 + 1];
   const double n = (double)HW * kCpg;
   const float m1 = (float)(S[((size_t)b * kG + g) * 2] / n), m2 = (float)(S[((size_t)b * kG + g) * 2 + 1] / n);
-  float ga[8];
+  float ga[8], fa[8], fb[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) ga[k] = gamma[g * kCpg + k];
+  for (int k = 0; k < 8; ++k) {
+    ga[k] = gamma[g * kCpg + k];
+    fa[k] = ga[k] * rstd;
+    fb[k] = (relu ? beta[g * kCpg + k] : 0.f) - mean * fa[k];
+  }
   const long long p0 = (long long)blockIdx.x * span, p1 = p0 + span < HW ? p0 + span : HW;
   const T* xb = x + (size_t)b * x_bs + g * kCpg;
   const T* db = dy + (size_t)b * dy_bs + g * kCpg;
@@ -212,6 +226,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const float xh = (v[k] - mean) * rstd;
+      if (relu && !(v[k] * fa[k] + fb[k] > 0.f)) d[k] = 0.f;
       v[k] = rstd * (d[k] * ga[k] - m1 - xh * m2);
     }
     store8<T>(ob + p * kC, v);
@@ -280,7 +295,7 @@ extern "C" int64_t dskd_gn_workspace(int B, int64_t HW) {
 
 extern "C" int dskd_gn_fwd(const void* x, const float* gamma, const float* beta, void* y, double* sums, float* stats,
                            int B, int64_t HW, int C, int groups, int64_t x_batch_stride, int64_t y_batch_stride,
-                           float eps, int dtype, void* stream) {
+                           float eps, int relu, int dtype, void* stream) {
   if (C != kC || groups != kG)
     return fail(DSKD_ERR_INVALID_ARG, "dskd_gn_fwd: 256 channels in 32 groups only (got %d / %d)", C, groups);
   if (!x || !gamma || !beta || !y || !sums || !stats || B < 0 || HW < 0)
@@ -296,20 +311,21 @@ extern "C" int dskd_gn_fwd(const void* x, const float* gamma, const float* beta,
     hipLaunchKernelGGL(gn_stats_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16*)x, sums, (long long)HW, (long long)x_batch_stride, span);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)B), dim3(256), 0, st, sums, stats, (int)grid.x, (long long)HW, eps);
     hipLaunchKernelGGL(gn_apply_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16*)x, stats, gamma, beta, (__bf16*)y,
-                       (long long)HW, (long long)x_batch_stride, (long long)y_batch_stride, span);
+                       (long long)HW, (long long)x_batch_stride, (long long)y_batch_stride, span, relu);
   } else {
     hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), 0, st, (const float*)x, sums, (long long)HW, (long long)x_batch_stride, span);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)B), dim3(256), 0, st, sums, stats, (int)grid.x, (long long)HW, eps);
     hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, stats, gamma, beta, (float*)y,
-                       (long long)HW, (long long)x_batch_stride, (long long)y_batch_stride, span);
+                       (long long)HW, (long long)x_batch_stride, (long long)y_batch_stride, span, relu);
   }
   return check_launch("dskd_gn_fwd");
 }
 
-extern "C" int dskd_gn_bwd(const void* x, const void* grad_y, const float* stats, const float* gamma, void* grad_x,
-                           double* sums, float* grad_gamma_beta, int copies, int B, int64_t HW, int C, int groups,
-                           int64_t x_batch_stride, int64_t gy_batch_stride, int64_t gx_batch_stride, int dtype,
-                           void* stream) {
+extern "C" int dskd_gn_bwd(const void* x, const void* grad_y, const float* stats, const float* gamma, const float* beta,
+                           void* grad_x, double* sums, float* grad_gamma_beta, int copies, int B, int64_t HW, int C,
+                           int groups, int64_t x_batch_stride, int64_t gy_batch_stride, int64_t gx_batch_stride, int relu,
+                           int dtype, void* stream) {
+  if (relu && !beta) return fail(DSKD_ERR_INVALID_ARG, "dskd_gn_bwd: relu needs beta (the mask is the sign of the forward's output)");
   if (C != kC || groups != kG)
     return fail(DSKD_ERR_INVALID_ARG, "dskd_gn_bwd: 256 channels in 32 groups only (got %d / %d)", C, groups);
   if (!x || !grad_y || !stats || !gamma || !grad_x || !sums || !grad_gamma_beta || B < 0 || HW < 0 || copies < 1)
@@ -322,17 +338,17 @@ extern "C" int dskd_gn_bwd(const void* x, const void* grad_y, const float* stats
   const dim3 grid((unsigned)((HW + span - 1) / span), (unsigned)B);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DSKD_DTYPE_BF16) {
-    hipLaunchKernelGGL(gn_bwd_stats_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16*)x, (const __bf16*)grad_y, stats, gamma, sums,
-                       grad_gamma_beta, copies, (long long)HW, (long long)x_batch_stride, (long long)gy_batch_stride, span);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16*)x, (const __bf16*)grad_y, stats, gamma, sums,
+    hipLaunchKernelGGL(gn_bwd_stats_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16*)x, (const __bf16*)grad_y, stats, gamma, beta, sums,
+                       grad_gamma_beta, copies, (long long)HW, (long long)x_batch_stride, (long long)gy_batch_stride, span, relu);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16*)x, (const __bf16*)grad_y, stats, gamma, beta, sums,
                        (__bf16*)grad_x, (long long)HW, (long long)x_batch_stride, (long long)gy_batch_stride,
-                       (long long)gx_batch_stride, span);
+                       (long long)gx_batch_stride, span, relu);
   } else {
-    hipLaunchKernelGGL(gn_bwd_stats_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)grad_y, stats, gamma, sums,
-                       grad_gamma_beta, copies, (long long)HW, (long long)x_batch_stride, (long long)gy_batch_stride, span);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)grad_y, stats, gamma, sums,
+    hipLaunchKernelGGL(gn_bwd_stats_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)grad_y, stats, gamma, beta, sums,
+                       grad_gamma_beta, copies, (long long)HW, (long long)x_batch_stride, (long long)gy_batch_stride, span, relu);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)grad_y, stats, gamma, beta, sums,
                        (float*)grad_x, (long long)HW, (long long)x_batch_stride, (long long)gy_batch_stride,
-                       (long long)gx_batch_stride, span);
+                       (long long)gx_batch_stride, span, relu);
   }
   return check_launch("dskd_gn_bwd");
 }

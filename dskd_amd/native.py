@@ -51,8 +51,8 @@ _SIGNATURES = {
     "dskd_lin256_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_gn_workspace": (_i64, [C.c_int, _i64]),
     "dskd_nhwc_to_nchw_f32": (C.c_int, [_vp, _vp, C.c_int, _i64, C.c_int, _i64, C.c_int, _vp]),
-    "dskd_gn_fwd": (C.c_int, [_vp] * 6 + [C.c_int, _i64, C.c_int, C.c_int, _i64, _i64, _f32, C.c_int, _vp]),
-    "dskd_gn_bwd": (C.c_int, [_vp] * 7 + [C.c_int, C.c_int, _i64, C.c_int, C.c_int, _i64, _i64, _i64, C.c_int, _vp]),
+    "dskd_gn_fwd": (C.c_int, [_vp] * 6 + [C.c_int, _i64, C.c_int, C.c_int, _i64, _i64, _f32, C.c_int, C.c_int, _vp]),
+    "dskd_gn_bwd": (C.c_int, [_vp] * 8 + [C.c_int, C.c_int, _i64, C.c_int, C.c_int, _i64, _i64, _i64, C.c_int, C.c_int, _vp]),
     "dskd_lsap_host": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "dskd_lsap_batched": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "dskd_match_cost": (C.c_int, [_vp] * 7 + [C.c_int] * 3 + [_f32] * 3 + [_vp]),
@@ -716,7 +716,7 @@ def _cl_rows(t: torch.Tensor):
 
 class _GroupNormCLFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, groups, eps):
+    def forward(ctx, x, gamma, beta, groups, eps, relu):
         dt = {torch.float32: DTYPE_F32, torch.bfloat16: DTYPE_BF16}[x.dtype]
         B, Cc, H, W = x.shape
         y = torch.empty_like(x)                       # preserve_format: channels_last
@@ -725,17 +725,18 @@ class _GroupNormCLFunction(torch.autograd.Function):
         stats = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
         gamma_f, beta_f = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
         rc = load().dskd_gn_fwd(x.data_ptr(), gamma_f.data_ptr(), beta_f.data_ptr(), y.data_ptr(), sums.data_ptr(),
-                                stats.data_ptr(), B, H * W, Cc, groups, x.stride(0), y.stride(0), eps, dt, _stream(x))
+                                stats.data_ptr(), B, H * W, Cc, groups, x.stride(0), y.stride(0), eps, 1 if relu else 0, dt,
+                                _stream(x))
         _check(rc, "dskd_gn_fwd")
         if train:
-            ctx.save_for_backward(x, stats, gamma_f)
-            ctx.meta = (dt, groups, gamma.dtype)
+            ctx.save_for_backward(x, stats, gamma_f, beta_f)
+            ctx.meta = (dt, groups, gamma.dtype, relu)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, stats, gamma_f = ctx.saved_tensors
-        dt, groups, gdtype = ctx.meta
+        x, stats, gamma_f, beta_f = ctx.saved_tensors
+        dt, groups, gdtype, relu = ctx.meta
         B, Cc, H, W = x.shape
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
@@ -747,12 +748,12 @@ class _GroupNormCLFunction(torch.autograd.Function):
         copies = _colsum_copies(B * H * W)
         sums = zeros((B, groups, 2), torch.float64, x.device)
         dgb = zeros((copies, 2, Cc), torch.float32, x.device)
-        rc = load().dskd_gn_bwd(x.data_ptr(), dy.data_ptr(), stats.data_ptr(), gamma_f.data_ptr(), dx.data_ptr(),
-                                sums.data_ptr(), dgb.data_ptr(), copies, B, H * W, Cc, groups, x.stride(0), dy_bs,
-                                dx.stride(0), dt, _stream(x))
+        rc = load().dskd_gn_bwd(x.data_ptr(), dy.data_ptr(), stats.data_ptr(), gamma_f.data_ptr(), beta_f.data_ptr(),
+                                dx.data_ptr(), sums.data_ptr(), dgb.data_ptr(), copies, B, H * W, Cc, groups, x.stride(0),
+                                dy_bs, dx.stride(0), 1 if relu else 0, dt, _stream(x))
         _check(rc, "dskd_gn_bwd")
         dgb = dgb.sum(0) if copies > 1 else dgb[0]
-        return dx, dgb[0].to(gdtype), dgb[1].to(gdtype), None, None
+        return dx, dgb[0].to(gdtype), dgb[1].to(gdtype), None, None, None
 
 
 def nchw_f32(t: torch.Tensor) -> torch.Tensor:
@@ -779,10 +780,11 @@ def group_norm_cl_ok(x: torch.Tensor, gn: torch.nn.GroupNorm) -> bool:
             and not os.environ.get("DSKD_GN_ATEN") and _cl_rows(x) == x.shape[1] * x.shape[2] * x.shape[3])
 
 
-def group_norm_cl(x: torch.Tensor, gn: torch.nn.GroupNorm) -> torch.Tensor:
-    """``gn(x)`` for a channels_last [B, 256, H, W] activation in two streaming passes each way; the result has x's
-    dtype and memory format (under autocast: bf16 in, bf16 out -- ATen would cast to f32, copy to NCHW and back)."""
-    return _GroupNormCLFunction.apply(x, gn.weight, gn.bias, gn.num_groups, float(gn.eps))
+def group_norm_cl(x: torch.Tensor, gn: torch.nn.GroupNorm, relu: bool = False) -> torch.Tensor:
+    """``gn(x)`` (``relu(gn(x))`` with ``relu``) for a channels_last [B, 256, H, W] activation in two streaming passes
+    each way; the result has x's dtype and memory format (under autocast: bf16 in, bf16 out -- ATen would cast to f32,
+    copy to NCHW and back)."""
+    return _GroupNormCLFunction.apply(x, gn.weight, gn.bias, gn.num_groups, float(gn.eps), bool(relu))
 
 
 # --------------------------------------------------------------------------- conv epilogue

@@ -28,7 +28,8 @@ class ConvModule(nn.Module):
     def forward(self, x):
         x = self.conv(x)
         if self.norm_name == "gn" and native.group_norm_cl_ok(x, self.gn):
-            x = native.group_norm_cl(x, self.gn)          # channels_last GroupNorm(32, 256): csrc/gn.hip
+            # channels_last GroupNorm(32, 256), with the ReLU of the GFL head's towers folded in: csrc/gn.hip
+            return native.group_norm_cl(x, self.gn, relu=isinstance(self.activate, nn.ReLU))
         elif self.norm_name:
             x = getattr(self, self.norm_name)(x)
         if self.activate is not None:

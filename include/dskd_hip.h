@@ -374,6 +374,8 @@ int dskd_lin256_fwd(const void* x, const void* packed, const void* bias, void* y
  *   sums                   forward: device scratch of dskd_gn_workspace(B, HW) bytes (partial moments, summed in a
  *                          fixed order: the forward is deterministic); backward: device f64 [B, 32, 2], ZEROED by the caller
  *   stats                  device f32 [B, 32, 2] = {mean, rstd}: written by the forward, read by the backward
+ *   relu                   != 0: y = max(GroupNorm(x), 0) (ext-mmcv ConvModule with act_cfg=ReLU: the GFL head's towers); the
+ *                          backward then masks grad_y by the sign of the forward's output, recomputed from x (needs beta)
  *   grad_gamma_beta        device f32 [copies, 2, 256], zeroed by the caller: [k][0] += partial grad_gamma, [k][1] +=
  *                          partial grad_beta (copies as in dskd_add_ln_bwd)
  * ------------------------------------------------------------------------- */
@@ -383,11 +385,12 @@ int64_t dskd_gn_workspace(int B, int64_t HW);
 int dskd_nhwc_to_nchw_f32(const void* x, float* out, int B, int64_t HW, int C, int64_t x_batch_stride, int dtype,
                           void* stream);
 int dskd_gn_fwd(const void* x, const float* gamma, const float* beta, void* y, double* sums, float* stats, int B,
-                int64_t HW, int C, int groups, int64_t x_batch_stride, int64_t y_batch_stride, float eps, int dtype,
+                int64_t HW, int C, int groups, int64_t x_batch_stride, int64_t y_batch_stride, float eps, int relu,
+                int dtype, void* stream);
+int dskd_gn_bwd(const void* x, const void* grad_y, const float* stats, const float* gamma, const float* beta,
+                void* grad_x, double* sums, float* grad_gamma_beta, int copies, int B, int64_t HW, int C, int groups,
+                int64_t x_batch_stride, int64_t gy_batch_stride, int64_t gx_batch_stride, int relu, int dtype,
                 void* stream);
-int dskd_gn_bwd(const void* x, const void* grad_y, const float* stats, const float* gamma, void* grad_x, double* sums,
-                float* grad_gamma_beta, int copies, int B, int64_t HW, int C, int groups, int64_t x_batch_stride,
-                int64_t gy_batch_stride, int64_t gx_batch_stride, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1084,9 +1084,10 @@ def test_ffn_block_node_equals_two_nodes(with_q, monkeypatch):
 
 
 # --------------------------------------------------------------------------- GroupNorm of the neck (csrc/gn.hip)
+@pytest.mark.parametrize("relu", [False, True])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("hw", [(100, 167), (13, 21), (1, 3)])
-def test_group_norm_cl_vs_torch(dtype, hw):
+def test_group_norm_cl_vs_torch(dtype, hw, relu):
     """dskd_gn_fwd / dskd_gn_bwd on a channels_last activation against F.group_norm + autograd evaluated in fp32 on the CPU
     from the same (rounded) inputs: output, input gradient, affine gradients; the incoming gradient is a level's slice of a
     concatenated token tensor (own batch stride), as the encoder's backward hands it over.  Tolerance: f32 1e-4 of the
@@ -1106,13 +1107,15 @@ def test_group_norm_cl_vs_torch(dtype, hw):
     up = up_tok[:, 5:5 + H * W].transpose(1, 2).reshape(B, 256, H, W)          # logical NCHW view of the slice
     xr = x.float().requires_grad_(True)
     yr = F.group_norm(xr, 32, gn.weight, gn.bias, gn.eps)
+    if relu:                                             # ConvModule(conv, GN, ReLU) of the GFL towers
+        yr = torch.relu(yr)
     gxr, gwr, gbr = torch.autograd.grad(yr, (xr, gn.weight, gn.bias), up.float())
 
     gnd = nn.GroupNorm(32, 256).to(DEV)
     gnd.load_state_dict(gn.state_dict())
     xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     assert native.group_norm_cl_ok(xd, gnd)
-    y = native.group_norm_cl(xd, gnd)
+    y = native.group_norm_cl(xd, gnd, relu=relu)
     assert y.dtype == dtype and y.is_contiguous(memory_format=torch.channels_last)
     upd_tok = up_tok.to(DEV)
     upd = upd_tok[:, 5:5 + H * W].transpose(1, 2).unflatten(2, (H, W))         # channels_last rows with a batch stride
@@ -1122,7 +1125,7 @@ def test_group_norm_cl_vs_torch(dtype, hw):
         err = float((a.float().cpu() - r).abs().max())
         assert err <= tol * float(r.abs().max()) + 1e-6, (name, err, float(r.abs().max()))
     with torch.no_grad():                                # inference (the frozen teacher): no statistics saved
-        assert torch.equal(native.group_norm_cl(xd.detach(), gnd), y)
+        assert torch.equal(native.group_norm_cl(xd.detach(), gnd, relu=relu), y)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
