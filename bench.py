@@ -2,7 +2,13 @@
 """Headline benchmark: images/sec of one full teacher+student DSKD distillation training step
 (BASELINE.json metric) on synthetic COCO-shaped 800x1333 batches.
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N>1 either way: under a launcher (``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...``: RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment), or WITHOUT one -- ``python bench.py --gpus N`` finds no
+WORLD_SIZE, starts N fresh rank processes itself (one per GPU, before this process has touched the GPU; the
+reference launches the same way, tools/dist_train_increment.sh:22-28), relays rank 0's JSON line and exits non-zero
+if any rank failed.
 
 Workload (config.workload): BASELINE.json configs[1] -- Deformable-DETR R50 70+10 incremental,
 bf16 autocast for conv/GEMM (fp32 losses, costs, LSAP, MSDA accumulation), batch 4 per GPU.
@@ -227,6 +233,70 @@ def mfma_utilisation(step_fn, dtype):
             "top_kernels_ms": {k: round(v / 1e3, 2) for k, v in top}, "hand_written": own}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """``python bench.py --gpus N`` without a launcher: this (parent) process has NOT initialised the GPU -- it starts N
+    fresh children of the same command line with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (never an exec of a
+    process that has touched the GPU), lets them inherit stdout / stderr (rank 0 prints the one JSON line), and
+    returns the first non-zero exit code (0 if every rank succeeded)."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv),
+                                      env=dict(env, RANK=str(r), LOCAL_RANK=str(r))))
+    rc = 0
+    try:
+        pending = dict(enumerate(procs))
+        while pending:
+            for r, p in list(pending.items()):
+                code = p.poll()
+                if code is None:
+                    continue
+                del pending[r]
+                if code != 0 and rc == 0:
+                    rc = code
+                    print(f"[bench] rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                    for q in pending.values():         # a dead rank leaves the others blocked in a collective
+                        q.terminate()
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def launch_check(world, rank, local_rank):
+    """``--launch-check``: the rank plumbing alone (rendezvous, backend, an all-reduced rank count), no model and no
+    kernels -- runs on a CPU-only host over gloo (tests/test_bench_contract.py) and on a GPU box over RCCL."""
+    use_gpu = torch.cuda.device_count() >= world and not os.environ.get("DSKD_BENCH_REHEARSE")
+    backend = "nccl" if use_gpu else "gloo"
+    device = torch.device("cuda", local_rank) if use_gpu else torch.device("cpu")
+    if use_gpu:
+        torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    count = torch.ones(1, device=device)
+    if world > 1:
+        dist.all_reduce(count)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "rccl_ranks" if use_gpu else "gloo_ranks": int(count.item()),
+                          "backend": backend if world > 1 else None}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -251,11 +321,24 @@ def main():
                     "workload); swin_t = configs[3] (SURVEY.md 8f row 2) and gfl_r50 = configs[4] (GFL CNN head with the "
                     "DSKD feature-map term only), reported in DESIGN.md only")
     ap.add_argument("--seed", type=int, default=111)
+    ap.add_argument("--launch-check", action="store_true", help="only start the ranks, all-reduce a rank count and print "
+                    "it (no model, no kernels; works on a CPU-only host over gloo)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: be the launcher.  Nothing above this line initialises HIP (torch.cuda.device_count() does not).
+        if not args.launch_check and not os.environ.get("DSKD_BENCH_REHEARSE") and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: this host shows {torch.cuda.device_count()} GPU(s)")
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}, "
+                         "or without a launcher (bench.py starts the ranks itself)")
+    if args.launch_check:
+        return launch_check(world, rank, local_rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP hot path has no CPU fallback)")
     # Rehearsal switch (one-GPU box): DSKD_BENCH_REHEARSE=1 runs all ranks on cuda:0 over gloo, to
@@ -268,7 +351,6 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo" if rehearse else "nccl", rank=rank, world_size=world)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     native.load()
 
     torch.backends.cudnn.benchmark = True
@@ -392,8 +474,10 @@ def main():
             print(f"[bench] mfma probe failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
 
     tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    nranks = torch.ones(1, device=device)          # counted over the same backend the gradients travel on
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(nranks)
     dt = float(tmax.item())
     final_loss = float(loss.detach().float().item())
     if getattr(model.bbox_head, "last_lsap_status", None) is not None:
@@ -436,7 +520,8 @@ def main():
         out = {"metric": "images/sec (teacher+student distill step), %s COCO 800x1333" %
                          {"r50": "DefDETR-R50", "swin_t": "DefDETR-SwinT", "gfl_r50": "GFL-R50"}[args.backbone],
                "value": round(ips, 3),
-               "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "unit": "images/sec", "n_gpus": world,
+               ("gloo_ranks_shared_gpu" if rehearse else "rccl_ranks"): int(nranks.item()), "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype,
                "data": "synthetic (N(0,1) images 800x1333, 7 GT + 10 injected teacher detections per image, "

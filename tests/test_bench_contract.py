@@ -50,3 +50,48 @@ def test_command_line_contract(bench, monkeypatch, capsys):
     assert 'add_argument("--gpus", type=int, default=1)' in src          # no flags: one GPU, a K / W that finish in minutes
     assert 'add_argument("--steps", type=int, default=20)' in src and 'add_argument("--warmup", type=int, default=3)' in src
     assert '"higher_is_better": True' in src and '"scaling": "weak"' in src and '"vs_baseline": None' in src
+
+
+def _run_bench(args, env_extra=None, timeout=240):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def test_gpus_2_without_a_launcher_starts_two_ranks():
+    """``python bench.py --gpus 2`` with no WORLD_SIZE in the environment must start its ranks itself
+    (the driver's command shape; the reference: tools/dist_train_increment.sh:22-28).  ``--launch-check`` runs only the
+    rank plumbing -- on this CPU-only host over gloo -- and prints the all-reduced rank count."""
+    import json
+    r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--launch-check"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                                  # rank 0 alone prints
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out.get("gloo_ranks", out.get("rccl_ranks")) == 2
+
+
+def test_a_failing_rank_fails_the_launch():
+    """The parent must not report success (or hang) when a rank dies: a WORLD_SIZE that disagrees with --gpus makes
+    every child exit 1 at once; so does a real run on a host without GPUs."""
+    r = _run_bench(["--gpus", "2", "--launch-check"], {"WORLD_SIZE": "3", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"DSKD_BENCH_REHEARSE": "1"})
+        assert r.returncode != 0 and "needs a GPU" in r.stderr
+
+
+def test_launcher_form_still_works():
+    """``python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`` (the documented form) keeps working."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29731", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--launch-check"], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert '"n_gpus": 2' in r.stdout
