@@ -48,7 +48,7 @@ from dskd_amd.graph_step import GraphedDistillStep  # noqa: E402
 from dskd_amd.runner import build_optimizer  # noqa: E402
 
 CONFIGS = {"r50": os.path.join(ROOT, "configs", "dskd_gfl_deformable_detr_r50_70_10.py"),           # BASELINE configs[1]
-           "swin_t": os.path.join(ROOT, "configs", "dskd_gfl_deformable_detr_swin_t_70_10.py"),      # BASELINE configs[3]
+           "swin_t": os.path.join(ROOT, "configs", "dskd_gfl_deformable_detr_swin_t_40_40.py"),      # BASELINE configs[3]
            "gfl_r50": os.path.join(ROOT, "configs", "dskd_gfl_r50_fpn_40_40.py")}                   # BASELINE configs[4]
 CONFIG = CONFIGS["r50"]
 IMG_H, IMG_W = 800, 1333
@@ -528,7 +528,7 @@ def main():
                        "random-init weights, teacher = perturbed copy)",
                "config": {"workload": {"r50": "Deformable-DETR R50 70+10 incremental DSKD distillation step "
                                               "(BASELINE.json configs[1])",
-                                       "swin_t": "Deformable-DETR Swin-T 70+10 incremental DSKD distillation step "
+                                       "swin_t": "Deformable-DETR Swin-T 40+40 incremental DSKD distillation step "
                                                  "(BASELINE.json configs[3])",
                                        "gfl_r50": "GFL R50-FPN 40+40 incremental step with the DSKD feature-map term "
                                                   "(BASELINE.json configs[4])"}[args.backbone], "global_batch": args.batch * world,

@@ -1,9 +1,10 @@
-# DSKD incremental Deformable-DETR with a Swin-T backbone, 70+10 split (the split of the headline workload, configs[1], on the
-# Swin-T trunk of configs[3]; configs[3] itself is dskd_gfl_deformable_detr_swin_t_40_40.py).  The reference has no Swin + Deformable-DETR config (configs/swin/*
+# DSKD incremental Deformable-DETR with a Swin-T backbone, 40+40 split -- BASELINE.json configs[3] exactly
+# ("Deformable-DETR Swin-T backbone 40+40").  Head, losses, optimizer (lr 4e-4) and schedule
+# are those of the reference's 40+40 R50 config (configs/deformable_detr/chaosuan_gfl_deformable_detr_40_r50_8x4_1x_qoqo_il.py).  The reference has no Swin + Deformable-DETR config (configs/swin/*
 # are Mask-RCNN / RetinaNet): this composes type='SwinTransformer' (kwargs of
 # /root/reference/configs/swin/retinanet_swin-t-p4-w7_fpn_1x_coco.py) with
 # ChannelMapper(in_channels=[192, 384, 768]) and the DSKD head of the R50 config.
-num_prev, num_curr = 70, 10
+num_prev, num_curr = 40, 40
 
 model = dict(
     type='DeformableDETR_il',
@@ -53,7 +54,7 @@ data = dict(samples_per_gpu=4, workers_per_gpu=0, cat_split_load='auto',
                        img_size=(800, 1333), n_gt=7, num_images=64))
 task_nums = len(catsplit)
 workflow = [('train', 1)]
-optimizer = [dict(type='AdamW', lr=2e-4, weight_decay=0.0001,
+optimizer = [dict(type='AdamW', lr=4e-4, weight_decay=0.0001,
                   paramwise_cfg=dict(custom_keys={'backbone': dict(lr_mult=0.1), 'sampling_offsets': dict(lr_mult=0.1),
                                                   'reference_points': dict(lr_mult=0.1)}))] * task_nums
 optimizer_config = dict(grad_clip=dict(max_norm=0.1, norm_type=2))

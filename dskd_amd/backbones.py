@@ -72,10 +72,17 @@ def _conv1x1_gemm_wgrad(conv, x, w):
     return _token_chunk(tokens, w.numel())
 
 
+_CONV1X1_MFMA = not os.environ.get("DSKD_CONV1X1_LIB")      # A/B switch: the library convolution + bias_act pass
+
+
 def _conv_epilogue(conv, x, w, b, relu, identity):
     """Folded convolution WITHOUT bias, then ONE in-place pass for bias (+ identity) (+ ReLU)
     (native.bias_act).  PyTorch's MIOpen path would run the bias add, the residual add and the
     ReLU as separate launches that each stream the whole activation."""
+    if _CONV1X1_MFMA and native.conv1x1_ok(x, w, conv) and (b is None or b.shape[0] == w.shape[0]) and \
+            (identity is None or identity.is_cuda):
+        # 1x1 convolution + folded-BN shift + residual + ReLU as ONE hand-written MFMA launch (csrc/gemm_nt.hip)
+        return native.conv1x1(x, w, b, identity, relu, conv.stride[0])
     chunk = _conv1x1_gemm_wgrad(conv, x, w) if os.environ.get("DSKD_CONV_WGRAD_GEMM") else None
     if chunk is not None:
         y = _Conv1x1Fn.apply(x, w, chunk)

@@ -1,0 +1,289 @@
+// Y[M, N] = act(X[M, K] W[N, K]^T + bias[N] (+ R[M, N])) in bf16 with f32 accumulation on the matrix cores of gfx950 --
+// the 1x1 convolutions of the ResNet trunk and of the ChannelMapper on channels_last activations, where the activation
+// IS the [B*H*W, Cin] matrix and the folded convolution weight [Cout, Cin, 1, 1] IS W.
+//
+// Replaces, for every Bottleneck (mmdet/models/backbones/resnet.py:271-303: conv1 -> bn1 -> relu, conv3 -> bn3 ->
+// (+ identity) -> relu, downsample conv -> bn) and for ChannelMapper's lateral convolutions
+// (mmdet/models/necks/channel_mapper.py:90-100), the library convolution + the separate bias / residual / ReLU pass
+// (csrc/biasact.hip): the folded-BN shift, the residual and the ReLU are applied to the f32 accumulators and the
+// output is written once.  The same kernel with the transposed weight is the input-gradient GEMM dX = dY W.
+//
+// Why hand-written: these GEMMs are short in K and N (64 .. 2048) and very tall (M = 4 200 .. 267 200 at B = 4,
+// 800 x 1333), i.e. mostly memory-bound streaming of the activation; the library's implicit-GEMM kernels run them at
+// ~270 TFLOP/s with a second pass over every output for the epilogue (profiles/r02_step_breakdown.txt).
+//
+// Structure (cdna_hip_programming.md section 5):
+//  * workgroup = 4 waves, tile 128 tokens x 128 outputs (x 64 outputs when N == 64); every wave owns 64 outputs x
+//    (64 | 32) tokens = 2 x (2 | 1) accumulator tiles of v_mfma_f32_32x32x16_bf16.  The WEIGHT is the A operand and the
+//    activation the B operand, so a lane ends up with ONE token and -- rows of the A tile permuted by pi (as in
+//    ffn_mfma.hip) -- 16 CONSECUTIVE output channels per accumulator tile: 32 contiguous bytes per lane, bias / residual
+//    / ReLU in registers, two 16-byte stores.
+//  * both operands are K-contiguous (16 bytes = the 8 k of one lane's fragment), so they go global -> LDS with 16-byte
+//    LDS-DMA (global_load_lds), no register staging and no pack kernel.  K is walked in stages of 64: two panels of
+//    [rows][32 k] = 64-byte rows per operand; the 16-byte chunk c of row r sits at chunk position c ^ ((r >> 2) & 3) --
+//    applied on the SOURCE address, the LDS image of one DMA instruction stays lane-linear (16 rows x 64 B) -- which
+//    makes every ds_read_b128 fragment read conflict-free (the four 16-lane groups of that instruction cover rows
+//    {0-3, 12-15, 20-27}, ...: four different (r >> 2) & 3 for every r & 3; pi permutes rows inside those groups).
+//  * two LDS stages (48 | 64 KB per workgroup -> 3 | 2 workgroups per CU cover each other's waits); the DMA of stage
+//    k + 1 is issued before stage k is consumed and retired with a COUNTED s_waitcnt vmcnt; raw s_barrier.
+//  * a strided 1x1 convolution (the downsample branch: stride 2) only changes the row address of the activation.
+//  * blockIdx -> tile: XCD-contiguous (xcd_remap), output tiles of one token tile adjacent, so the activation tile is
+//    fetched from HBM once and re-read from that XCD's L2.
+#include "common.h"
+#include <stdlib.h>
+
+namespace dskd {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int pi_row(int r) { return (r & 3) + 4 * (r >> 3) + 16 * ((r >> 2) & 1); }
+
+struct GemmArgs {
+  const __bf16* x;       // activation rows (see the row map below)
+  const __bf16* w;       // [N, K]
+  const __bf16* bias;    // [N] or null
+  const __bf16* res;     // [M, N] or null: added before the activation
+  __bf16* y;             // [M, N]
+  long long M;
+  int N, K, relu;
+  // row map: output row m = (img, ho, wo) reads the activation row ((img * Hi + s * ho) * Wi + s * wo); s == 0: row m
+  int s, HoWo, Wo, Hi, Wi;
+};
+
+__device__ __forceinline__ unsigned lds_offset(const void* p) {
+  return (unsigned)(unsigned long)((const __attribute__((address_space(3))) char*)p);
+}
+__device__ __forceinline__ bf16x8 frag_read(unsigned lds_addr) {
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(lds_addr));
+  return v;
+}
+
+template <int BN, int MT, int NS>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs a) {
+  constexpr int WN = BN / 64;              // waves along the outputs
+  constexpr int WM = 4 / WN;               // waves along the tokens
+  constexpr int BM = WM * MT * 32;         // 128
+  static_assert(BM == 128, "tile");
+  constexpr int PX = BM * 64, PW = BN * 64;          // bytes of one 32-k panel
+  constexpr int STAGE = 2 * (PX + PW);
+  constexpr int WRB = BN / 64;             // 16-row weight blocks loaded per wave (activation: always 2)
+  constexpr int LOADS = 4 + 2 * WRB;       // LDS-DMA instructions per wave and stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];      // NS stages
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int wn = wave % WN, wm = wave / WN;
+
+  const int tiles_n = a.N / BN;
+  const int vb = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = vb % tiles_n;
+  const long long tm = vb / tiles_n;
+  const long long m0 = tm * BM;
+  const int n0 = tn * BN;
+
+  // ---- per-lane source pointers of the LDS-DMA: lane i of an instruction fills row (i >> 2), chunk position (i & 3)
+  const int lr = lane >> 2;
+  const int csw = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;        // logical chunk held at that position (bytes)
+  const char* xp[2];
+  const char* wp[WRB];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    long long m = m0 + wave * 32 + j * 16 + lr;
+    if (m >= a.M) m = a.M - 1;                                  // rows past the end: any valid row, never stored
+    long long row = m;
+    if (a.s) {
+      const long long img = m / a.HoWo;
+      const int rem = (int)(m - img * a.HoWo);
+      const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+      row = (img * a.Hi + (long long)a.s * ho) * a.Wi + (long long)a.s * wo;
+    }
+    xp[j] = reinterpret_cast<const char*>(a.x) + row * a.K * 2 + csw;
+  }
+#pragma unroll
+  for (int j = 0; j < WRB; ++j)
+    wp[j] = reinterpret_cast<const char*>(a.w) + (long long)(n0 + (wave * WRB + j) * 16 + lr) * a.K * 2 + csw;
+
+  auto issue = [&](int kt, int buf) {
+    char* sx = smem + buf * STAGE;
+    char* sw = sx + 2 * PX;
+    const int kb = kt * 128;                                    // bytes along K
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xp[j] + kb + p * 64),
+                                         (__attribute__((address_space(3))) void*)(sx + p * PX + (wave * 2 + j) * 1024),
+                                         16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < WRB; ++j)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp[j] + kb + p * 64),
+                                         (__attribute__((address_space(3))) void*)(sw + p * PW + (wave * WRB + j) * 1024),
+                                         16, 0, 0);
+  };
+
+  // ---- fragment addresses inside a stage (k-step ks of 4: panel ks >> 1, logical chunk 2 (ks & 1) + h)
+  const unsigned base = lds_offset(smem);
+  unsigned xa[MT][2], wa[2][2];           // [tile][ks & 1]; the panel adds PX / PW
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int c = 2 * e + h;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = (wm * MT + mt) * 32 + r;
+      xa[mt][e] = base + row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int row = (wn * 2 + nt) * 32 + pi_row(r);
+      wa[nt][e] = base + 2 * PX + row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
+    }
+  }
+
+  f32x16 acc[MT][2];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+
+  // NS stages in LDS, the DMA runs NS - 1 stages ahead of the MFMAs: with few tiles per CU (the deep-K layers at
+  // 4 200 .. 16 800 tokens) a stage would otherwise cost one full memory latency.
+  const int nk = a.K >> 6;
+#pragma unroll
+  for (int p = 0; p < NS - 1; ++p)
+    if (p < nk) issue(p, p);
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + NS - 1 < nk) issue(kt + NS - 1, (kt + NS - 1) % NS);
+    // stage kt has landed (mine): all but the loads of the stages behind it are done
+    const int ahead = min(NS - 1, nk - 1 - kt);
+    if (ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LOADS) : "memory");
+    else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                       // ... and everybody's
+    const unsigned so = (kt % NS) * STAGE;
+    bf16x8 wf[4][2], xf[4][MT];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) wf[ks][nt] = frag_read(wa[nt][ks & 1] + so + (ks >> 1) * PW);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) xf[ks][mt] = frag_read(xa[mt][ks & 1] + so + (ks >> 1) * PX);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      // LDS returns in order: all but the (3 - ks) * (2 + MT) youngest reads are done
+      if constexpr (MT == 2) {
+        if (ks == 0) asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(wf[0][0]), "+v"(wf[0][1]), "+v"(xf[0][0]), "+v"(xf[0][1]));
+        if (ks == 1) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(wf[1][0]), "+v"(wf[1][1]), "+v"(xf[1][0]), "+v"(xf[1][1]));
+        if (ks == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wf[2][0]), "+v"(wf[2][1]), "+v"(xf[2][0]), "+v"(xf[2][1]));
+        if (ks == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[3][0]), "+v"(wf[3][1]), "+v"(xf[3][0]), "+v"(xf[3][1]));
+      } else {
+        if (ks == 0) asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(wf[0][0]), "+v"(wf[0][1]), "+v"(xf[0][0]));
+        if (ks == 1) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(wf[1][0]), "+v"(wf[1][1]), "+v"(xf[1][0]));
+        if (ks == 2) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(wf[2][0]), "+v"(wf[2][1]), "+v"(xf[2][0]));
+        if (ks == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[3][0]), "+v"(wf[3][1]), "+v"(xf[3][0]));
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][nt], xf[ks][mt], acc[mt][nt], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_barrier();       // every wave has read this stage before a later DMA overwrites it
+  }
+
+  // ---- epilogue: lane = one token, 16 consecutive outputs per accumulator tile
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const long long m = m0 + (wm * MT + mt) * 32 + r;
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int n = n0 + (wn * 2 + nt) * 32 + 16 * h;
+      float v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = acc[mt][nt][i];
+      if (a.bias) {
+        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(a.bias + n), b1 = *reinterpret_cast<const bf16x8*>(a.bias + n + 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { v[i] += (float)b0[i]; v[8 + i] += (float)b1[i]; }
+      }
+      if (a.res) {
+        const __bf16* rp = a.res + m * a.N + n;
+        const bf16x8 r0 = *reinterpret_cast<const bf16x8*>(rp), r1 = *reinterpret_cast<const bf16x8*>(rp + 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { v[i] += (float)r0[i]; v[8 + i] += (float)r1[i]; }
+      }
+      bf16x8 o0, o1;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float p = v[i], q = v[8 + i];
+        if (a.relu) { p = fmaxf(p, 0.f); q = fmaxf(q, 0.f); }
+        o0[i] = (__bf16)p;
+        o1[i] = (__bf16)q;
+      }
+      __bf16* yp = a.y + m * a.N + n;
+      *reinterpret_cast<bf16x8*>(yp) = o0;
+      *reinterpret_cast<bf16x8*>(yp + 8) = o1;
+    }
+  }
+}
+
+template <int BN, int MT, int NS>
+int launch_gemm(const GemmArgs& a, hipStream_t st) {
+  constexpr int LDS = NS * 2 * (128 * 64 + BN * 64);
+  auto kern = gemm_nt_kernel<BN, MT, NS>;
+  int dev = 0;
+  static bool done[64] = {};              // the attribute is per device: set it once on each
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!done[dev]) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return fail(DSKD_ERR_LAUNCH, "dskd_gemm_nt: cannot reserve %d bytes of LDS", LDS);
+    done[dev] = true;
+  }
+  const long long tiles = ((a.M + 127) / 128) * (a.N / BN);
+  if (tiles > 0x7FFFFFFFll) return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_nt: too many tiles");
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), LDS, st, a);
+  return check_launch("dskd_gemm_nt");
+}
+
+}  // namespace
+}  // namespace dskd
+
+using namespace dskd;
+
+extern "C" int dskd_gemm_nt(const void* x, const void* w, const void* bias, const void* res, void* y, int64_t M, int N, int K,
+                            int relu, int stride, int Ho, int Wo, int Hi, int Wi, int dtype, void* stream) {
+  if (dtype != DSKD_DTYPE_BF16) return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_nt: bf16 only");
+  if (!x || !w || !y || M < 0) return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_nt: null pointer or negative row count");
+  if (N <= 0 || K <= 0 || (N & 63) || (K & 63))
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_nt: N and K must be positive multiples of 64 (got N=%d K=%d)", N, K);
+  auto mis = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
+  if (mis(x) || mis(w) || mis(y) || (bias && mis(bias)) || (res && mis(res)))
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_nt: pointers must be 16-byte aligned");
+  if (stride < 0 || (stride > 0 && (Ho <= 0 || Wo <= 0 || Hi <= 0 || Wi <= 0 || M % ((int64_t)Ho * Wo) != 0 ||
+                                    (int64_t)stride * (Ho - 1) >= Hi || (int64_t)stride * (Wo - 1) >= Wi)))
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_nt: bad row map (stride=%d Ho=%d Wo=%d Hi=%d Wi=%d)", stride, Ho, Wo, Hi, Wi);
+  if (M == 0) return DSKD_OK;
+  GemmArgs a;
+  a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = (const __bf16*)bias; a.res = (const __bf16*)res;
+  a.y = (__bf16*)y; a.M = M; a.N = N; a.K = K; a.relu = relu;
+  a.s = stride; a.HoWo = stride ? Ho * Wo : 1; a.Wo = stride ? Wo : 1; a.Hi = Hi; a.Wi = Wi;
+  hipStream_t st = (hipStream_t)stream;
+  // Stages in LDS: with at most ~2 tiles per CU and a deep K the DMA must run several stages ahead (one workgroup per
+  // CU, 4 x 32 KB); with many tiles per CU two stages and two or three workgroups per CU hide the latency better.
+  const long long tiles = ((M + 127) / 128) * (N / (N % 128 == 0 ? 128 : 64));
+  (void)tiles;
+  int ns = 2;      // measured (scratch/r03_conv1x1.py): four stages lose everywhere -- the fill RATE binds, not its latency
+  if (const char* e = getenv("DSKD_GEMM_NS")) { const int v = atoi(e); if (v == 2 || v == 4) ns = v; }
+  if (N % 128 == 0) return ns == 4 ? launch_gemm<128, 2, 4>(a, st) : launch_gemm<128, 2, 2>(a, st);
+  return ns == 4 ? launch_gemm<64, 1, 4>(a, st) : launch_gemm<64, 1, 2>(a, st);
+}

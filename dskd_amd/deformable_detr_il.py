@@ -91,7 +91,8 @@ class TeacherAhead:
                 with no_gc_during_capture(), torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local"):
                     feats, outs = self._forward(static, img_metas, amp_dtype)
                 g.replay()
-                entries.append(dict(graph=g, img=static, feats=feats, outs=outs))
+                pins = getattr(self.det.teacher_model.bbox_head, "graph_pins", lambda d: [])(img.device)
+                entries.append(dict(graph=g, img=static, feats=feats, outs=outs, keepalive=pins))
             torch.cuda.synchronize(img.device)
         except Exception as e:  # noqa: BLE001  (an accelerator, not a requirement)
             import warnings

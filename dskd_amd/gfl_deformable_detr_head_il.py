@@ -32,7 +32,7 @@ from .bbox import bbox_cxcywh_to_xyxy, bbox_overlaps, bbox_xyxy_to_cxcywh
 from .builder import HEADS, build_assigner, build_loss, build_positional_encoding, build_sampler, build_transformer
 from .dist import reduce_mean
 from .transformer import Linear, inverse_sigmoid, lowp_params
-from .utils import GraphedFunction, deepcopy_without, device_const
+from .utils import GraphedFunction, const_cache_snapshot, deepcopy_without, device_const
 
 
 def multi_apply(func, *args, **kwargs):
@@ -201,6 +201,7 @@ class GFLDeformableDETRHead_il(nn.Module):
     # low-precision copies live in persistent buffers, ``lowp_params``), and the dropout kernels take the per-step part
     # of their key from a device word (``native.advance_dropout_epoch``).  DSKD_EAGER_HEAD=1 disables.
     graph_head = not os.environ.get("DSKD_EAGER_HEAD")
+    max_head_graphs = 4          # captured batch signatures kept at once (multi-scale training: the rest stays eager)
 
     def _forward_graphed(self, mlvl_feats, img_metas, lp):
         from .dist import hipgraphs_allowed
@@ -223,6 +224,8 @@ class GFLDeformableDETRHead_il(nn.Module):
         sig = (tuple((tuple(f.shape), f.dtype) for f in feats), (H, W), dtype, drops, len(statics))
         graphs = self.__dict__.setdefault("_head_graphs", {})
         g = graphs.get(sig)
+        if g is None and sum(1 for v in graphs.values() if v not in (None, False)) >= self.max_head_graphs:
+            return None                                   # each captured signature pins a full activation pool: stay eager
         if g is not None and g is not False and not g.matches(feats, statics):
             g = graphs[sig] = None                        # parameters were re-allocated (.to(), load): capture again
         if g is None:
@@ -272,6 +275,12 @@ class GFLDeformableDETRHead_il(nn.Module):
                 warnings.warn(f"student-head hipGraph capture failed ({type(e).__name__}: {e}); staying eager")
                 torch.cuda.synchronize(dev)
                 g = False
+            if g is not False:
+                # The captured kernels hold raw pointers into tensors owned by caches that evict or re-allocate
+                # (positional encodings, reference points, ones rows, the MSDA backward workspace, device constants, the
+                # dropout epoch word): the graph pins the objects it was captured on, so a second shape -- or a larger
+                # workspace -- can replace the cache ENTRY without freeing what this graph reads.
+                g.keepalive = self.graph_pins(dev)
             graphs[sig] = g
         if g is False:
             return None
@@ -280,14 +289,22 @@ class GFLDeformableDETRHead_il(nn.Module):
         shapes = device_const([tuple(f.shape[-2:]) for f in feats], torch.long, dev)
         return cls, box, (memory, shapes), hs
 
+    def graph_pins(self, dev):
+        """References a hipGraph captured over this head's forward must hold (see ``_forward_graphed``): every tensor the
+        captured kernels read out of an evicting / re-allocating cache."""
+        from . import transformer as _tr
+        return [dict(self.__dict__.get("_pe_cache", {})), dict(self.transformer.__dict__.get("_ref_cache", {})),
+                list(_tr._ONES.values()), native.graph_pins(dev), const_cache_snapshot()]
+
     def _forward(self, mlvl_feats, img_metas):
         batch_size = mlvl_feats[0].size(0)
         input_img_h, input_img_w = img_metas[0]["batch_input_shape"]
         full = all(tuple(m["img_shape"][:2]) == (input_img_h, input_img_w) for m in img_metas)
         key = (full, batch_size, input_img_h, input_img_w, tuple(f.shape[-2:] for f in mlvl_feats), mlvl_feats[0].device)
-        if full and getattr(self, "_pe_key", None) == key:
+        pe_cache = self.__dict__.setdefault("_pe_cache", {})      # per shape: a captured head graph reads these tensors
+        if full and key in pe_cache:
             # un-padded batch: masks are all False and the sine encodings are constants
-            mlvl_masks, mlvl_positional_encodings = self._pe_cache
+            mlvl_masks, mlvl_positional_encodings = pe_cache[key]
         else:
             img_masks = mlvl_feats[0].new_ones((batch_size, input_img_h, input_img_w), dtype=torch.float32)
             for img_id in range(batch_size):
@@ -298,7 +315,9 @@ class GFLDeformableDETRHead_il(nn.Module):
                 mlvl_masks.append(F.interpolate(img_masks[None], size=feat.shape[-2:]).to(torch.bool).squeeze(0))
                 mlvl_positional_encodings.append(self.positional_encoding(mlvl_masks[-1]))
             if full:
-                self._pe_key, self._pe_cache = key, (mlvl_masks, mlvl_positional_encodings)
+                if len(pe_cache) >= 16:                   # bounded; an entry a graph was captured on is pinned by that graph
+                    pe_cache.pop(next(iter(pe_cache)))
+                pe_cache[key] = (mlvl_masks, mlvl_positional_encodings)
         hs, init_reference, inter_references, memory, _, _ = self.transformer(
             mlvl_feats, mlvl_masks, self.query_embedding.weight, mlvl_positional_encodings,
             reg_branches=None, cls_branches=None, all_valid=full)
@@ -495,6 +514,7 @@ class GFLDeformableDETRHead_il(nn.Module):
             try:
                 with torch.autocast(cls_scores.device.type, enabled=False):
                     g = GraphedFunction(lambda *a: self.loss_layers_dense(*a), args)
+                g.keepalive = [const_cache_snapshot()]       # the LRU of device constants may evict what the graph reads
             except Exception as e:  # noqa: BLE001  (an accelerator, not a requirement)
                 import warnings
                 warnings.warn(f"dense-loss hipGraph capture failed ({type(e).__name__}: {e}); staying eager")

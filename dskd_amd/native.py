@@ -49,6 +49,7 @@ _SIGNATURES = {
     "dskd_lin256_packed_bytes": (_i64, [C.c_int]),
     "dskd_lin256_pack": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_lin256_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "dskd_gemm_nt": (C.c_int, [_vp] * 5 + [_i64] + [C.c_int] * 9 + [_vp]),
     "dskd_gn_workspace": (_i64, [C.c_int, _i64]),
     "dskd_nhwc_to_nchw_f32": (C.c_int, [_vp, _vp, C.c_int, _i64, C.c_int, _i64, C.c_int, _vp]),
     "dskd_gn_fwd": (C.c_int, [_vp] * 6 + [C.c_int, _i64, C.c_int, C.c_int, _i64, _i64, _f32, C.c_int, C.c_int, _vp]),
@@ -273,6 +274,16 @@ def _msda_bwd_workspace(device, B, Nv, Nq, heads, L, P) -> torch.Tensor:
             raise NativeError("msda backward workspace must be allocated before a hipGraph capture (run one eager step)")
         ws = _msda_ws_cache[key] = torch.zeros(need, dtype=torch.uint8, device=device)
     return ws
+
+
+def graph_pins(device):
+    """What a hipGraph captured on ``device`` must keep alive of this module's caches: the MSDA backward workspace
+    (re-allocated when a larger shape arrives -- the captured launches keep writing their stray list into the one they
+    were captured on) and the dropout epoch word."""
+    device = torch.device(device)
+    if device.index is None and device.type == "cuda":
+        device = torch.device("cuda", torch.cuda.current_device())
+    return [t for t in (_msda_ws_cache.get(device), _drop_epochs.get(device)) if t is not None]
 
 
 class _MSDAFunction(torch.autograd.Function):
@@ -702,6 +713,79 @@ def lin256(x: torch.Tensor, packed: torch.Tensor, n_out: int, bias: Optional[tor
     global _ffn_flops
     _ffn_flops += 2 * tokens * 256 * n_out
     return y
+
+
+# --------------------------------------------------------------------------- 1x1 convolution + epilogue (MFMA GEMM)
+def conv1x1_ok(x: torch.Tensor, w: torch.Tensor, conv) -> bool:
+    """Can csrc/gemm_nt.hip take this convolution: 1x1, stride 1 or 2, no padding / dilation / groups, on a channels_last
+    bf16 CUDA activation with channel counts that are multiples of 64?"""
+    return (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+            and conv.kernel_size == (1, 1) and conv.stride in ((1, 1), (2, 2)) and conv.padding == (0, 0)
+            and conv.dilation == (1, 1) and conv.groups == 1 and x.shape[1] % 64 == 0 and w.shape[0] % 64 == 0
+            and x.numel() > 0 and x.is_contiguous(memory_format=torch.channels_last) and x.data_ptr() % 16 == 0
+            and w.data_ptr() % 16 == 0 and (w.stride(1) == 1 or w.is_contiguous()) and w.stride(0) == w.shape[1])
+
+
+def gemm_nt_raw(x, w2d, bias, res, M, N, K, relu, out, stride=0, Ho=0, Wo=0, Hi=0, Wi=0):
+    """``out[M, N] = act(x[M, K] w2d[N, K]^T + bias (+ res))`` -- raw launch of dskd_gemm_nt (bf16, no autograd)."""
+    rc = load().dskd_gemm_nt(x.data_ptr(), w2d.data_ptr(), None if bias is None else bias.data_ptr(),
+                             None if res is None else res.data_ptr(), out.data_ptr(), M, N, K, 1 if relu else 0, stride,
+                             Ho, Wo, Hi, Wi, DTYPE_BF16, _stream(x))
+    _check(rc, "dskd_gemm_nt")
+    global _ffn_flops
+    _ffn_flops += 2 * M * N * K
+    return out
+
+
+class _Conv1x1Function(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, identity, relu, stride):
+        B, K, H, W = x.shape
+        N = w.shape[0]
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        y = torch.empty((B, N, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        gemm_nt_raw(x, w, bias, identity, B * Ho * Wo, N, K, relu, y, *((0, 0, 0, 0, 0) if stride == 1 else
+                                                                       (stride, Ho, Wo, H, W)))
+        ctx.relu, ctx.stride = relu, stride
+        ctx.save_for_backward(x, w, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, y = ctx.saved_tensors
+        if not g.is_contiguous(memory_format=torch.channels_last):
+            g = g.contiguous(memory_format=torch.channels_last)
+        if ctx.relu:
+            g = torch.ops.aten.threshold_backward(g, y, 0)
+        need = ctx.needs_input_grad
+        gx = gw = gb = None
+        B, K, H, W = x.shape
+        N = w.shape[0]
+        if need[0]:
+            if ctx.stride == 1:         # dX = dY W: the same kernel on the transposed weight
+                wt = w.reshape(N, K).t().contiguous()
+                gx = torch.empty_like(x)
+                gemm_nt_raw(g, wt, None, None, B * H * W, K, N, False, gx)
+            else:
+                gx = torch.ops.aten.convolution_backward(g, x, w, None, [ctx.stride] * 2, [0, 0], [1, 1], False, [0, 0], 1,
+                                                         [True, False, False])[0]
+        if need[1]:
+            gw = torch.ops.aten.convolution_backward(g, x, w, None, [ctx.stride] * 2, [0, 0], [1, 1], False, [0, 0], 1,
+                                                     [False, True, False])[1]
+        if need[2]:
+            gb = g.sum((0, 2, 3))
+        return gx, gw, gb, (g if need[3] else None), None, None
+
+
+def conv1x1(x, w, bias=None, identity=None, relu=False, stride=1):
+    """``act(conv2d(x, w, stride) + bias (+ identity))`` for a 1x1 convolution that :func:`conv1x1_ok` accepts: ONE MFMA
+    launch (csrc/gemm_nt.hip) instead of the library convolution plus an epilogue pass; dX through the same kernel, dW
+    through the library's weight-gradient convolution.  Reference: Bottleneck.forward, resnet.py:271-303."""
+    if bias is not None and (bias.dtype != torch.bfloat16 or not bias.is_contiguous()):
+        bias = bias.to(torch.bfloat16).contiguous()
+    if identity is not None and (identity.dtype != x.dtype or not identity.is_contiguous(memory_format=torch.channels_last)):
+        identity = identity.to(x.dtype).contiguous(memory_format=torch.channels_last)
+    return _Conv1x1Function.apply(x, w, bias, identity, bool(relu), int(stride))
 
 
 # --------------------------------------------------------------------------- GroupNorm of the neck

@@ -2,6 +2,7 @@
 k x k conv + norm per input level and ``num_outs - len(in_channels)`` extra 3x3 stride-2
 convs on the last map.  Sub-module names follow ext-mmcv ``ConvModule`` (``conv``, ``gn``)
 so reference checkpoints load."""
+import torch
 import torch.nn as nn
 
 from . import native
@@ -26,7 +27,16 @@ class ConvModule(nn.Module):
         self.activate = nn.ReLU(inplace=True) if act_cfg is not None else None
 
     def forward(self, x):
-        x = self.conv(x)
+        w = self.conv.weight
+        if x.is_cuda and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16 \
+                and self.conv.kernel_size == (1, 1) and x.dtype == torch.bfloat16:
+            wl = w.to(torch.bfloat16)
+            if native.conv1x1_ok(x, wl, self.conv):       # lateral 1x1 convolution on the MFMA GEMM (csrc/gemm_nt.hip)
+                x = native.conv1x1(x, wl, self.conv.bias, None, False, self.conv.stride[0])
+            else:
+                x = self.conv(x)
+        else:
+            x = self.conv(x)
         if self.norm_name == "gn" and native.group_norm_cl_ok(x, self.gn):
             # channels_last GroupNorm(32, 256), with the ReLU of the GFL head's towers folded in: csrc/gn.hip
             return native.group_norm_cl(x, self.gn, relu=isinstance(self.activate, nn.ReLU))

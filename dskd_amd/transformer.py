@@ -60,8 +60,8 @@ def rowsum(t2d):
     key = (t2d.shape[0], t2d.dtype, t2d.device)
     ones = _ONES.get(key)
     if ones is None:
-        if len(_ONES) > 64:
-            _ONES.clear()
+        if len(_ONES) > 64:                  # captured graphs pin the rows they read (head._forward_graphed's keepalive)
+            _ONES.pop(next(iter(_ONES)))
         ones = _ONES[key] = torch.ones((1, t2d.shape[0]), dtype=t2d.dtype, device=t2d.device)
     return torch.mm(ones, t2d).view(-1)
 
@@ -1200,10 +1200,13 @@ class DeformableDetrTransformer(nn.Module):
         if all_valid:
             bs0 = feat_flatten.shape[0]
             key = (tuple(spatial_shapes), bs0, device)
-            if getattr(self, "_ref_key", None) != key:
+            ref_cache = self.__dict__.setdefault("_ref_cache", {})      # per shape: captured head graphs read these tensors
+            if key not in ref_cache:
                 vr = torch.ones((bs0, len(spatial_shapes), 2), dtype=torch.float32, device=device)
-                self._ref_key, self._ref_cache = key, (vr, self.get_reference_points(spatial_shapes, vr, device=device))
-            valid_ratios, reference_points = self._ref_cache
+                if len(ref_cache) >= 16:              # bounded; the graph captured on an entry pins it (head._forward_graphed)
+                    ref_cache.pop(next(iter(ref_cache)))
+                ref_cache[key] = (vr, self.get_reference_points(spatial_shapes, vr, device=device))
+            valid_ratios, reference_points = ref_cache[key]
             mask_flatten = None
         else:
             valid_ratios = torch.stack([self.get_valid_ratio(m) for m in mlvl_masks], 1)

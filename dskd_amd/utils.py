@@ -78,6 +78,7 @@ class GraphedFunction:
     def __init__(self, fn, sample_args, static_args=(), verify=False, autocast_dtype=None, against_eager=False,
                  arg_names=None):
         self.arg_names = arg_names
+        self.keepalive = []      # set by the owner: cache-owned tensors the captured kernels read (see head._forward_graphed)
         self.args_meta = [(tuple(a.shape), a.dtype, a.requires_grad) for a in sample_args]
         self.static_meta = [(a.data_ptr(), tuple(a.shape), a.dtype) for a in static_args]
         self.static_in = [a.detach().clone().requires_grad_(a.requires_grad) for a in sample_args]

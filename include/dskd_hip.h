@@ -364,6 +364,20 @@ int dskd_lin256_fwd(const void* x, const void* packed, const void* bias, void* y
                     int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * y[M, N] = act(x[M, K] w[N, K]^T + bias[N] (+ res[M, N]))  (bf16 in / out, f32 accumulation; N, K multiples of 64):
+ * a 1x1 convolution on a channels_last activation with the folded-BN shift, the residual and the ReLU in the epilogue --
+ * conv1 / conv3 / downsample of every Bottleneck (mmdet/models/backbones/resnet.py:271-303, the conv -> norm -> relu
+ * chains of :271-296 and `out += identity; out = self.relu(out)` of :298-303) and ChannelMapper's lateral convolutions
+ * (mmdet/models/necks/channel_mapper.py:90-100), which the reference runs as cuDNN convolution + BatchNorm + add + ReLU
+ * launches.  One hand-written MFMA kernel (csrc/gemm_nt.hip); with w = W^T it is the input-gradient GEMM dX = dY W.
+ *   x        activation rows, row stride K elements; stride == 0: row m of x; stride s > 0 (a strided 1x1 convolution):
+ *            output row m = (img, ho, wo) of an [.., Ho, Wo] map reads row ((img * Hi + s * ho) * Wi + s * wo)
+ *   bias     bf16 [N] or NULL;  res bf16 [M, N] or NULL (added before the activation);  relu != 0: max(., 0)
+ * ------------------------------------------------------------------------- */
+int dskd_gemm_nt(const void* x, const void* w, const void* bias, const void* res, void* y, int64_t M, int N, int K,
+                 int relu, int stride, int Ho, int Wo, int Hi, int Wi, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------
  * GroupNorm(32 groups, 256 channels) on a channels_last activation -- the norm of every ChannelMapper level
  * (mmdet/models/necks/channel_mapper.py:10-100: ext-mmcv ConvModule(conv, GN)); replaces F.group_norm and, under
  * autocast, the f32 casts and layout copies around it.  Other channel / group counts are refused.

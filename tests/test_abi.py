@@ -74,3 +74,18 @@ def test_lsap_host_entry_matches_scipy():
         native.lsap_host(torch.tensor([[1.0, float("nan")]]))
     with pytest.raises(ValueError, match="infeasible"):
         native.lsap_host(torch.tensor([[float("inf"), float("inf")], [1.0, 2.0]]))
+
+
+def test_gemm_nt_argument_validation():
+    """dskd_gemm_nt refuses what the kernel's tiling cannot take before any launch (no GPU needed)."""
+    lib = native.load()
+    ok_ptr = 4096
+    assert lib.dskd_gemm_nt(ok_ptr, ok_ptr, None, None, ok_ptr, 128, 96, 64, 0, 0, 0, 0, 0, 0, 1, None) == -1
+    assert b"multiples of 64" in lib.dskd_last_error()
+    assert lib.dskd_gemm_nt(ok_ptr, ok_ptr, None, None, ok_ptr, 128, 64, 100, 0, 0, 0, 0, 0, 0, 1, None) == -1
+    assert lib.dskd_gemm_nt(ok_ptr + 2, ok_ptr, None, None, ok_ptr, 128, 64, 64, 0, 0, 0, 0, 0, 0, 1, None) == -1
+    assert b"aligned" in lib.dskd_last_error()
+    assert lib.dskd_gemm_nt(ok_ptr, ok_ptr, None, None, ok_ptr, 128, 64, 64, 0, 0, 0, 0, 0, 0, 0, None) == -1      # f32: refused
+    assert lib.dskd_gemm_nt(ok_ptr, ok_ptr, None, None, ok_ptr, 100, 64, 64, 0, 2, 5, 5, 9, 8, 1, None) == -1      # 2 * 4 >= Wi
+    assert b"row map" in lib.dskd_last_error()
+    assert lib.dskd_gemm_nt(ok_ptr, ok_ptr, None, None, ok_ptr, 0, 64, 64, 0, 0, 0, 0, 0, 0, 1, None) == 0         # nothing to do

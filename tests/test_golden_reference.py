@@ -238,6 +238,11 @@ def test_logit_and_localisation_distillation_vs_reference(tag, cates_distill, lo
     """'soft' classification distillation (:590-622) and 'bbox' / 'logit' localisation distillation
     (:624-645) of the reference's loss(), with the constructor's default loss modules, against
     goldens from the reference (values and gradients w.r.t. the last decoder layer's outputs)."""
+    _logit_ld_case(tag, cates_distill, locat_distill, keys, torch.device("cpu"))
+
+
+def _logit_ld_case(tag, cates_distill, locat_distill, keys, dev, rtol=2e-4, grad_rtol=1e-3):
+    """Body of the 'soft' / 'bbox' / 'logit' test on ``dev`` (the -m gpu suite runs it on cuda:0 through the HIP path)."""
     d = _load_loss_case("loss_b2_l70.npz")
     v = np.load(os.path.join(G, "loss_variants_b2_l70.npz"))
     head = _make_head(d["L"])
@@ -245,24 +250,27 @@ def test_logit_and_localisation_distillation_vs_reference(tag, cates_distill, lo
     head.loss_kd = plosses.KnowledgeDistillationKLDivLoss(loss_weight=10, T=2)
     head.loss_ld_bbox = plosses.SmoothL1Loss(loss_weight=10, reduction="mean")
     head.loss_ld_logit = plosses.KnowledgeDistillationKLDivLoss(loss_weight=0.25, T=10)
-    cls = d["cls"].clone().requires_grad_(True)
-    box = d["box"].clone().requires_grad_(True)
+    cls = d["cls"].to(dev).requires_grad_(True)
+    box = d["box"].to(dev).requires_grad_(True)
     metas = [dict(img_shape=(d["img_hw"][b][0], d["img_hw"][b][1], 3)) for b in range(d["B"])]
     spatial = torch.tensor(d["shapes"])
-    tinfo = dict(neck_feats=d["feats_t"], head_outs=(t(v["cls_t"]), t(v["box_t"]), (t(v["mem_t"]), spatial), d["hs_t"][None]),
-                 pred_keepid=d["keep"], pred_labels=d["t_l"], pred_bboxes=d["t_b"])
-    losses = head.loss(cls, box, (t(v["mem_s"]), spatial), d["hs"].clone(), d["gt_b"], d["gt_l"], metas,
-                       student_feat=d["feats_s"], teacher_info=tinfo,
+    on = lambda xs: [x.to(dev) for x in xs]                                                     # noqa: E731
+    tinfo = dict(neck_feats=on(d["feats_t"]),
+                 head_outs=(t(v["cls_t"]).to(dev), t(v["box_t"]).to(dev), (t(v["mem_t"]).to(dev), spatial),
+                            d["hs_t"][None].to(dev)),
+                 pred_keepid=d["keep"].to(dev), pred_labels=on(d["t_l"]), pred_bboxes=on(d["t_b"]))
+    losses = head.loss(cls, box, (t(v["mem_s"]).to(dev), spatial), d["hs"].to(dev), on(d["gt_b"]), on(d["gt_l"]), metas,
+                       student_feat=on(d["feats_s"]), teacher_info=tinfo,
                        task_labels={"prev": list(range(d["L"])), "curr": [], "next": []})
     assert sorted(losses.keys()) == sorted(v[f"{tag}/keys"].tolist())
     for key in keys:
-        torch.testing.assert_close(losses[key].detach(), t(v[f"{tag}/loss/{key}"]), rtol=2e-4, atol=1e-9)
+        torch.testing.assert_close(losses[key].detach().cpu(), t(v[f"{tag}/loss/{key}"]), rtol=rtol, atol=1e-9)
         g = torch.autograd.grad(losses[key], [cls, box], allow_unused=True, retain_graph=True)
         if f"{tag}/grad_cls_last/{key}" in v.files:
-            torch.testing.assert_close(g[0][-1], t(v[f"{tag}/grad_cls_last/{key}"]), rtol=1e-3, atol=1e-9)
+            torch.testing.assert_close(g[0][-1].cpu(), t(v[f"{tag}/grad_cls_last/{key}"]), rtol=grad_rtol, atol=1e-9)
             assert float(g[0][:-1].abs().max()) == 0.0
         if f"{tag}/grad_box_last/{key}" in v.files:
-            torch.testing.assert_close(g[1][-1], t(v[f"{tag}/grad_box_last/{key}"]), rtol=1e-3, atol=1e-9)
+            torch.testing.assert_close(g[1][-1].cpu(), t(v[f"{tag}/grad_box_last/{key}"]), rtol=grad_rtol, atol=1e-9)
 
 
 @pytest.mark.parametrize("tag", ["many", "few", "none", "rescale", "cfg"])

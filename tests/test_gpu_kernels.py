@@ -939,9 +939,10 @@ def _close(a, ref, tol):
     return float((a.float().cpu() - ref).abs().max()) <= tol * float(ref.abs().max())
 
 
-@pytest.mark.parametrize("T", [1, 200, 4096 + 37])
+@pytest.mark.parametrize("T", [1, 200, 4096 + 37, 88892])
 def test_ffn_fused_vs_float_reference(T):
-    """dskd_ffn_fwd / dskd_ffn_bwd without dropout against the FFN chain of the reference (ext-mmcv FFN.layers:
+    """T = 88 892 = 4 x 22 223 is the benchmark's token count (ragged last workgroup at the real size).
+    dskd_ffn_fwd / dskd_ffn_bwd without dropout against the FFN chain of the reference (ext-mmcv FFN.layers:
     Linear -> ReLU -> Dropout -> Linear) evaluated in fp32 on the CPU from the same bf16-rounded inputs; ragged token
     counts (last workgroup / last wave partly or wholly dead)."""
     x, w1, b1, w2, b2, gy = _ffn_inputs(T)
@@ -1140,7 +1141,7 @@ def test_nchw_f32_of_channels_last_maps(dtype):
 
 
 # --------------------------------------------------------------------------- tall Linear with 256 inputs (lin256_kernel)
-@pytest.mark.parametrize("T,N", [(16384 + 77, 256), (20000, 384), (16384, 32), (17000, 512)])
+@pytest.mark.parametrize("T,N", [(16384 + 77, 256), (20000, 384), (16384, 32), (17000, 512), (88892, 256), (88892, 384)])
 def test_lin256_vs_float_reference(T, N):
     """dskd_lin256_fwd (and the transposed pack used for dX) against x @ W^T + b evaluated in fp32 on the CPU from the same
     bf16 inputs; ragged token counts; with and without bias / ReLU.  Tolerance 8e-3 of the largest magnitude."""
@@ -1200,3 +1201,69 @@ def test_add_pos_equals_the_mixed_dtype_add():
         assert torch.equal(gx, up) and gp.shape == pos.shape
         refp = up.float() if pos.shape[0] == 2 else up.float().sum(0, keepdim=True)
         assert float((gp - refp).abs().max()) <= 1e-6 * float(refp.abs().max()) + 1e-6
+
+
+# --------------------------------------------------------------------------- 1x1 convolution + epilogue (csrc/gemm_nt.hip)
+@pytest.mark.parametrize("B,K,N,H,W,stride,with_res,relu", [
+    (2, 64, 64, 23, 37, 1, False, True),        # layer1 conv1 of the first block (N = 64 tile variant), ragged M
+    (2, 64, 256, 23, 37, 1, True, True),        # conv3 + identity + ReLU
+    (1, 256, 128, 20, 33, 1, False, True),
+    (2, 256, 512, 21, 35, 2, False, False),     # downsample branch: stride 2, no activation, odd input size
+    (1, 1024, 2048, 13, 21, 2, False, False),
+    (1, 2048, 512, 13, 21, 1, False, True),     # K = 2048: 32 stages
+    (2, 512, 256, 9, 11, 1, False, False),      # ChannelMapper lateral (no bias)
+    (1, 128, 192, 5, 7, 1, True, False),        # N = 192: 64-wide tiles, M < one tile
+])
+def test_conv1x1_mfma_vs_float_reference(B, K, N, H, W, stride, with_res, relu):
+    """dskd_gemm_nt behind native.conv1x1: ``act(conv2d(x, w, stride) + bias (+ identity))`` and its input gradient against
+    F.conv2d + autograd evaluated in fp32 on the CPU from the same bf16-rounded inputs (the chain of
+    mmdet/models/backbones/resnet.py:271-303 with the BN folded).  Tolerance: 8e-3 of the largest magnitude (bf16 output of
+    an f32 accumulation, as for the other MFMA kernels); dW / d(bias) / d(identity) come from the library and ATen."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(K + N + stride)
+    x = torch.randn(B, K, H, W, generator=g).bfloat16()
+    w = (torch.randn(N, K, 1, 1, generator=g) / K ** 0.5).bfloat16()
+    b = (torch.randn(N, generator=g) * 0.3).bfloat16() if N != 256 or with_res else None
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    res = torch.randn(B, N, Ho, Wo, generator=g).bfloat16() if with_res else None
+    up = torch.randn(B, N, Ho, Wo, generator=g).bfloat16()
+
+    xr, wr = x.float().requires_grad_(True), w.float().requires_grad_(True)
+    rr = res.float().requires_grad_(True) if with_res else None
+    yr = F.conv2d(xr, wr, None if b is None else b.float(), stride=stride)
+    if with_res:
+        yr = yr + rr
+    if relu:
+        yr = torch.relu(yr)
+    gr = torch.autograd.grad(yr, [xr, wr] + ([rr] if with_res else []), up.float())
+
+    conv = torch.nn.Conv2d(K, N, 1, stride=stride, bias=False)
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wd = w.to(DEV).requires_grad_(True)
+    rd = res.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True) if with_res else None
+    assert native.conv1x1_ok(xd, wd, conv)
+    guard = torch.full((4096,), 5.0, dtype=torch.bfloat16, device=DEV)
+    y = native.conv1x1(xd, wd, None if b is None else b.to(DEV), rd, relu, stride)
+    assert y.shape == (B, N, Ho, Wo) and y.is_contiguous(memory_format=torch.channels_last)
+    assert _close(y, yr.detach(), 8e-3)
+    gd = torch.autograd.grad(y, [xd, wd] + ([rd] if with_res else []), up.to(DEV).contiguous(memory_format=torch.channels_last))
+    for name, a, r in zip(("dx", "dw", "dres"), gd, gr):
+        assert _close(a, r, 1.2e-2), (name, float((a.float().cpu() - r).abs().max()), float(r.abs().max()))
+    torch.cuda.synchronize()
+    assert bool((guard == 5.0).all())
+
+
+def test_conv1x1_mfma_full_size_layer1():
+    """The benchmark's largest 1x1 convolution (layer1 conv3 at B = 4, 800 x 1333: 267 200 tokens, 64 -> 256 with identity
+    and ReLU): every output against the f32 CPU evaluation."""
+    g = torch.Generator().manual_seed(9)
+    B, K, N, H, W = 4, 64, 256, 200, 334
+    x = torch.randn(B, H, W, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) / 8).bfloat16()
+    b = (torch.randn(N, generator=g) * 0.3).bfloat16()
+    res = torch.randn(B, H, W, N, generator=g).bfloat16()
+    ref = torch.relu(x.float().view(-1, K) @ w.float().t() + b.float() + res.float().view(-1, N))
+    xd = x.to(DEV).permute(0, 3, 1, 2)
+    rd = res.to(DEV).permute(0, 3, 1, 2)
+    y = native.conv1x1(xd, w.to(DEV).view(N, K, 1, 1), b.to(DEV), rd, True, 1)
+    assert _close(y.permute(0, 2, 3, 1).reshape(-1, N), ref, 8e-3)

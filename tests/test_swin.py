@@ -116,8 +116,9 @@ def test_official_checkpoint_conversion(tmp_path):
             torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-4)
 
 
-def test_swin_detector_step_on_cpu(cpu_ops):
-    """BASELINE config #4 shape: Swin-T + ChannelMapper([192, 384, 768]) + the DSKD head builds from
+@pytest.mark.parametrize("split", ["40_40", "70_10"])
+def test_swin_detector_step_on_cpu(cpu_ops, split):
+    """BASELINE configs[3] (Swin-T 40+40; 70+10 = the same trunk on the headline split): Swin-T + ChannelMapper([192, 384, 768]) + the DSKD head builds from
     the config file and runs one distillation step (CPU, oracle ops) with finite losses and
     gradients reaching the trainable backbone stages."""
     import copy
@@ -125,14 +126,20 @@ def test_swin_detector_step_on_cpu(cpu_ops):
     from dskd_amd.builder import build_detector
     from dskd_amd.config import Config
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cfg = Config.fromfile(os.path.join(root, "configs", "dskd_gfl_deformable_detr_swin_t_70_10.py"))
+    cfg = Config.fromfile(os.path.join(root, "configs", f"dskd_gfl_deformable_detr_swin_t_{split}.py"))
+    assert (cfg.num_prev, cfg.num_curr) == tuple(int(v) for v in split.split("_"))
+    if split == "40_40":      # configs[3] = the reference's 40+40 schedule (lr 4e-4) on the Swin-T trunk
+        ref40 = Config.fromfile(os.path.join(root, "configs", "dskd_gfl_deformable_detr_r50_40_40.py"))
+        assert cfg.optimizer[0]["lr"] == ref40.optimizer[0]["lr"] == 4e-4
+        assert cfg.model.bbox_head.feats_distill == ref40.model.bbox_head.feats_distill
+        assert cfg.model.bbox_head.cates_distill == ref40.model.bbox_head.cates_distill
     cfg.model.bbox_head.num_query = 30
     torch.manual_seed(0)
     m = build_detector(cfg.model)
     m.init_weights()
     t = copy.deepcopy(m)
     m.set_teacher(model=t)
-    m.LableInPCNTask = {"prev": list(range(70)), "curr": list(range(70, 80)), "next": []}
+    m.LableInPCNTask = {"prev": list(range(cfg.num_prev)), "curr": list(range(cfg.num_prev, 80)), "next": []}
     m.train()
     img = torch.randn(1, 3, 128, 160)
     metas = [dict(img_shape=(128, 160, 3), batch_input_shape=(128, 160), scale_factor=1.0)]
