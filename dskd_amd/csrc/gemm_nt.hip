@@ -30,7 +30,6 @@
 //  * blockIdx -> tile: XCD-contiguous (xcd_remap), output tiles of one token tile adjacent, so the activation tile is
 //    fetched from HBM once and re-read from that XCD's L2.
 #include "common.h"
-#include <stdlib.h>
 
 namespace dskd {
 namespace {
@@ -61,16 +60,105 @@ __device__ __forceinline__ bf16x8 frag_read(unsigned lds_addr) {
   return v;
 }
 
-template <int BN, int MT, int NS>
+// Fragment reads of one K stage (64): 16 ds_read_b128, written as asm (hipcc would sink each read down to its use:
+// ds_read -> s_waitcnt 0 -> MFMA), issued in k-step order so that counted waits can release the MFMAs step by step.
+template <int MT>
+struct Frags {
+  bf16x8 w[4][2], x[4][MT];
+};
+template <int MT, int PX, int PW>
+__device__ __forceinline__ void read_stage(Frags<MT>& f, const unsigned (&xa)[MT][2], const unsigned (&wa)[2][2], unsigned so) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) f.w[ks][nt] = frag_read(wa[nt][ks & 1] + so + (ks >> 1) * PW);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) f.x[ks][mt] = frag_read(xa[mt][ks & 1] + so + (ks >> 1) * PX);
+  }
+}
+// the 16 MFMAs of a stage; COUNTED: the fragments were read just before (LDS returns in order: before k-step ks all
+// but the (3 - ks) * (2 + MT) youngest reads are done); otherwise they are already complete
+template <int MT, bool COUNTED>
+__device__ __forceinline__ void mfma_stage(f32x16 (&acc)[MT][2], Frags<MT>& f) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    if constexpr (COUNTED && MT == 2) {
+      if (ks == 0) asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(f.w[0][0]), "+v"(f.w[0][1]), "+v"(f.x[0][0]), "+v"(f.x[0][1]));
+      if (ks == 1) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(f.w[1][0]), "+v"(f.w[1][1]), "+v"(f.x[1][0]), "+v"(f.x[1][1]));
+      if (ks == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f.w[2][0]), "+v"(f.w[2][1]), "+v"(f.x[2][0]), "+v"(f.x[2][1]));
+      if (ks == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.w[3][0]), "+v"(f.w[3][1]), "+v"(f.x[3][0]), "+v"(f.x[3][1]));
+    } else if constexpr (COUNTED) {
+      if (ks == 0) asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(f.w[0][0]), "+v"(f.w[0][1]), "+v"(f.x[0][0]));
+      if (ks == 1) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(f.w[1][0]), "+v"(f.w[1][1]), "+v"(f.x[1][0]));
+      if (ks == 2) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(f.w[2][0]), "+v"(f.w[2][1]), "+v"(f.x[2][0]));
+      if (ks == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.w[3][0]), "+v"(f.w[3][1]), "+v"(f.x[3][0]));
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w[ks][nt], f.x[ks][mt], acc[mt][nt], 0, 0, 0);
+  }
+}
+// Epilogue: lane = one token (m_first + 32 mt), 16 consecutive outputs (n_first + 32 nt ..) per accumulator tile.
+template <int MT>
+__device__ __forceinline__ void store_tile(const GemmArgs& a, const f32x16 (&acc)[MT][2], long long m_first, int n_first) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const long long m = m_first + mt * 32;
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int n = n_first + nt * 32;
+      float v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = acc[mt][nt][i];
+      if (a.bias) {
+        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(a.bias + n), b1 = *reinterpret_cast<const bf16x8*>(a.bias + n + 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { v[i] += (float)b0[i]; v[8 + i] += (float)b1[i]; }
+      }
+      if (a.res) {
+        const __bf16* rp = a.res + m * a.N + n;
+        const bf16x8 r0 = *reinterpret_cast<const bf16x8*>(rp), r1 = *reinterpret_cast<const bf16x8*>(rp + 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { v[i] += (float)r0[i]; v[8 + i] += (float)r1[i]; }
+      }
+      bf16x8 o0, o1;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float p = v[i], q = v[8 + i];
+        if (a.relu) { p = fmaxf(p, 0.f); q = fmaxf(q, 0.f); }
+        o0[i] = (__bf16)p;
+        o1[i] = (__bf16)q;
+      }
+      __bf16* yp = a.y + m * a.N + n;
+      *reinterpret_cast<bf16x8*>(yp) = o0;
+      *reinterpret_cast<bf16x8*>(yp + 8) = o1;
+    }
+  }
+}
+
+// Two LDS stages, the DMA of stage k + 1 issued before stage k is consumed; 48 | 64 KB per workgroup, so two or three
+// workgroups share a CU and cover each other's waits.  Measured and NOT kept (scratch/r03_conv1x1.py, every variant
+// green on the parity tests, each slower on all 19 layer shapes of the trunk): four stages with the DMA three ahead;
+// a fifth, DMA-only wave with three stages; four stages + register double-buffered fragments + one barrier per stage;
+// a per-tile rotation of the K order.  What they have in common is one workgroup per CU (96 - 128 KB of LDS): the
+// layers where a deeper pipeline should pay (K >= 512) have 4 200 .. 16 800 tokens, i.e. 264 .. 1 056 tiles -- about
+// one round of the chip -- and there tile quantisation (264 = 256 + 8) and the second resident workgroup matter more
+// than the per-stage latency.  SQ counters of the K = 1024, N = 256, 16 800-token layer: no LDS bank conflicts, MFMA
+// pipe busy 24 % of the wave's lifetime, 30 % in s_waitcnt / barrier.
+template <int BN, int MT>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs a) {
+  constexpr int NS = 2;
   constexpr int WN = BN / 64;              // waves along the outputs
   constexpr int WM = 4 / WN;               // waves along the tokens
   constexpr int BM = WM * MT * 32;         // 128
   static_assert(BM == 128, "tile");
   constexpr int PX = BM * 64, PW = BN * 64;          // bytes of one 32-k panel
   constexpr int STAGE = 2 * (PX + PW);
-  constexpr int WRB = BN / 64;             // 16-row weight blocks loaded per wave (activation: always 2)
-  constexpr int LOADS = 4 + 2 * WRB;       // LDS-DMA instructions per wave and stage
+  constexpr int WRB = BN / 64;             // 16-row weight blocks whose DMA this wave issues (activation: always 2)
+  constexpr int LOADS = 2 * (2 + WRB);     // LDS-DMA instructions per wave and stage
   extern __shared__ __attribute__((aligned(16))) char smem[];      // NS stages
 
   const int lane = threadIdx.x & 63;
@@ -84,16 +172,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs a) {
   const long long tm = vb / tiles_n;
   const long long m0 = tm * BM;
   const int n0 = tn * BN;
+  const int nk = a.K >> 6;
 
   // ---- per-lane source pointers of the LDS-DMA: lane i of an instruction fills row (i >> 2), chunk position (i & 3)
   const int lr = lane >> 2;
-  const int csw = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;        // logical chunk held at that position (bytes)
+  const int csw = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;      // logical chunk held at that position (bytes)
   const char* xp[2];
   const char* wp[WRB];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    long long m = m0 + wave * 32 + j * 16 + lr;
-    if (m >= a.M) m = a.M - 1;                                  // rows past the end: any valid row, never stored
+    long long m = m0 + (wave * 2 + j) * 16 + lr;
+    if (m >= a.M) m = a.M - 1;                                // rows past the end: any valid row, never stored
     long long row = m;
     if (a.s) {
       const long long img = m / a.HoWo;
@@ -107,10 +196,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs a) {
   for (int j = 0; j < WRB; ++j)
     wp[j] = reinterpret_cast<const char*>(a.w) + (long long)(n0 + (wave * WRB + j) * 16 + lr) * a.K * 2 + csw;
 
-  auto issue = [&](int kt, int buf) {
-    char* sx = smem + buf * STAGE;
+  auto issue = [&](int kt) {
+    char* sx = smem + (kt % NS) * STAGE;
     char* sw = sx + 2 * PX;
-    const int kb = kt * 128;                                    // bytes along K
+    const int kb = kt * 128;                                  // bytes along K
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -144,7 +233,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs a) {
       wa[nt][e] = base + 2 * PX + row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
     }
   }
-
   f32x16 acc[MT][2];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -153,94 +241,29 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
 
-  // NS stages in LDS, the DMA runs NS - 1 stages ahead of the MFMAs: with few tiles per CU (the deep-K layers at
-  // 4 200 .. 16 800 tokens) a stage would otherwise cost one full memory latency.
-  const int nk = a.K >> 6;
-#pragma unroll
-  for (int p = 0; p < NS - 1; ++p)
-    if (p < nk) issue(p, p);
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + NS - 1 < nk) issue(kt + NS - 1, (kt + NS - 1) % NS);
-    // stage kt has landed (mine): all but the loads of the stages behind it are done
-    const int ahead = min(NS - 1, nk - 1 - kt);
-    if (ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LOADS) : "memory");
-    else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
-    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                       // ... and everybody's
-    const unsigned so = (kt % NS) * STAGE;
-    bf16x8 wf[4][2], xf[4][MT];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) wf[ks][nt] = frag_read(wa[nt][ks & 1] + so + (ks >> 1) * PW);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) xf[ks][mt] = frag_read(xa[mt][ks & 1] + so + (ks >> 1) * PX);
-    }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      // LDS returns in order: all but the (3 - ks) * (2 + MT) youngest reads are done
-      if constexpr (MT == 2) {
-        if (ks == 0) asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(wf[0][0]), "+v"(wf[0][1]), "+v"(xf[0][0]), "+v"(xf[0][1]));
-        if (ks == 1) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(wf[1][0]), "+v"(wf[1][1]), "+v"(xf[1][0]), "+v"(xf[1][1]));
-        if (ks == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wf[2][0]), "+v"(wf[2][1]), "+v"(xf[2][0]), "+v"(xf[2][1]));
-        if (ks == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[3][0]), "+v"(wf[3][1]), "+v"(xf[3][0]), "+v"(xf[3][1]));
+  {
+    issue(0);
+    Frags<MT> f;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) {
+        issue(kt + 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");      // stage kt has landed (mine); kt + 1 in flight
       } else {
-        if (ks == 0) asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(wf[0][0]), "+v"(wf[0][1]), "+v"(xf[0][0]));
-        if (ks == 1) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(wf[1][0]), "+v"(wf[1][1]), "+v"(xf[1][0]));
-        if (ks == 2) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(wf[2][0]), "+v"(wf[2][1]), "+v"(xf[2][0]));
-        if (ks == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[3][0]), "+v"(wf[3][1]), "+v"(xf[3][0]));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][nt], xf[ks][mt], acc[mt][nt], 0, 0, 0);
-    }
-    __builtin_amdgcn_s_barrier();       // every wave has read this stage before a later DMA overwrites it
-  }
-
-  // ---- epilogue: lane = one token, 16 consecutive outputs per accumulator tile
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const long long m = m0 + (wm * MT + mt) * 32 + r;
-    if (m >= a.M) continue;
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int n = n0 + (wn * 2 + nt) * 32 + 16 * h;
-      float v[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) v[i] = acc[mt][nt][i];
-      if (a.bias) {
-        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(a.bias + n), b1 = *reinterpret_cast<const bf16x8*>(a.bias + n + 8);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { v[i] += (float)b0[i]; v[8 + i] += (float)b1[i]; }
-      }
-      if (a.res) {
-        const __bf16* rp = a.res + m * a.N + n;
-        const bf16x8 r0 = *reinterpret_cast<const bf16x8*>(rp), r1 = *reinterpret_cast<const bf16x8*>(rp + 8);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { v[i] += (float)r0[i]; v[8 + i] += (float)r1[i]; }
-      }
-      bf16x8 o0, o1;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        float p = v[i], q = v[8 + i];
-        if (a.relu) { p = fmaxf(p, 0.f); q = fmaxf(q, 0.f); }
-        o0[i] = (__bf16)p;
-        o1[i] = (__bf16)q;
-      }
-      __bf16* yp = a.y + m * a.N + n;
-      *reinterpret_cast<bf16x8*>(yp) = o0;
-      *reinterpret_cast<bf16x8*>(yp + 8) = o1;
+      __builtin_amdgcn_s_barrier();                                       // ... and everybody's
+      read_stage<MT, PX, PW>(f, xa, wa, (kt % NS) * STAGE);
+      mfma_stage<MT, true>(acc, f);
+      __builtin_amdgcn_s_barrier();       // every wave has read this stage before the next DMA overwrites it
     }
   }
+  store_tile<MT>(a, acc, m0 + wm * MT * 32 + r, n0 + wn * 64 + 16 * h);
 }
 
-template <int BN, int MT, int NS>
+template <int BN, int MT>
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
-  constexpr int LDS = NS * 2 * (128 * 64 + BN * 64);
-  auto kern = gemm_nt_kernel<BN, MT, NS>;
+  constexpr int LDS = 2 * 2 * (128 * 64 + BN * 64);
+  auto kern = gemm_nt_kernel<BN, MT>;
   int dev = 0;
   static bool done[64] = {};              // the attribute is per device: set it once on each
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -278,12 +301,6 @@ extern "C" int dskd_gemm_nt(const void* x, const void* w, const void* bias, cons
   a.y = (__bf16*)y; a.M = M; a.N = N; a.K = K; a.relu = relu;
   a.s = stride; a.HoWo = stride ? Ho * Wo : 1; a.Wo = stride ? Wo : 1; a.Hi = Hi; a.Wi = Wi;
   hipStream_t st = (hipStream_t)stream;
-  // Stages in LDS: with at most ~2 tiles per CU and a deep K the DMA must run several stages ahead (one workgroup per
-  // CU, 4 x 32 KB); with many tiles per CU two stages and two or three workgroups per CU hide the latency better.
-  const long long tiles = ((M + 127) / 128) * (N / (N % 128 == 0 ? 128 : 64));
-  (void)tiles;
-  int ns = 2;      // measured (scratch/r03_conv1x1.py): four stages lose everywhere -- the fill RATE binds, not its latency
-  if (const char* e = getenv("DSKD_GEMM_NS")) { const int v = atoi(e); if (v == 2 || v == 4) ns = v; }
-  if (N % 128 == 0) return ns == 4 ? launch_gemm<128, 2, 4>(a, st) : launch_gemm<128, 2, 2>(a, st);
-  return ns == 4 ? launch_gemm<64, 1, 4>(a, st) : launch_gemm<64, 1, 2>(a, st);
+  if (N % 128 == 0) return launch_gemm<128, 2>(a, st);
+  return launch_gemm<64, 1>(a, st);
 }
