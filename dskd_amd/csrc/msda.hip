@@ -119,6 +119,8 @@ __device__ __forceinline__ void point_params(float lx_n, float ly_n, float a, in
 // element 0 with this compiler (hipcc 7.2); always go through a scalar by-value helper.
 __device__ __forceinline__ float as_f32(unsigned u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ int as_i32(float f) { return __builtin_bit_cast(int, f); }
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16x2 as_bf16x2(unsigned u) { return __builtin_bit_cast(bf16x2, u); }
 using i32x2 = __attribute__((ext_vector_type(2))) int;
 
 __device__ __forceinline__ void unpack_bf16x8(const u32x4& v, float* f) {
@@ -633,11 +635,24 @@ __device__ unsigned long long g_vprof[64];
 #define VPROF(slot)
 #endif
 
-template <typename T, int NCH, int PPQ, int NW>
+// FUSED (the levels-2+3 launch, bf16): the kernel also forms the grad_loc / grad_attn dot products of ITS samples, so the
+// gather kernel keeps the fine levels only.  The scatter loop is paced by the LDS atomic pipe and leaves the texture path
+// idle: the four corner rows of a sample (64 B per head, L2-resident: levels 2+3 are 1 323 pixels) are fetched with
+// buffer loads -- lane = (point parity, corner, 8-byte part of the row), i.e. the SAME lane roles as the ds_add loop, with
+// the lane's channels now contiguous (4 cl + k instead of cl + 8 k; channel-plane stride == 1 (mod 32) keeps the 32 lanes
+// of a half-wave on 32 banks) -- issued before the ds_add loop of the pass and consumed behind it: dot over the lane's
+// 4 channels, DPP sum over the 8 part-lanes, the 4 x 8 corner results of a pass parked in LDS; then lane = (query, point)
+// finishes (gx, gy, ga) with the (lx, ly, attn) it still holds from phase 1 and writes its 12 bytes; the 8 points of a
+// (query, head) are 8 consecutive lanes: whole 32-B / 64-B runs.
+// stats != nullptr: the fixed-point bound comes from the gather kernel's by-product (max |grad_out|, sum |attn| per
+// (16 x 16 region, head)) instead of a pre-pass over the region's rows.
+template <typename T, int NCH, int PPQ, int NW, bool FUSED>
 __global__ __launch_bounds__(NW * 64) void msda_bwd_value_kernel(
-    const float* __restrict__ loc, const float* __restrict__ attn,
-    const T* __restrict__ grad_out, float* __restrict__ grad_value, ValueGeom g, VarGeom vg,
-    int Nq, int LP, int points) {
+    const T* __restrict__ value, const float* __restrict__ loc, const float* __restrict__ attn,
+    const T* __restrict__ grad_out, float* __restrict__ grad_value, float* __restrict__ grad_loc,
+    float* __restrict__ grad_attn, const float* __restrict__ stats, int sRX, int sRY, int sEX, int sEY, ValueGeom g,
+    VarGeom vg, int Nq, int LP, int points) {
+  static_assert(!FUSED || (sizeof(T) == 2 && NCH == kCh), "fused dot products: bf16, whole heads");
   constexpr int NQW = 64 / PPQ;           // queries per wave pass
   constexpr int NG = kCh / NCH;           // channel groups per head
   extern __shared__ float smem[];
@@ -647,6 +662,7 @@ __global__ __launch_bounds__(NW * 64) void msda_bwd_value_kernel(
   float* s_red = s_g + NW * NQW * NCH;                             // [2 * waves]
   i32x4* s_tab = reinterpret_cast<i32x4*>(s_red + 2 * NW);              // [4][4] lookup rows
   int* s_geo = reinterpret_cast<int*>(s_tab + 4 * kMaxLevels);     // [24] region geometry
+  i32x4* s_voff = reinterpret_cast<i32x4*>(s_geo + 6 * kMaxLevels + 8);   // FUSED: [waves][64] global corner offsets
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -715,6 +731,31 @@ __global__ __launch_bounds__(NW * 64) void msda_bwd_value_kernel(
   // ---- fixed-point scale: bound of any window cell = max|grad_out| * sum|attn| over the
   // region's queries (this channel group, these levels)
   float gmax = 0.f, asum = 0.f;
+  if (stats) {
+    // from the gather kernel: the (16 x 16-pixel region, head) cells that cover this region's level-0 pixel range (a
+    // query's region is its centre's level-0 pixel / edge in both kernels, so the union contains every query of ours)
+    if (wave == 0) {
+      const int px0 = rx * g.EX, px1 = min((rx + 1) * g.EX, g.W[0]) - 1;
+      const int py0 = ry * g.EY, py1 = min((ry + 1) * g.EY, g.H[0]) - 1;
+      const int gx0 = px0 / sEX, gx1 = min(px1 / sEX, sRX - 1), gy0 = py0 / sEY, gy1 = min(py1 / sEY, sRY - 1);
+      const int nx = gx1 - gx0 + 1, ncell = nx * (gy1 - gy0 + 1);
+      for (int i = lane; i < ncell; i += 64) {
+        const int iy = i / nx, ix = i - iy * nx;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(
+            stats + ((((size_t)b * sRY + gy0 + iy) * sRX + gx0 + ix) * kHeads + h) * 4);
+        gmax = fmaxf(gmax, v.x);
+        asum += vg.lv0 == 1 ? v.y : v.z;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        gmax = fmaxf(gmax, __shfl_xor(gmax, o));
+        asum += __shfl_xor(asum, o);
+      }
+      if (lane == 0) { s_red[0] = gmax; s_red[1] = asum; }
+    }
+    __syncthreads();
+    gmax = s_red[0]; asum = s_red[1];
+  } else {
   for (int i0 = tid; i0 < nq * (NCH / 8); i0 += 4 * NW * 64) {   // 8 channels per lane and step,
 #pragma unroll                                                    // 4 steps of loads in flight
     for (int u = 0; u < 4; ++u) {
@@ -744,9 +785,12 @@ __global__ __launch_bounds__(NW * 64) void msda_bwd_value_kernel(
   gmax = 0.f; asum = 0.f;
 #pragma unroll
   for (int w2 = 0; w2 < NW; ++w2) { gmax = fmaxf(gmax, s_red[w2]); asum += s_red[NW + w2]; }
+  }
   const float bound = gmax * asum;
   VPROF(1);
-  if (bound == 0.f) return;   // nothing to scatter from this region (uniform across the workgroup)
+  // nothing to scatter from this region (uniform across the workgroup); the fused launch still owes its gradients
+  const bool no_scatter = bound == 0.f;
+  if (!FUSED && no_scatter) return;
   // NaN / inf gradients: accumulate nothing here and let them through the float fallback below
   const bool fx_ok = bound > 0.f && bound < 3.0e38f;
   const float fx_scale = fx_ok ? 1.0e9f / bound : 0.f;        // 1e9 < 2^30: headroom for rounding
@@ -760,8 +804,10 @@ __global__ __launch_bounds__(NW * 64) void msda_bwd_value_kernel(
   // plane stride == 4 (mod 32) spreads the channel lanes -> 32 distinct banks.
   constexpr int K = NCH / 8;
   const int pp = lane >> 5, crn = (lane >> 3) & 3, cl = lane & 7;
-  char* win_cl = reinterpret_cast<char*>(win + cl * vg.NP);
-  const int plane8 = vg.NP * 32;                  // bytes between channel planes cl and cl + 8
+  // the lane's K channels: cl + 8 k (plane stride == 4 mod 32), or -- FUSED -- the contiguous 4 cl + k (== 1 mod 32)
+  constexpr int CHM = FUSED ? K : 1, CHS = FUSED ? 1 : 8;      // channel of (cl, k) = CHM * cl + CHS * k
+  char* win_cl = reinterpret_cast<char*>(win + CHM * cl * vg.NP);
+  const int plane8 = vg.NP * 4 * CHS;             // bytes between the planes of the lane's consecutive channels
   const unsigned dummy = (unsigned)(vg.npos + crn + 4 * pp) * 4u;
   const int* rec_lane = my_rec + pp * 8 + crn * 2;
 
@@ -785,8 +831,24 @@ __global__ __launch_bounds__(NW * 64) void msda_bwd_value_kernel(
   };
   fetch(wave * NQW);
 
+  // FUSED: value rows through the texture path; what phase 3 needs of phase 1 stays in registers
+  __amdgpu_buffer_rsrc_t vrsrc;
+  if constexpr (FUSED)
+    vrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(value + (size_t)b * Nq * (kHeads * kCh)), 0,
+                                              Nq * (kHeads * kCh * (int)sizeof(T)), 0x00020000);
+  // dot-product lane roles: (row of the instruction, 16-byte part of the head's 64-byte row); a pass has 64 points x
+  // 4 corners = 256 rows = 16 load instructions, the rows of instruction i belong to query i / 2
+  const int dpart = lane & 3, drow = lane >> 2;
+  const int hb16 = h * (kCh * (int)sizeof(T)) + dpart * 16;
+  i32x4* my_voff = s_voff + wave * 64;
+  // corner dot products [64 points][4] over the pass's records, which are dead by then; accessed as int like the
+  // records themselves (type-based alias analysis would otherwise let the compiler move float stores across int loads)
+  int* my_dot = s_rec + wave * 64 * 8;
+
   for (int qbase = wave * NQW; qbase < nq; qbase += NW * NQW) {
     unsigned long long fbmask;   // points of this pass that left the window
+    float p_lx = 0.f, p_ly = 0.f, p_a = 0.f, p_wf = 0.f, p_hf = 0.f;      // FUSED: this lane's point, for phase 3
+    const int p_qg = n_qg;
     // ---- phase 1: one lane per sampling point (NQW queries x PPQ points)
     {
       const int s = s_first + (lane & (PPQ - 1));
@@ -794,6 +856,7 @@ __global__ __launch_bounds__(NW * 64) void msda_bwd_value_kernel(
       // lane's dummy slot by an unsigned min in phase 2
       i32x4 off = i32x4{kSkip, kSkip, kSkip, kSkip};
       f32x4 w = f32x4{0.f, 0.f, 0.f, 0.f};
+      i32x4 voff = i32x4{kOOB, kOOB, kOOB, kOOB};
       bool is_fb = false;
       const int qg = n_qg;
       if (qg >= 0) {
@@ -804,11 +867,19 @@ __global__ __launch_bounds__(NW * 64) void msda_bwd_value_kernel(
         const int H = lb.w, W = lb.z, st = lb.y;
         const float x = xy.x * (float)W - 0.5f;
         const float y = xy.y * (float)H - 0.5f;
+        p_a = a; p_wf = (float)W; p_hf = (float)H;
         if (x > -1.f && y > -1.f && x < (float)W && y < (float)H) {
           const float xf = floorf(x), yf = floorf(y);
           const int x0 = (int)xf, y0 = (int)yf;
           const float lx = x - xf, ly = y - yf, hx = 1.f - lx, hy = 1.f - ly;
           const bool vx0 = x0 >= 0, vx1 = x0 + 1 <= W - 1, vy0 = y0 >= 0, vy1 = y0 + 1 <= H - 1;
+          if constexpr (FUSED) {
+            p_lx = lx; p_ly = ly;
+            const int r00 = (st + y0 * W + x0) * (kHeads * kCh * (int)sizeof(T));
+            const int rb = kHeads * kCh * (int)sizeof(T);
+            voff = i32x4{(vy0 && vx0) ? r00 : kOOB, (vy0 && vx1) ? r00 + rb : kOOB, (vy1 && vx0) ? r00 + W * rb : kOOB,
+                         (vy1 && vx1) ? r00 + W * rb + rb : kOOB};
+          }
           w = f32x4{(vy0 && vx0) ? hy * hx * a : 0.f, (vy0 && vx1) ? hy * lx * a : 0.f,
                     (vy1 && vx0) ? ly * hx * a : 0.f, (vy1 && vx1) ? ly * lx * a : 0.f};
           const int wwl = lc.x, whl = lc.y;
@@ -828,6 +899,7 @@ __global__ __launch_bounds__(NW * 64) void msda_bwd_value_kernel(
       i32x4* rec = reinterpret_cast<i32x4*>(my_rec + lane * 8);   // {off0, w0, off1, w1} {off2, w2, off3, w3}
       rec[0] = i32x4{off.x, as_i32(w.x), off.y, as_i32(w.y)};
       rec[1] = i32x4{off.z, as_i32(w.z), off.w, as_i32(w.w)};
+      if constexpr (FUSED) my_voff[lane] = voff;
       // the pass's grad_out rows (this channel group), NE channels per lane
       float* gdst = my_g + (lane / PPQ) * NCH + (lane & (PPQ - 1)) * NE;
 #pragma unroll
@@ -838,14 +910,23 @@ __global__ __launch_bounds__(NW * 64) void msda_bwd_value_kernel(
     fetch(qbase + NW * NQW);
     wave_lds_sync();
 
+    // ---- FUSED: request this lane's 16 bytes of every (point, corner) row of the pass; consumed behind the ds_add loop
+    u32x4 vv[FUSED ? 16 : 1];
+    if constexpr (FUSED) {
+      const int* vo = reinterpret_cast<const int*>(my_voff) + drow;
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        vv[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vrsrc, vo[i * 16] + hb16, 0, 0));
+    }
     // ---- phase 2: branch-free accumulation.  Per pair of points: one 8-byte LDS read
     // {offset, weight}, one unsigned min (skipped / out-of-window corners land on the lane's
     // dummy slot), and per channel one multiply, one rounding convert, one ds_add.
+    if (!no_scatter)
 #pragma unroll
     for (int qk = 0; qk < NQW; ++qk) {
       float gs[K];
 #pragma unroll
-      for (int k = 0; k < K; ++k) gs[k] = my_g[qk * NCH + cl + 8 * k] * fx_scale;
+      for (int k = 0; k < K; ++k) gs[k] = my_g[qk * NCH + CHM * cl + CHS * k] * fx_scale;
       i32x2 r[PPQ / 2];
 #pragma unroll
       for (int j = 0; j < PPQ / 2; ++j)
@@ -866,12 +947,48 @@ __global__ __launch_bounds__(NW * 64) void msda_bwd_value_kernel(
       if (o <= -2) {
         const float wj = as_f32((unsigned)my_rec[pt * 8 + crn * 2 + 1]);
         for (int k = pp; k < K; k += 2)
-          atomicAdd(gvb + (size_t)(-(o + 2)) * (kHeads * kCh) + cl + 8 * k,
-                    wj * my_g[(pt / PPQ) * NCH + cl + 8 * k]);
+          atomicAdd(gvb + (size_t)(-(o + 2)) * (kHeads * kCh) + CHM * cl + CHS * k,
+                    wj * my_g[(pt / PPQ) * NCH + CHM * cl + CHS * k]);
+      }
+    }
+    if constexpr (FUSED) {
+      // ---- dot products <value[corner row], grad_out[query, head]>: 8 channels per lane as four v_dot2c_f32_bf16 (the
+      // products of two bf16 are exact in f32), summed over the row's 4 part-lanes with DPP
+#pragma unroll
+      for (int qk = 0; qk < NQW; ++qk) {
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(my_g + qk * NCH + 8 * dpart);
+        const f32x4 gb = *reinterpret_cast<const f32x4*>(my_g + qk * NCH + 8 * dpart + 4);
+        const bf16x2 g0 = {(__bf16)ga.x, (__bf16)ga.y}, g1 = {(__bf16)ga.z, (__bf16)ga.w};
+        const bf16x2 g2 = {(__bf16)gb.x, (__bf16)gb.y}, g3 = {(__bf16)gb.z, (__bf16)gb.w};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const u32x4 v = vv[2 * qk + e];
+          // (bit casts of vector ELEMENTS go through a by-value helper: see the note at as_f32)
+          float d = __builtin_amdgcn_fdot2_f32_bf16(as_bf16x2(v.x), g0, 0.f, false);
+          d = __builtin_amdgcn_fdot2_f32_bf16(as_bf16x2(v.y), g1, d, false);
+          d = __builtin_amdgcn_fdot2_f32_bf16(as_bf16x2(v.z), g2, d, false);
+          d = __builtin_amdgcn_fdot2_f32_bf16(as_bf16x2(v.w), g3, d, false);
+          d = group4_sum(d);
+          if (dpart == 0) my_dot[(2 * qk + e) * 16 + drow] = as_i32(d);
+        }
+      }
+      wave_lds_sync();
+      // ---- phase 3: lane = (query, point) again
+      if (p_qg >= 0) {
+        const i32x4 di = *reinterpret_cast<const i32x4*>(my_dot + lane * 4);
+        const f32x4 d = f32x4{as_f32((unsigned)di.x), as_f32((unsigned)di.y), as_f32((unsigned)di.z), as_f32((unsigned)di.w)};
+        const float hx = 1.f - p_lx, hy = 1.f - p_ly;
+        const float ga = (hy * hx) * d.x + (hy * p_lx) * d.y + (p_ly * hx) * d.z + (p_ly * p_lx) * d.w;
+        const float gx = p_wf * p_a * (hy * (d.y - d.x) + p_ly * (d.w - d.z));
+        const float gy = p_hf * p_a * (hx * (d.z - d.x) + p_lx * (d.w - d.y));
+        const size_t base = (((size_t)b * Nq + p_qg) * kHeads + h) * (size_t)LP + s_first + (lane & (PPQ - 1));
+        grad_attn[base] = ga;
+        *reinterpret_cast<f32x2*>(grad_loc + base * 2) = f32x2{gx, gy};
       }
     }
     wave_lds_sync();
   }
+  if (FUSED && no_scatter) return;
   VPROF(2);
   __syncthreads();
   VPROF(3);
@@ -905,15 +1022,17 @@ constexpr int kVarNch[kNumVar] = {16, 32, 32};
 constexpr int kVarPpq[kNumVar] = {4, 4, 8};
 constexpr size_t kMaxLds = 160 * 1024;
 
-inline size_t value_lds_bytes(int nch, int ppq, int nw, int NP) {
+inline size_t value_lds_bytes(int nch, int ppq, int nw, int NP, bool fused) {
   const int nqw = 64 / ppq;
   return sizeof(int) * (size_t)nch * NP + sizeof(int) * nw * 64 * 8 +
          sizeof(float) * nw * nqw * nch + sizeof(float) * 2 * nw +
-         sizeof(int) * 4 * 4 * kMaxLevels + sizeof(int) * 6 * kMaxLevels;
+         sizeof(int) * 4 * 4 * kMaxLevels + sizeof(int) * (6 * kMaxLevels + 8) +
+         (fused ? (size_t)nw * 64 * 16 : 0);       // global corner offsets of a pass
 }
 
+// fuse23: the levels-2+3 launch also forms its samples' grad_loc / grad_attn (channel planes then == 1 mod 32)
 bool make_value_geom(const LevelGeom& lg, int levels, int points, int Nq, ValueGeom* g,
-                     VarGeom* var, size_t* lds_bytes) {
+                     VarGeom* var, size_t* lds_bytes, bool fuse23 = false) {
   if (levels != 4 || points != 4) return false;
   int tot = 0;
   for (int l = 0; l < levels; ++l) tot += lg.H[l] * lg.W[l];
@@ -946,14 +1065,15 @@ bool make_value_geom(const LevelGeom& lg, int levels, int points, int Nq, ValueG
       if (mine) npos += g->ww[l] * g->wh[l];
     }
     vg.npos = npos;
-    // channel-plane stride (incl. 8 dummy slots): == 4 (mod 32), see the kernel's lane roles
+    // channel-plane stride (incl. 8 dummy slots): == 4 (mod 32), see the kernel's lane roles (fused launch: == 1)
+    const bool fused = fuse23 && v == 2;
     int NP = npos + 8;
-    while ((NP & 31) != 4) ++NP;
+    while ((NP & 31) != (fused ? 1 : 4)) ++NP;
     vg.NP = NP;
     // as many waves as the LDS left beside the window allows (each wave owns a parameter slice)
     vg.waves = 0;
     for (int nw : {16, 12, 8}) {
-      lds_bytes[v] = (value_lds_bytes(kVarNch[v], kVarPpq[v], nw, NP) + 15) & ~(size_t)15;
+      lds_bytes[v] = (value_lds_bytes(kVarNch[v], kVarPpq[v], nw, NP, fused) + 15) & ~(size_t)15;
       if (lds_bytes[v] <= kMaxLds) { vg.waves = nw; break; }
     }
     if (vg.waves == 0) return false;
@@ -961,28 +1081,52 @@ bool make_value_geom(const LevelGeom& lg, int levels, int points, int Nq, ValueG
   return true;
 }
 
-template <typename T, int V, int NW>
+// What the fused / statistics-fed launches need beyond the scatter's own arguments.
+struct ValueExtra {
+  const void* value;      // fused launch: the value tensor
+  float* grad_loc;
+  float* grad_attn;
+  const float* stats;     // per (gather region, head) {max |grad_out|, sum |attn| level 1, levels 2+3, -} or null
+  int sRX, sRY, sEX, sEY; // the gather kernel's region grid
+  bool fuse23;
+};
+
+template <typename T, int V, int NW, bool FUSED>
 int launch_value_nw(const float* loc, const float* attn, const T* grad_out, float* grad_value,
                     const ValueGeom& g, const VarGeom& vg, size_t lds, int B, int Nq, int LP,
-                    int points, hipStream_t st) {
+                    int points, const ValueExtra& ex, hipStream_t st) {
   constexpr int NCH = kVarNch[V], PPQ = kVarPpq[V];
-  auto kern = msda_bwd_value_kernel<T, NCH, PPQ, NW>;
-  static const hipError_t attr = hipFuncSetAttribute(
-      (const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
-  if (attr != hipSuccess) return fail(DSKD_ERR_LAUNCH, "dskd_msda_bwd: cannot reserve LDS");
+  auto kern = msda_bwd_value_kernel<T, NCH, PPQ, NW, FUSED>;
+  int dev = 0;
+  static bool done[64] = {};              // the attribute is per device: set it once on each
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!done[dev]) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds) != hipSuccess)
+      return fail(DSKD_ERR_LAUNCH, "dskd_msda_bwd: cannot reserve LDS");
+    done[dev] = true;
+  }
   const dim3 grid((unsigned)(B * g.RY * g.RX * kHeads * (kCh / NCH))), block(NW * 64);
-  hipLaunchKernelGGL(kern, grid, block, lds, st, loc, attn, grad_out, grad_value, g, vg, Nq, LP, points);
+  const float* stats = V == 0 ? nullptr : ex.stats;       // the by-product has no level-0 sum
+  hipLaunchKernelGGL(kern, grid, block, lds, st, (const T*)ex.value, loc, attn, grad_out, grad_value, ex.grad_loc,
+                     ex.grad_attn, stats, ex.sRX, ex.sRY, ex.sEX, ex.sEY, g, vg, Nq, LP, points);
   return DSKD_OK;
 }
 
 template <typename T, int V>
 int launch_value_variant(const float* loc, const float* attn, const T* grad_out, float* grad_value,
                          const ValueGeom& g, const VarGeom& vg, size_t lds, int B, int Nq, int LP,
-                         int points, hipStream_t st) {
+                         int points, const ValueExtra& ex, hipStream_t st) {
+  if constexpr (V == 2 && sizeof(T) == 2) {
+    if (ex.fuse23) switch (vg.waves) {
+      case 16: return launch_value_nw<T, V, 16, true>(loc, attn, grad_out, grad_value, g, vg, lds, B, Nq, LP, points, ex, st);
+      case 12: return launch_value_nw<T, V, 12, true>(loc, attn, grad_out, grad_value, g, vg, lds, B, Nq, LP, points, ex, st);
+      default: return launch_value_nw<T, V, 8, true>(loc, attn, grad_out, grad_value, g, vg, lds, B, Nq, LP, points, ex, st);
+    }
+  }
   switch (vg.waves) {
-    case 16: return launch_value_nw<T, V, 16>(loc, attn, grad_out, grad_value, g, vg, lds, B, Nq, LP, points, st);
-    case 12: return launch_value_nw<T, V, 12>(loc, attn, grad_out, grad_value, g, vg, lds, B, Nq, LP, points, st);
-    default: return launch_value_nw<T, V, 8>(loc, attn, grad_out, grad_value, g, vg, lds, B, Nq, LP, points, st);
+    case 16: return launch_value_nw<T, V, 16, false>(loc, attn, grad_out, grad_value, g, vg, lds, B, Nq, LP, points, ex, st);
+    case 12: return launch_value_nw<T, V, 12, false>(loc, attn, grad_out, grad_value, g, vg, lds, B, Nq, LP, points, ex, st);
+    default: return launch_value_nw<T, V, 8, false>(loc, attn, grad_out, grad_value, g, vg, lds, B, Nq, LP, points, ex, st);
   }
 }
 
@@ -990,18 +1134,21 @@ int launch_value_variant(const float* loc, const float* attn, const T* grad_out,
 template <typename T>
 int launch_value(const float* loc, const float* attn, const T* grad_out, float* grad_value,
                  const ValueGeom& g, const VarGeom* var, const size_t* lds, int B, int Nq, int LP,
-                 int points, hipStream_t st, int variants = 7) {
+                 int points, const ValueExtra& ex, hipStream_t st, int variants = 7) {
   if (variants & 1)
-    if (int rc = launch_value_variant<T, 0>(loc, attn, grad_out, grad_value, g, var[0], lds[0], B, Nq, LP, points, st)) return rc;
+    if (int rc = launch_value_variant<T, 0>(loc, attn, grad_out, grad_value, g, var[0], lds[0], B, Nq, LP, points, ex, st)) return rc;
   if (variants & 2)
-    if (int rc = launch_value_variant<T, 1>(loc, attn, grad_out, grad_value, g, var[1], lds[1], B, Nq, LP, points, st)) return rc;
+    if (int rc = launch_value_variant<T, 1>(loc, attn, grad_out, grad_value, g, var[1], lds[1], B, Nq, LP, points, ex, st)) return rc;
   if (variants & 4)
-    return launch_value_variant<T, 2>(loc, attn, grad_out, grad_value, g, var[2], lds[2], B, Nq, LP, points, st);
+    return launch_value_variant<T, 2>(loc, attn, grad_out, grad_value, g, var[2], lds[2], B, Nq, LP, points, ex, st);
   return DSKD_OK;
 }
 
 // rows [row0, row0 + nrows) of every image of grad_value ([B, Nv, 256] f32) = 0
-__global__ void zero_rows_kernel(float* __restrict__ gv, int Nv, int row0, int nrows) {
+__global__ void zero_rows_kernel(float* __restrict__ gv, int Nv, int row0, int nrows, unsigned* __restrict__ hdr) {
+  // hdr: the stray-list header of the workspace, zeroed at the START of every backward (a launch that failed half-way
+  // must not leave a count behind for the next one)
+  if (hdr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 16) hdr[threadIdx.x] = 0u;
   u32x4* base = reinterpret_cast<u32x4*>(gv + ((size_t)blockIdx.y * Nv + row0) * (kHeads * kCh));
   const size_t n16 = (size_t)nrows * (kHeads * kCh) / 4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
@@ -1050,6 +1197,8 @@ struct FwdWinGeom {
   int lv0;                // first level held in LDS; levels below it (the finest, with the largest windows) stay on
                           // the buffer-load path, which then runs beside the LDS gather instead of idling
   int waves;              // workgroup size in waves (host side)
+  int lv_end;             // backward gather only: levels [0, lv_end) are processed here (the coarser ones have their dot
+                          // products formed inside the windowed grad_value kernel, which holds their windows anyway)
 };
 constexpr int kRegionF = 16;
 constexpr int kFwdHS = 5;       // staging slots per query: 4 points + 1 pad
@@ -1305,7 +1454,7 @@ __global__ __launch_bounds__(1024) void msda_fwd_win_kernel(
 
 // Host side: regions of <= kRegionF level-0 pixels, all four windows of one head in LDS.
 bool make_fwd_win_geom(const LevelGeom& lg, int levels, int points, int Nq, int lv0, int nw_req, ValueGeom* g,
-                       FwdWinGeom* fw, size_t* lds_bytes) {
+                       FwdWinGeom* fw, size_t* lds_bytes, int lv_end = kMaxLevels) {
   if (levels != 4 || points != 4) return false;
   int tot = 0;
   for (int l = 0; l < levels; ++l) tot += lg.H[l] * lg.W[l];
@@ -1325,10 +1474,11 @@ bool make_fwd_win_geom(const LevelGeom& lg, int levels, int points, int Nq, int 
     g->ww[l] = (g->EX * lg.W[l] + W0 - 1) / W0 + 1 + kMarginLo + kMarginHi;
     g->wh[l] = (g->EY * lg.H[l] + H0 - 1) / H0 + 1 + kMarginLo + kMarginHi;
     fw->base[l] = npos;
-    if (l >= lv0) npos += g->ww[l] * g->wh[l];
+    if (l >= lv0 && l < lv_end) npos += g->ww[l] * g->wh[l];
   }
   fw->npos = npos;
   fw->lv0 = lv0;
+  fw->lv_end = lv_end;
   // queries of the largest region (the kernel's own integer arithmetic)
   auto edge = [](int E, int r, int Sl, int S0) {
     const int q = floor_div(2 * E * r * Sl - S0 + 2 * S0 - 1, 2 * S0);
@@ -1378,8 +1528,8 @@ int launch_fwd_win(const __bf16* value, const float* loc, const float* attn, __b
 template <typename T>
 __global__ __launch_bounds__(1024) void msda_bwd_win_kernel(
     const T* __restrict__ value, const float* __restrict__ loc, const float* __restrict__ attn,
-    const T* __restrict__ grad_out, float* __restrict__ grad_loc, float* __restrict__ grad_attn, ValueGeom g,
-    FwdWinGeom fw, int Nq, int points) {
+    const T* __restrict__ grad_out, float* __restrict__ grad_loc, float* __restrict__ grad_attn, float* __restrict__ stats,
+    ValueGeom g, FwdWinGeom fw, int Nq, int points) {
   static_assert(sizeof(T) == 2, "windowed gather: bf16 only");
   constexpr int PIXB = kCh * (int)sizeof(T);     // 64 B: one head of one pixel
   constexpr int ROWB = kHeads * PIXB;            // 512 B: one pixel, all heads
@@ -1393,6 +1543,7 @@ __global__ __launch_bounds__(1024) void msda_bwd_win_kernel(
   float* s_ga_all = reinterpret_cast<float*>(s_gl_all + NW * 16 * LP);               // [NW][16][16]
   i32x4* s_tab = reinterpret_cast<i32x4*>(s_ga_all + NW * 16 * LP);                  // [4][4] lookup rows
   int* s_geo = reinterpret_cast<int*>(s_tab + 4 * kMaxLevels);                       // [24] region geometry
+  float* s_st = reinterpret_cast<float*>(s_geo + 6 * kMaxLevels);                    // [NW][4] statistics partials
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1504,6 +1655,11 @@ __global__ __launch_bounds__(1024) void msda_bwd_win_kernel(
   };
   fetch(wave * 16);
 
+  // By-product for the windowed grad_value kernels (their fixed-point scale): max |grad_out| and the sums of |attn| of
+  // levels 1 and 2+3 over this workgroup's (region, head) -- the data is in registers here anyway, and those kernels
+  // no longer walk their region's grad_out / attn rows a second time (that pre-pass was 8-17 % of their run time).
+  unsigned st_gbits = 0u;      // bf16 bit pattern of max |grad_out| (NaN patterns compare above every number: kept)
+  float st_a1 = 0.f, st_a23 = 0.f;
   for (int qbase = wave * 16; qbase < nq; qbase += NW * 16) {
     const int qg = n_qg;
     f32x2 c_xy[kMaxLevels];
@@ -1512,10 +1668,20 @@ __global__ __launch_bounds__(1024) void msda_bwd_win_kernel(
     for (int l = 0; l < kMaxLevels; ++l) { c_xy[l] = n_xy[l]; c_a[l] = n_a[l]; }
     float go[8];
     unpack_bf16x8(n_go, go);
+    if (qg >= 0) {
+      // |bf16| compares like its bit pattern: the max over the 8 packed channels without unpacking them
+      const unsigned ax = n_go.x & 0x7FFF7FFFu, ay = n_go.y & 0x7FFF7FFFu, az = n_go.z & 0x7FFF7FFFu, aw = n_go.w & 0x7FFF7FFFu;
+      const unsigned hi = max(max(ax >> 16, ay >> 16), max(az >> 16, aw >> 16));
+      const unsigned lo = max(max(ax & 0xFFFFu, ay & 0xFFFFu), max(az & 0xFFFFu, aw & 0xFFFFu));
+      st_gbits = max(st_gbits, max(hi, lo));
+      st_a1 += fabsf(c_a[1]);
+      st_a23 += fabsf(c_a[2]) + fabsf(c_a[3]);
+    }
     fetch(qbase + NW * 16);
 
 #pragma unroll
     for (int lvl = 0; lvl < kMaxLevels; ++lvl) {
+      if (lvl >= fw.lv_end) break;          // wave-uniform: the coarser levels belong to the grad_value kernel
       // ---- stage the 4 points of this level: lane = (query, point)
       {
         i32x4 off = i32x4{zero_slot, zero_slot, zero_slot, zero_slot};
@@ -1605,7 +1771,7 @@ __global__ __launch_bounds__(1024) void msda_bwd_win_kernel(
         const int idx = it * 64 + lane;          // (query of the pass, sample)
         const int q2 = idx >> 4, smp = idx & 15;
         const int qg2 = __shfl(qg, q2 * 4);      // the query's global index lives in its first lane (all lanes take part:
-        if (q2 < nvalid) {                       // a shuffle reads nothing from a lane that sits out a branch)
+        if (q2 < nvalid && smp < fw.lv_end * 4) {   // a shuffle reads nothing from a lane that sits out a branch)
           const size_t base = (((size_t)b * Nq + qg2) * kHeads + h) * (size_t)LP + smp;
           grad_attn[base] = s_ga[q2 * LP + smp];
           *reinterpret_cast<f32x2*>(grad_loc + base * 2) = s_gl[q2 * LP + smp];
@@ -1614,17 +1780,36 @@ __global__ __launch_bounds__(1024) void msda_bwd_win_kernel(
     }
     wave_lds_sync();
   }
+  if (stats) {
+    float st_gmax = as_f32(st_gbits << 16);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      st_gmax = fmaxf(st_gmax, __shfl_xor(st_gmax, o));
+      st_a1 += __shfl_xor(st_a1, o);
+      st_a23 += __shfl_xor(st_a23, o);
+    }
+    // every lane of a (query) quad saw the same grad_out slice only in part (8 of 32 channels): the max over the quad is
+    // in the wave max; attn: each lane one point per level -> the sums count every sample once
+    if (lane == 0) { s_st[wave * 4 + 0] = st_gmax; s_st[wave * 4 + 1] = st_a1; s_st[wave * 4 + 2] = st_a23; }
+    __syncthreads();
+    if (tid == 0) {
+      float gm = 0.f, a1 = 0.f, a23 = 0.f;
+      for (int w2 = 0; w2 < NW; ++w2) { gm = fmaxf(gm, s_st[w2 * 4]); a1 += s_st[w2 * 4 + 1]; a23 += s_st[w2 * 4 + 2]; }
+      float* dst = stats + ((((size_t)b * g.RY + ry) * g.RX + rx) * kHeads + h) * 4;
+      *reinterpret_cast<f32x4*>(dst) = f32x4{gm, a1, a23, 0.f};
+    }
+  }
 }
 
 int launch_bwd_win(const __bf16* value, const float* loc, const float* attn, const __bf16* grad_out, float* grad_loc,
-                   float* grad_attn, const ValueGeom& g, const FwdWinGeom& fw, size_t lds, int B, int Nq, int points,
-                   hipStream_t st) {
+                   float* grad_attn, float* stats, const ValueGeom& g, const FwdWinGeom& fw, size_t lds, int B, int Nq,
+                   int points, hipStream_t st) {
   auto kern = msda_bwd_win_kernel<__bf16>;
   static const hipError_t attr = hipFuncSetAttribute(
       (const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
   if (attr != hipSuccess) return fail(DSKD_ERR_LAUNCH, "dskd_msda_bwd: cannot reserve LDS");
   const dim3 grid((unsigned)(B * g.RY * g.RX * kHeads)), block(fw.waves * 64);
-  hipLaunchKernelGGL(kern, grid, block, lds, st, value, loc, attn, grad_out, grad_loc, grad_attn, g, fw, Nq, points);
+  hipLaunchKernelGGL(kern, grid, block, lds, st, value, loc, attn, grad_out, grad_loc, grad_attn, stats, g, fw, Nq, points);
   return DSKD_OK;
 }
 
@@ -1805,19 +1990,60 @@ int msda_bwd_impl(const void* value, const int64_t* spatial_shapes, const int64_
   ValueGeom vg;
   VarGeom var[kNumVar];
   size_t lds[kNumVar];
-  const char* env = getenv("DSKD_MSDA_BWD");   // "v1" forces the plain-atomics kernel (A/B tests)
+  const char* env = getenv("DSKD_MSDA_BWD");   // A/B runs: "v1" = plain global atomics, "r2" = round 2's four launches
   const bool force_v1 = env && env[0] == 'v' && env[1] == '1';
-  const bool windowed = !force_v1 && Nq == Nv && make_value_geom(g, levels, points, Nq, &vg, var, lds);
+  const bool legacy = env && env[0] == 'r' && env[1] == '2';
+  bool windowed = !force_v1 && Nq == Nv && make_value_geom(g, levels, points, Nq, &vg, var, lds);
   int pull_mask = 0;
   MsdaLevels ml;
-  if (workspace) {
+  // The bf16 workspace path: gather kernel on the fine levels only (+ the statistics behind the fixed-point scales),
+  // the levels-2+3 launch forms its own samples' grad_loc / grad_attn.
+  ValueGeom wg;
+  FwdWinGeom fw;
+  size_t wl = 0;
+  bool gather_win = false, fuse23 = false;
+  size_t stats_bytes = 0;
+  if (workspace && windowed) {
     for (int l = 0; l < kMaxLevels; ++l) { ml.H[l] = g.H[l]; ml.W[l] = g.W[l]; ml.start[l] = g.start[l]; }
-    if (windowed) {
-      pull_mask = pull_level_mask();
-      if (pull_mask && !pull_supported(ml, levels, points, Nv, Nq, dtype, pull_mask)) pull_mask = 0;
+    pull_mask = pull_level_mask();
+    // every level's tile geometry is validated here, before the first launch of this call
+    if (pull_mask && !pull_supported(ml, levels, points, Nv, Nq, dtype, pull_mask)) pull_mask = 0;
+  }
+  if (windowed && dtype == DSKD_DTYPE_BF16) {
+    fuse23 = workspace && !legacy && (pull_mask >> 2) == 0;     // levels 2+3 on the windowed kernel (the default split)
+    gather_win = make_fwd_win_geom(g, levels, points, Nq, 2, 8, &wg, &fw, &wl, fuse23 ? 2 : kMaxLevels);
+    if (gather_win) {
+      wl += (size_t)fw.waves * 16 * 16 * 12 + (size_t)fw.waves * 16;   // parked (gx, gy, ga) triples; statistics partials
+      gather_win = wl <= kMaxLds;
     }
-    // zero what the atomics of the remaining kernels add into
+    if (fuse23) {
+      stats_bytes = (size_t)B * wg.RY * wg.RX * kHeads * 16;
+      VarGeom var2[kNumVar];
+      size_t lds2[kNumVar];
+      fuse23 = gather_win && workspace_bytes >= kPullWsHeader + stats_bytes + kPullWsEntry &&
+               make_value_geom(g, levels, points, Nq, &vg, var2, lds2, true);
+      if (fuse23) {
+        for (int v = 0; v < kNumVar; ++v) { var[v] = var2[v]; lds[v] = lds2[v]; }
+      } else {                                    // back to the unfused launches (the gather then takes every level)
+        stats_bytes = 0;
+        windowed = make_value_geom(g, levels, points, Nq, &vg, var, lds);
+        gather_win = windowed && make_fwd_win_geom(g, levels, points, Nq, 2, 8, &wg, &fw, &wl);
+        if (gather_win) {
+          wl += (size_t)fw.waves * 16 * 16 * 12 + (size_t)fw.waves * 16;
+          gather_win = wl <= kMaxLds;
+        }
+      }
+    }
+  }
+  // statistics at the END of the workspace; the stray list of the pull kernel keeps the front
+  float* stats = fuse23 ? reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ((workspace_bytes - stats_bytes) & ~(size_t)15))
+                        : nullptr;
+  if (fuse23) stats_bytes = workspace_bytes - (size_t)(reinterpret_cast<char*>(stats) - reinterpret_cast<char*>(workspace));
+  if (workspace) {
+    // zero what the atomics of the remaining kernels add into, and the stray-list header
+    unsigned* hdr = reinterpret_cast<unsigned*>(workspace);
     if (pull_mask == 0) {
+      zero_fill(workspace, kPullWsHeader, st);
       zero_fill(grad_value, sizeof(float) * (size_t)B * Nv * (kHeads * kCh), st);
     } else {
       for (int l = 0; l < levels; ++l)
@@ -1825,55 +2051,40 @@ int msda_bwd_impl(const void* value, const int64_t* spatial_shapes, const int64_
           const int nrows = g.H[l] * g.W[l];
           const int bx = (nrows * 64 + 255) / 256;
           hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)(bx < 1024 ? bx : 1024), (unsigned)B), dim3(256), 0, st,
-                             grad_value, Nv, g.start[l], nrows);
+                             grad_value, Nv, g.start[l], nrows, hdr);
+          hdr = nullptr;
         }
+      if (hdr) zero_fill(workspace, kPullWsHeader, st);       // every level pulled: nothing else zeroes it
     }
   }
   const int variants = (pull_mask & 1 ? 0 : 1) | (pull_mask & 2 ? 0 : 2) | ((pull_mask >> 2) == 3 ? 0 : 4);
   if (windowed) {
+    ValueExtra ex;
+    ex.value = value; ex.grad_loc = grad_loc; ex.grad_attn = grad_attn; ex.stats = stats;
+    ex.sRX = wg.RX; ex.sRY = wg.RY; ex.sEX = wg.EX; ex.sEY = wg.EY; ex.fuse23 = fuse23;
     if (dtype == DSKD_DTYPE_F32) {
+      ex.stats = nullptr;
       hipLaunchKernelGGL((msda_bwd_kernel<float, false, 1>), grid, block, 0, st, (const float*)value, loc, attn,
                          (const float*)grad_out, grad_value, grad_loc, grad_attn, g, Nv, Nq, LP, points, qpb,
                          bpi);
       if (int rc = launch_value<float>(loc, attn, (const float*)grad_out, grad_value, vg, var, lds, B, Nq, LP,
-                                       points, st, variants)) return rc;
+                                       points, ex, st, variants)) return rc;
     } else {
-#define DSKD_BWD_BF16(PH)                                                                                         \
-  hipLaunchKernelGGL((msda_bwd_kernel<__bf16, false, PH>), grid, block, 0, st, (const __bf16*)value, loc, attn,   \
-                     (const __bf16*)grad_out, grad_value, grad_loc, grad_attn, g, Nv, Nq, LP, points, qpb, bpi)
-      // grad_loc / grad_attn: the mixed windowed gather (levels 2+3 of one head in LDS, bit-identical to the plain
-      // kernel); DSKD_MSDA_BWD_GATHER=plain forces the plain kernel, DSKD_MSDA_FWD_LV0 / _NW are shared A/B knobs
-      bool gathered = false;
-      const char* gv_env = getenv("DSKD_MSDA_BWD_GATHER");
-      if (!(gv_env && gv_env[0] == 'p')) {
-        const char* e_lv0 = getenv("DSKD_MSDA_FWD_LV0");
-        const char* e_nw = getenv("DSKD_MSDA_FWD_NW");
-        int lv0 = e_lv0 ? atoi(e_lv0) : 2;
-        if (lv0 < 0 || lv0 > 3) lv0 = 2;
-        ValueGeom wg;
-        FwdWinGeom fw;
-        size_t wl = 0;
-        if (make_fwd_win_geom(g, levels, points, Nq, lv0, e_nw ? atoi(e_nw) : 8, &wg, &fw, &wl)) {
-          wl += (size_t)fw.waves * 16 * 16 * 12;            // the parked (gx, gy, ga) triples of a pass
-          if (wl <= kMaxLds) {
-            if (int rc = launch_bwd_win((const __bf16*)value, loc, attn, (const __bf16*)grad_out, grad_loc, grad_attn, wg,
-                                        fw, wl, B, Nq, points, st)) return rc;
-            gathered = true;
-          }
-        }
+      // grad_loc / grad_attn: the windowed gather kernel (fused path: levels 0+1 on the buffer-load path, no windows;
+      // otherwise levels 2+3 of one head in LDS), else the plain gather kernel
+      if (gather_win) {
+        if (int rc = launch_bwd_win((const __bf16*)value, loc, attn, (const __bf16*)grad_out, grad_loc, grad_attn, stats,
+                                    wg, fw, wl, B, Nq, points, st)) return rc;
+      } else {
+        hipLaunchKernelGGL((msda_bwd_kernel<__bf16, false, 1>), grid, block, 0, st, (const __bf16*)value, loc, attn,
+                           (const __bf16*)grad_out, grad_value, grad_loc, grad_attn, g, Nv, Nq, LP, points, qpb, bpi);
       }
-      if (!gathered) switch (pick_phases(LP, dtype, 4)) {
-        case 4: DSKD_BWD_BF16(4); break;
-        case 2: DSKD_BWD_BF16(2); break;
-        default: DSKD_BWD_BF16(1); break;
-      }
-#undef DSKD_BWD_BF16
       if (int rc = launch_value<__bf16>(loc, attn, (const __bf16*)grad_out, grad_value, vg, var, lds, B, Nq, LP,
-                                        points, st, variants)) return rc;
+                                        points, ex, st, variants)) return rc;
     }
     if (pull_mask)
       if (int rc = launch_pull(loc, attn, grad_out, grad_value, ml, pull_mask, B, Nq, dtype, workspace,
-                               workspace_bytes, st)) return rc;
+                               workspace_bytes - stats_bytes, st)) return rc;
     return check_launch("dskd_msda_bwd");
   }
   if (dtype == DSKD_DTYPE_F32)
@@ -1902,10 +2113,12 @@ extern "C" int dskd_msda_bwd(const void* value, const int64_t* spatial_shapes,
 extern "C" int64_t dskd_msda_bwd_workspace(int B, int Nv, int Nq, int heads, int levels, int points) {
   (void)Nv;
   if (B < 0 || Nq < 0 || heads < 0 || levels < 0 || points < 0) return -1;
-  // header + room for 1/16 of all (query, head, point, corner) contributions as stray entries
+  // header + room for 1/16 of all (query, head, point, corner) contributions as stray entries + the gather kernel's
+  // statistics: 16 bytes per (16 x 16-pixel region, head); regions <= Nq / 256 + Nq / 16 + 2 for any level-0 shape
   int64_t entries = (int64_t)B * Nq * heads * levels * points * 4 / 16;
   if (entries < 4096) entries = 4096;
-  return (int64_t)kPullWsHeader + entries * (int64_t)kPullWsEntry;
+  const int64_t stats = (int64_t)B * ((int64_t)Nq / 256 + Nq / 16 + 2) * heads * 16 + 16;
+  return (int64_t)kPullWsHeader + entries * (int64_t)kPullWsEntry + stats;
 }
 
 extern "C" int dskd_msda_bwd_ws(const void* value, const int64_t* spatial_shapes,

@@ -14,7 +14,8 @@ struct MsdaLevels {
 };
 
 // Workspace of dskd_msda_bwd_ws: a 64-byte header {count, overflow, ticket} followed by 16-byte
-// fallback entries.  The header is zero on entry and is left zero by the apply kernel.
+// fallback entries.  The header is zeroed at the start of every call (msda.hip) and is left zero by the apply kernel;
+// the tail of the workspace holds the gather kernel's per-region statistics (msda.hip).
 constexpr size_t kPullWsHeader = 64;
 constexpr size_t kPullWsEntry = 16;
 

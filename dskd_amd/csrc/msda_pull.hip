@@ -630,9 +630,14 @@ int launch_pull_level(const float* loc, const float* attn, const T* grad_out, fl
   constexpr size_t lds = sizeof(int) * ((NC + 4) & ~3) + sizeof(i32x2) * (size_t)NT * 4 +
                          (sizeof(T) == 2 ? (size_t)(NT / 2) * 64 : 0);
   auto kern = msda_bwd_pull_kernel<T, NT, R>;
-  static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                     (int)lds);
-  if (attr != hipSuccess) return fail(DSKD_ERR_LAUNCH, "dskd_msda_bwd: cannot reserve LDS for the pull kernel");
+  int dev = 0;
+  static bool done[64] = {};              // the attribute is per device: set it once on each
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!done[dev]) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail(DSKD_ERR_LAUNCH, "dskd_msda_bwd: cannot reserve LDS for the pull kernel");
+    done[dev] = true;
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)g.nblocks), dim3(NT), lds, st, loc, attn, grad_out, grad_value, g, hdr,
                      fb, cap);
   return DSKD_OK;
@@ -646,15 +651,20 @@ int launch_pull_t(const float* loc, const float* attn, const T* grad_out, float*
   const size_t cap64 = (workspace_bytes - kPullWsHeader) / kPullWsEntry;
   const unsigned cap = (unsigned)(cap64 > 0x7FFFFFFFull ? 0x7FFFFFFFull : cap64);
   const int M = pull_margin();
+  // every level's geometry first: nothing is launched unless all of them fit (the apply kernel must follow every pull
+  // launch, or the stray list would be left behind)
   PullGeomSet gs;
   gs.n = 0;
   for (int l = 0; l < kMsdaMaxLevels; ++l) {
     if (!(level_mask & (1 << l))) continue;
-    PullGeom g;
-    if (!make_pull_geom(lg, l, dtype, B, Nq, M, &g))
+    if (!make_pull_geom(lg, l, dtype, B, Nq, M, &gs.g[gs.n]))
       return fail(DSKD_ERR_INVALID_ARG, "dskd_msda_bwd: level %d does not fit the pull kernel's tables", l);
+    ++gs.n;
+  }
+  for (int i = 0; i < gs.n; ++i) {
+    const PullGeom& g = gs.g[i];
     int rc;
-    const LevelPlan pl = plan_level(l, dtype);
+    const LevelPlan pl = plan_level(g.tl, dtype);
 #define DSKD_PULL_LAUNCH(NT_)                                                                                      \
   (pl.R == 1 ? launch_pull_level<T, NT_, 1>(loc, attn, grad_out, grad_value, g, hdr, fb, cap, st)                  \
              : launch_pull_level<T, NT_, 4>(loc, attn, grad_out, grad_value, g, hdr, fb, cap, st))
@@ -663,7 +673,6 @@ int launch_pull_t(const float* loc, const float* attn, const T* grad_out, float*
     else rc = DSKD_PULL_LAUNCH(256);
 #undef DSKD_PULL_LAUNCH
     if (rc) return rc;
-    gs.g[gs.n++] = g;
   }
   if (gs.n == 0) return DSKD_OK;
   hipLaunchKernelGGL(msda_bwd_pull_apply_kernel<T>, dim3(256), dim3(kMaxThreads), 0, st, loc, attn, grad_out, grad_value,
