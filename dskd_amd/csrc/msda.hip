@@ -1636,7 +1636,7 @@ __global__ __launch_bounds__(1024) void msda_bwd_win_kernel(
   const int ql = lane >> 2;                  // query of the pass
   const int zero_slot = fw.npos * PIXB;
 
-  f32x2 n_xy[kMaxLevels];
+  f32x2 n_xy[kMaxLevels] = {};
   float n_a[kMaxLevels];
   u32x4 n_go = u32x4{0u, 0u, 0u, 0u};
   int n_qg = -1;
@@ -1647,8 +1647,8 @@ __global__ __launch_bounds__(1024) void msda_bwd_win_kernel(
       const size_t base = (((size_t)b * Nq + n_qg) * kHeads + h) * (size_t)LP + part;
 #pragma unroll
       for (int l = 0; l < kMaxLevels; ++l) {
-        n_xy[l] = *reinterpret_cast<const f32x2*>(loc + (base + l * points) * 2);
-        n_a[l] = attn[base + l * points];
+        if (l < fw.lv_end) n_xy[l] = *reinterpret_cast<const f32x2*>(loc + (base + l * points) * 2);
+        n_a[l] = attn[base + l * points];      // every level's weight: the statistics need them (same 64-byte line)
       }
       n_go = *reinterpret_cast<const u32x4*>(grad_out + ((size_t)b * Nq + n_qg) * (kHeads * kCh) + h * kCh + part * 8);
     }
@@ -2011,7 +2011,10 @@ int msda_bwd_impl(const void* value, const int64_t* spatial_shapes, const int64_
   }
   if (windowed && dtype == DSKD_DTYPE_BF16) {
     fuse23 = workspace && !legacy && (pull_mask >> 2) == 0;     // levels 2+3 on the windowed kernel (the default split)
-    gather_win = make_fwd_win_geom(g, levels, points, Nq, 2, 8, &wg, &fw, &wl, fuse23 ? 2 : kMaxLevels);
+    const int gnw = 8;      // waves per gather workgroup (4: 175 us, 8: 152-159 us, 12 / 16: 200-206 us)
+    // fused path: the gather keeps levels 0+1 -- level 1's windows (23 KB) in LDS, level 0 on the buffer-load path
+    // (measured: 152 us against 168 us with no window and 203 us with both levels' windows)
+    gather_win = make_fwd_win_geom(g, levels, points, Nq, fuse23 ? 1 : 2, gnw, &wg, &fw, &wl, fuse23 ? 2 : kMaxLevels);
     if (gather_win) {
       wl += (size_t)fw.waves * 16 * 16 * 12 + (size_t)fw.waves * 16;   // parked (gx, gy, ga) triples; statistics partials
       gather_win = wl <= kMaxLds;
