@@ -133,9 +133,12 @@ def train_step(model, wrapped, optimizer, data, synth, amp_dtype, max_norm=0.1, 
     if ahead is not None:       # the next batch (synthetic: the same tensors), enqueued behind the backward
         ahead.launch(data["img"], data["img_metas"], amp_dtype=amp_dtype)
     loss.backward()
-    params = [p for gr in optimizer.param_groups for p in gr["params"] if p.grad is not None]
-    torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm, norm_type=2)
-    optimizer.step()
+    if hasattr(optimizer, "clip_and_step"):       # dskd_amd.optim.FusedClipAdamW: clip + AdamW of every tensor, two launches
+        optimizer.clip_and_step(max_norm)
+    else:
+        params = [p for gr in optimizer.param_groups for p in gr["params"] if p.grad is not None]
+        torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm, norm_type=2)
+        optimizer.step()
     return loss, log_vars
 
 

@@ -50,6 +50,8 @@ _SIGNATURES = {
     "dskd_lin256_pack": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_lin256_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_gemm_nt": (C.c_int, [_vp] * 5 + [_i64] + [C.c_int] * 9 + [_vp]),
+    "dskd_clip_adamw_chunk": (C.c_int, []),
+    "dskd_clip_adamw": (C.c_int, [_vp] * 5 + [C.c_int, C.c_int, _vp, _vp, C.c_int, _f32, _f32, _f32, _i64, _f32, _vp]),
     "dskd_gn_workspace": (_i64, [C.c_int, _i64]),
     "dskd_nhwc_to_nchw_f32": (C.c_int, [_vp, _vp, C.c_int, _i64, C.c_int, _i64, C.c_int, _vp]),
     "dskd_gn_fwd": (C.c_int, [_vp] * 6 + [C.c_int, _i64, C.c_int, C.c_int, _i64, _i64, _f32, C.c_int, C.c_int, _vp]),

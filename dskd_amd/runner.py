@@ -17,7 +17,7 @@ from .datasets import to_device
 from .dist import get_dist_info
 
 
-def build_optimizer(model, cfg, capturable=False):
+def build_optimizer(model, cfg, capturable=False, fused_clip=True):
     """ext-mmcv DefaultOptimizerConstructor semantics for the keys used by the DSKD configs:
     a parameter whose name contains a custom key gets lr * lr_mult (longest key wins)."""
     cfg = dict(cfg)
@@ -43,8 +43,14 @@ def build_optimizer(model, cfg, capturable=False):
     for g in groups:
         merged.setdefault((g["lr"], g["weight_decay"]), []).extend(g["params"])
     groups = [{"params": ps, "lr": lr, "weight_decay": wd} for (lr, wd), ps in merged.items()]
-    opt_cls = getattr(torch.optim, typ)
     kwargs = {k: v for k, v in cfg.items() if k not in ("lr", "weight_decay")}
+    if typ == "AdamW" and not capturable and fused_clip and len(groups) <= 8 and not kwargs.get("amsgrad") and \
+            all(p.is_cuda and p.dtype == torch.float32 for g in groups for p in g["params"]):
+        # clip + update of all tensors in two launches (csrc/optim.hip); the runner calls clip_and_step(max_norm)
+        from .optim import FusedClipAdamW
+        return FusedClipAdamW(groups, lr=base_lr, weight_decay=base_wd,
+                              **{k: v for k, v in kwargs.items() if k in ("betas", "eps")})
+    opt_cls = getattr(torch.optim, typ)
     if typ in ("AdamW", "Adam") and all(p.is_cuda for g in groups for p in g["params"]):
         kwargs.setdefault("fused", True)     # one multi-tensor kernel per group on the GPU
         if capturable:
@@ -115,10 +121,13 @@ class TaskEpochBasedRunner:
             if ahead is not None and next_data is not None:
                 ahead.launch(next_data["img"], next_data["img_metas"], amp_dtype=self.amp_dtype)
         out["loss"].backward()
-        if self.grad_clip:
-            params = [p for g in self.optimizer.param_groups for p in g["params"] if p.grad is not None]
-            out["grad_norm"] = torch.nn.utils.clip_grad_norm_(params, **self.grad_clip)
-        self.optimizer.step()
+        if self.grad_clip and hasattr(self.optimizer, "clip_and_step") and self.grad_clip.get("norm_type", 2) == 2:
+            out["grad_norm"] = self.optimizer.clip_and_step(self.grad_clip["max_norm"])      # two launches for both
+        else:
+            if self.grad_clip:
+                params = [p for g in self.optimizer.param_groups for p in g["params"] if p.grad is not None]
+                out["grad_norm"] = torch.nn.utils.clip_grad_norm_(params, **self.grad_clip)
+            self.optimizer.step()
         self.iter += 1
         return out
 

@@ -378,6 +378,22 @@ int dskd_gemm_nt(const void* x, const void* w, const void* bias, const void* res
                  int relu, int stride, int Ho, int Wo, int Hi, int Wi, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * Global-norm gradient clipping + AdamW for every trainable tensor in two launches -- the reference's optimizer hook
+ * (configs/deformable_detr/..._il.py:213-224: AdamW, grad_clip max_norm 0.1; ext-mmcv OptimizerHook = clip_grad_norm_ then
+ * optimizer.step()), f32 parameters / gradients / moments.  Device tables (int64 addresses, filled by the caller):
+ *   ptrs   [4][n_tensors]  parameter, gradient, exp_avg, exp_avg_sq
+ *   meta   [n_tensors][2]  number of elements, parameter group
+ *   chunks [n_chunks][2]   tensor, first element -- one entry per dskd_clip_adamw_chunk() elements of every tensor
+ *   partials [n_chunks] f32 scratch;  norm_out [2] f32: total gradient norm, clip coefficient
+ * lr / weight_decay: HOST arrays, one entry per group (<= 8); step = 1, 2, ... (bias corrections); max_norm <= 0: no
+ * clipping.  The gradients are not modified (the clipped gradient exists only inside the update).
+ * ------------------------------------------------------------------------- */
+int dskd_clip_adamw_chunk(void);
+int dskd_clip_adamw(const int64_t* ptrs, const int32_t* meta, const int32_t* chunks, float* partials, float* norm_out,
+                    int n_tensors, int n_chunks, const float* lr, const float* weight_decay, int n_groups, float beta1,
+                    float beta2, float eps, int64_t step, float max_norm, void* stream);
+
+/* ---------------------------------------------------------------------------
  * GroupNorm(32 groups, 256 channels) on a channels_last activation -- the norm of every ChannelMapper level
  * (mmdet/models/necks/channel_mapper.py:10-100: ext-mmcv ConvModule(conv, GN)); replaces F.group_norm and, under
  * autocast, the f32 casts and layout copies around it.  Other channel / group counts are refused.

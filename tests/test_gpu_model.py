@@ -410,19 +410,24 @@ def test_teacher_decode_values_on_gpu_vs_reference_goldens(tag):
     _teacher_decode_case(tag, torch.device("cuda:0"))
 
 
-def test_adamw_clip_update_gpu_matches_cpu():
+@pytest.mark.parametrize("fused_clip", [True, False], ids=["dskd_clip_adamw", "torch_fused"])
+def test_adamw_clip_update_gpu_matches_cpu(fused_clip):
     """Row A13: three optimizer updates (global-norm clip max_norm=0.1, AdamW with the config's parameter groups /
-    lr multipliers, warm-up lr) on the GPU -- fused multi-tensor AdamW -- against the same updates on the CPU from
-    identical gradients: every parameter agrees to rounding, and so does the clip's norm."""
+    lr multipliers, warm-up lr) on the GPU -- the two-launch ``dskd_clip_adamw`` (dskd_amd.optim.FusedClipAdamW, the
+    default) and PyTorch's fused multi-tensor AdamW behind ``clip_grad_norm_`` -- against the same updates on the CPU
+    (``torch.optim.AdamW``, ``clip_grad_norm_``) from identical gradients: every parameter agrees to rounding, and so does
+    the clip's norm; channels_last convolution weights included."""
+    from dskd_amd.optim import FusedClipAdamW
     from dskd_amd.runner import StepLrWarmup
     cfg, m_cpu = _build(seed=4, num_query=50)
-    m_gpu = copy.deepcopy(m_cpu).to("cuda:0")
+    m_gpu = copy.deepcopy(m_cpu).to("cuda:0").to(memory_format=torch.channels_last)
     opts, lrs = [], []
     for m in (m_cpu, m_gpu):
-        o = build_optimizer(m, cfg.optimizer[0])
+        o = build_optimizer(m, cfg.optimizer[0], fused_clip=fused_clip)
         opts.append(o)
         lrs.append(StepLrWarmup(o, **{k: v for k, v in dict(cfg.lr_config[0]).items() if k != "policy"}))
-    assert opts[1].defaults.get("fused") and not opts[0].defaults.get("fused")
+    assert isinstance(opts[1], FusedClipAdamW) == fused_clip and not isinstance(opts[0], FusedClipAdamW)
+    assert fused_clip or opts[1].defaults.get("fused")
     g = torch.Generator().manual_seed(99)
     pc, pg = dict(m_cpu.named_parameters()), dict(m_gpu.named_parameters())
     train = [n for n, p in pc.items() if p.requires_grad]
@@ -430,21 +435,38 @@ def test_adamw_clip_update_gpu_matches_cpu():
     for it in range(3):
         for n in train:
             gr = torch.randn(pc[n].shape, generator=g) * (10.0 ** (it - 1))      # clip active, very different scales
-            pc[n].grad, pg[n].grad = gr.clone(), gr.to("cuda:0")
+            pc[n].grad = gr.clone()
+            pg[n].grad = torch.empty_like(pg[n]).copy_(gr)                        # the parameter's layout, as autograd makes it
+        keep = pg[train[0]].grad.clone()
         norms = []
         for lr, o, params in ((lrs[0], opts[0], pc), (lrs[1], opts[1], pg)):
             lr.set(0, it)
-            norms.append(float(torch.nn.utils.clip_grad_norm_([params[n] for n in train], max_norm=0.1, norm_type=2)))
-            o.step()
+            if hasattr(o, "clip_and_step"):
+                norms.append(float(o.clip_and_step(0.1)))
+                assert float(o.last_norm[1]) == pytest.approx(min(1.0, 0.1 / (norms[-1] + 1e-6)), rel=1e-5)
+            else:
+                norms.append(float(torch.nn.utils.clip_grad_norm_([params[n] for n in train], max_norm=0.1, norm_type=2)))
+                o.step()
         assert norms[1] == pytest.approx(norms[0], rel=1e-4)          # fp32 sum of 40 M squares, two summation orders
         assert [gr["lr"] for gr in opts[0].param_groups] == [gr["lr"] for gr in opts[1].param_groups]
-    worst = 0.0
+        if fused_clip:
+            assert torch.equal(pg[train[0]].grad, keep)               # the gradients are not rewritten
     for n in train:
         torch.testing.assert_close(pg[n].detach().cpu(), pc[n].detach(), rtol=2e-5, atol=2e-7, msg=lambda m: f"{n}: {m}")
-        worst = max(worst, float((pg[n].detach().cpu() - pc[n].detach()).abs().max()))
     # the parameters did move (lr_mult 0.1 groups included)
     assert float((pc["backbone.layer4.2.conv3.weight"] - dict(_build(seed=4, num_query=50)[1].named_parameters())
                   ["backbone.layer4.2.conv3.weight"]).abs().max()) > 0
+    if fused_clip:      # state layout of torch.optim.AdamW: a checkpoint written by one loads into the other
+        sd = opts[1].state_dict()
+        st0 = sd["state"][0]
+        assert set(st0) == {"step", "exp_avg", "exp_avg_sq"} and int(st0["step"]) == 3
+        ref = torch.optim.AdamW([{"params": list(gr["params"])} for gr in opts[1].param_groups], lr=1e-4)
+        ref.load_state_dict(sd)
+        opts[1].load_state_dict(ref.state_dict())
+        for n in train[:3]:
+            pg[n].grad = torch.zeros_like(pg[n])
+        opts[1].clip_and_step(0.1)
+        assert int(opts[1].state[pg[train[0]]]["step"]) == 4
 
 
 def test_teacher_ahead_is_invalidated_by_set_teacher():
