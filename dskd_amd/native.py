@@ -50,6 +50,8 @@ _SIGNATURES = {
     "dskd_lin256_pack": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_lin256_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_gemm_nt": (C.c_int, [_vp] * 5 + [_i64] + [C.c_int] * 9 + [_vp]),
+    "dskd_winattn_fwd": (C.c_int, [_vp] * 4 + [C.c_int] * 5 + [_f32, C.c_int, _vp]),
+    "dskd_winattn_bwd": (C.c_int, [_vp] * 6 + [C.c_int] * 5 + [_f32, C.c_int, _vp]),
     "dskd_clip_adamw_chunk": (C.c_int, []),
     "dskd_clip_adamw": (C.c_int, [_vp] * 5 + [C.c_int, C.c_int, _vp, _vp, C.c_int, _f32, _f32, _f32, _i64, _f32, _vp]),
     "dskd_gn_workspace": (_i64, [C.c_int, _i64]),
@@ -788,6 +790,70 @@ def conv1x1(x, w, bias=None, identity=None, relu=False, stride=1):
     if identity is not None and (identity.dtype != x.dtype or not identity.is_contiguous(memory_format=torch.channels_last)):
         identity = identity.to(x.dtype).contiguous(memory_format=torch.channels_last)
     return _Conv1x1Function.apply(x, w, bias, identity, bool(relu), int(stride))
+
+
+# --------------------------------------------------------------------------- Swin window attention (MFMA kernels)
+WINATTN_TOKENS, WINATTN_HEAD_DIM, WINATTN_NEG = 49, 32, -30000.0
+
+
+def window_attention_ok(qkv: torch.Tensor, num_heads: int, tokens: int, dropout_p: float) -> bool:
+    """Can csrc/winattn.hip take this call: 49-token windows, head dimension 32, bf16 CUDA projection output, no
+    attention dropout?"""
+    return (qkv.is_cuda and qkv.dtype == torch.bfloat16 and qkv.dim() == 3 and tokens == WINATTN_TOKENS
+            and qkv.shape[1] == tokens and qkv.shape[2] == 3 * num_heads * WINATTN_HEAD_DIM and dropout_p == 0.0
+            and qkv.is_contiguous() and qkv.data_ptr() % 16 == 0)
+
+
+def window_attention_table(bias: torch.Tensor, mask_types: Optional[torch.Tensor]) -> torch.Tensor:
+    """The additive table the kernels read: [types][heads][64 keys][64 queries] f32 = bias[h][q][k] + mask[type][q][k],
+    -30000 on the padded keys.  bias [heads, 49, 49] (query, key); mask_types [types, 49, 49] or None."""
+    nH, N, _ = bias.shape
+    t = bias.detach().float().transpose(1, 2).unsqueeze(0)                       # [1, h, k, q]
+    if mask_types is not None:
+        t = t + mask_types.float().transpose(1, 2).unsqueeze(1)                  # [types, h, k, q]
+    out = torch.zeros((t.shape[0], nH, 64, 64), dtype=torch.float32, device=bias.device)
+    out[:, :, N:, :] = WINATTN_NEG
+    out[:, :, :N, :N] = t
+    return out
+
+
+class _WindowAttentionFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, bias, mask_types, wtype, num_heads, scale):
+        Bw, N, _ = qkv.shape
+        table = window_attention_table(bias, mask_types)
+        nW = 1 if wtype is None else wtype.numel()
+        out = torch.empty((Bw, N, num_heads * WINATTN_HEAD_DIM), dtype=qkv.dtype, device=qkv.device)
+        rc = load().dskd_winattn_fwd(qkv.data_ptr(), table.data_ptr(), None if wtype is None else wtype.data_ptr(),
+                                     out.data_ptr(), Bw, num_heads, nW, N, WINATTN_HEAD_DIM, scale, DTYPE_BF16, _stream(qkv))
+        _check(rc, "dskd_winattn_fwd")
+        ctx.save_for_backward(qkv, table, wtype)
+        ctx.meta = (num_heads, scale, nW, bias.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, table, wtype = ctx.saved_tensors
+        num_heads, scale, nW, bdtype = ctx.meta
+        Bw, N, _ = qkv.shape
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        dtable = zeros((num_heads, 64, 64), torch.float32, qkv.device)
+        rc = load().dskd_winattn_bwd(qkv.data_ptr(), table.data_ptr(), None if wtype is None else wtype.data_ptr(),
+                                     dout.data_ptr(), dqkv.data_ptr(), dtable.data_ptr(), Bw, num_heads, nW, N,
+                                     WINATTN_HEAD_DIM, scale, DTYPE_BF16, _stream(qkv))
+        _check(rc, "dskd_winattn_bwd")
+        dbias = dtable[:, :N, :N].transpose(1, 2).to(bdtype) if ctx.needs_input_grad[1] else None      # [h, q, k]
+        return dqkv, dbias, None, None, None, None
+
+
+def window_attention(qkv: torch.Tensor, bias: torch.Tensor, mask_types: Optional[torch.Tensor],
+                     wtype: Optional[torch.Tensor], num_heads: int, scale: float) -> torch.Tensor:
+    """``softmax(q k^T * scale + bias (+ mask)) v`` per window and head (reference: WindowMSA.forward,
+    mmdet/models/backbones/swin.py:81-126).  qkv [windows, 49, 3 * heads * 32] = the qkv Linear's output; bias
+    [heads, 49, 49] (differentiable); mask_types [types, 49, 49] with wtype [windows per image] int32 (type of each window
+    of an image) or both None.  Returns [windows, 49, heads * 32], the input of the output projection."""
+    return _WindowAttentionFunction.apply(qkv, bias, mask_types, wtype, int(num_heads), float(scale))
 
 
 # --------------------------------------------------------------------------- GroupNorm of the neck

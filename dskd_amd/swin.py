@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import native
 from .builder import BACKBONES
 
 
@@ -149,11 +150,28 @@ class WindowMSA(nn.Module):
         N = self.window_size[0] * self.window_size[1]
         return self.relative_position_bias_table[self.relative_position_index.view(-1)].view(N, N, -1).permute(2, 0, 1)
 
+    def _mask_types(self, mask):
+        """The distinct masks of a shifted layer (at most four: interior, last row, last column, corner of the window
+        grid) and the type of each window of an image; cached per mask tensor."""
+        key = (mask.data_ptr(), tuple(mask.shape))
+        if self.__dict__.get("_mt_key") != key:
+            nW = mask.shape[0]
+            types, inverse = torch.unique(mask.reshape(nW, -1), dim=0, return_inverse=True)
+            self.__dict__["_mt_key"] = key
+            self.__dict__["_mt"] = (types.view(-1, mask.shape[1], mask.shape[2]).contiguous(), inverse.to(torch.int32).contiguous(), mask)
+        return self.__dict__["_mt"][:2]
+
     def forward(self, x, mask=None):
         """x [nW*B, N, C]; mask [nW, N, N] additive (0 / -100) or None."""
         Bw, N, C = x.shape
         nH, d = self.num_heads, C // self.num_heads
-        qkv = self.qkv(x).view(Bw, N, 3, nH, d).permute(2, 0, 3, 1, 4)
+        qkv_flat = self.qkv(x)
+        if d == native.WINATTN_HEAD_DIM and native.window_attention_ok(qkv_flat, nH, N, self.attn_drop.p if self.training else 0.0):
+            # hand-written MFMA window attention (csrc/winattn.hip): q / k / v read in place, no [Bw, nH, N, N] bias tensor
+            types, wtype = (None, None) if mask is None else self._mask_types(mask)
+            x = native.window_attention(qkv_flat, self.bias(), types, wtype, nH, self.scale)
+            return self.proj_drop(self.proj(x))
+        qkv = qkv_flat.view(Bw, N, 3, nH, d).permute(2, 0, 3, 1, 4)
         q, k, v = qkv[0], qkv[1], qkv[2]
         bias = self.bias()                                                  # [nH, N, N]
         if mask is not None:

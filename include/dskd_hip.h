@@ -378,6 +378,23 @@ int dskd_gemm_nt(const void* x, const void* w, const void* bias, const void* res
                  int relu, int stride, int Ho, int Wo, int Hi, int Wi, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * Window attention of the Swin backbone (BASELINE configs[3]): softmax(q k^T * scale + bias (+ shift mask)) v for
+ * windows of 49 tokens and head dimension 32 -- WindowMSA.forward of the reference between its qkv Linear and its output
+ * projection (mmdet/models/backbones/swin.py:81-126; the mask of ShiftWindowMSA :180-286) -- and its backward, one wave
+ * per (window, head) on the matrix cores (csrc/winattn.hip).  bf16.
+ *   qkv    [windows, 49, 3, heads, 32]   the projection's output as it stands (q, k, v interleaved per token)
+ *   table  [types][heads][64][64] f32    additive term [key][query]: relative position bias + mask of that type; -30000
+ *                                        on the padded keys (>= 49)
+ *   wtype  [nW] int32 or NULL            mask type of the nW windows of one image (window w uses wtype[w % nW])
+ *   out    [windows, 49, heads * 32]     what the output projection reads;  dout: its gradient, same layout
+ *   dqkv   [windows, 49, 3, heads, 32];  dtable [heads][64][64] f32: += the bias gradient [key][query] (zero it first)
+ * ------------------------------------------------------------------------- */
+int dskd_winattn_fwd(const void* qkv, const float* table, const int32_t* wtype, void* out, int windows, int heads, int nW,
+                     int tokens, int head_dim, float scale, int dtype, void* stream);
+int dskd_winattn_bwd(const void* qkv, const float* table, const int32_t* wtype, const void* dout, void* dqkv, float* dtable,
+                     int windows, int heads, int nW, int tokens, int head_dim, float scale, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------
  * Global-norm gradient clipping + AdamW for every trainable tensor in two launches -- the reference's optimizer hook
  * (configs/deformable_detr/..._il.py:213-224: AdamW, grad_clip max_norm 0.1; ext-mmcv OptimizerHook = clip_grad_norm_ then
  * optimizer.step()), f32 parameters / gradients / moments.  Device tables (int64 addresses, filled by the caller):

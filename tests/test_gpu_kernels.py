@@ -1,4 +1,6 @@
 """Parity of every HIP kernel against the CPU oracle, through the C-ABI (-m gpu)."""
+import copy
+
 import numpy as np
 import pytest
 import torch
@@ -1274,3 +1276,93 @@ def test_conv1x1_mfma_full_size_layer1():
     rd = res.to(DEV).permute(0, 3, 1, 2)
     y = native.conv1x1(xd, w.to(DEV).view(N, K, 1, 1), b.to(DEV), rd, True, 1)
     assert _close(y.permute(0, 2, 3, 1).reshape(-1, N), ref, 8e-3)
+
+
+# --------------------------------------------------------------------------- Swin window attention (csrc/winattn.hip)
+def _window_attention_reference(qkv, bias, mask, nH, scale):
+    """WindowMSA.forward of the reference between qkv and proj (mmdet/models/backbones/swin.py:81-126) in plain fp32 ops:
+    q * scale @ k^T + bias (+ mask per window) -> softmax -> @ v -> [Bw, N, C]."""
+    Bw, N, _ = qkv.shape
+    q, k, v = qkv.view(Bw, N, 3, nH, 32).permute(2, 0, 3, 1, 4)
+    attn = (q * scale) @ k.transpose(-2, -1) + bias.unsqueeze(0)
+    if mask is not None:
+        nW = mask.shape[0]
+        attn = (attn.view(Bw // nW, nW, nH, N, N) + mask.unsqueeze(1).unsqueeze(0)).view(Bw, nH, N, N)
+    return (attn.softmax(-1) @ v).transpose(1, 2).reshape(Bw, N, nH * 32)
+
+
+@pytest.mark.parametrize("nH,nW,images,shifted", [(3, 12, 2, True), (6, 6, 1, False), (24, 4, 3, True), (12, 1, 5, False)])
+def test_window_attention_vs_float_reference(nH, nW, images, shifted):
+    """dskd_winattn_fwd / dskd_winattn_bwd (native.window_attention) against the reference formula evaluated in fp32 on the
+    CPU from the same bf16 inputs: output, d(qkv) and the relative-position-bias gradient; shifted layers with several
+    distinct masks (blocks of -100 as ShiftWindowMSA builds them), ragged window counts (tasks not a multiple of the
+    waves per workgroup).  Tolerances: output 8e-3 of the largest magnitude (bf16 result of f32 accumulation; P is rounded
+    to bf16 before P V as in every fused attention), gradients 2e-2 (dS is rounded to bf16 before the dQ / dK products)."""
+    N, C = 49, nH * 32
+    Bw = nW * images
+    g = torch.Generator().manual_seed(nH * 7 + nW)
+    qkv = (torch.randn(Bw, N, 3 * C, generator=g) * 1.5).bfloat16()
+    bias = torch.randn(nH, N, N, generator=g) * 0.5
+    up = torch.randn(Bw, N, C, generator=g).bfloat16()
+    scale = 32 ** -0.5
+    mask = None
+    if shifted:                               # label maps like the reference's img_mask, a few distinct ones
+        mask = torch.zeros(nW, N, N)
+        for w in range(nW):
+            kind = w % 4
+            lab = torch.zeros(7, 7)
+            if kind in (1, 3):
+                lab[:, 4:] += 1
+            if kind in (2, 3):
+                lab[4:, :] += 2
+            lab = lab.view(-1)
+            mask[w] = (lab[None, :] != lab[:, None]).float() * -100.0
+    qr, br = qkv.float().requires_grad_(True), bias.clone().requires_grad_(True)
+    ref = _window_attention_reference(qr, br, mask, nH, scale)
+    gq, gb = torch.autograd.grad(ref, (qr, br), up.float())
+
+    qd = qkv.to(DEV).requires_grad_(True)
+    bd = bias.to(DEV).requires_grad_(True)
+    types = wtype = None
+    if shifted:
+        t, inv = torch.unique(mask.view(nW, -1), dim=0, return_inverse=True)
+        types, wtype = t.view(-1, N, N).to(DEV), inv.to(torch.int32).to(DEV)
+        assert types.shape[0] == min(4, nW)
+    assert native.window_attention_ok(qd, nH, N, 0.0)
+    out = native.window_attention(qd, bd, types, wtype, nH, scale)
+    assert out.shape == (Bw, N, C) and out.dtype == torch.bfloat16
+    assert _close(out, ref.detach(), 8e-3)
+    dq, db = torch.autograd.grad(out, (qd, bd), up.to(DEV))
+    assert _close(dq, gq, 2e-2), float((dq.float().cpu() - gq).abs().max()) / float(gq.abs().max())
+    assert _close(db, gb, 2e-2), float((db.float().cpu() - gb).abs().max()) / float(gb.abs().max())
+
+
+@pytest.mark.parametrize("shift", [0, 3])
+def test_shift_window_msa_module_uses_the_mfma_kernel(shift):
+    """swin.ShiftWindowMSA on the GPU under bf16 autocast (window attention through csrc/winattn.hip) against the same
+    module on the CPU in fp32 (SDPA path), padded resolution (9 x 13 tokens): output and every parameter gradient."""
+    from dskd_amd import swin
+    torch.manual_seed(5 + shift)
+    att = swin.ShiftWindowMSA(96, 3, 7, shift_size=shift).eval()
+    with torch.no_grad():
+        att.w_msa.relative_position_bias_table.normal_(std=0.5)
+    x = torch.randn(2, 9 * 13, 96)
+    up = torch.randn(2, 9 * 13, 96)
+    xc = x.clone().requires_grad_(True)
+    yc = att(xc, (9, 13))
+    gc = torch.autograd.grad(yc, [xc] + list(att.parameters()), up)
+    att_d = copy.deepcopy(att).to(DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    calls = []
+    orig = native.window_attention
+    native.window_attention = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            yd = att_d(xd, (9, 13))
+    finally:
+        native.window_attention = orig
+    assert calls, "the MFMA window-attention kernel was not used"
+    gd = torch.autograd.grad(yd, [xd] + list(att_d.parameters()), up.to(DEV))
+    assert _close(yd, yc.detach(), 3e-2)
+    for a, r in zip(gd, gc):
+        assert _close(a, r, 5e-2), (tuple(r.shape), float((a.float().cpu() - r).abs().max()) / float(r.abs().max()))
