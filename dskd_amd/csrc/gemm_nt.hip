@@ -13,8 +13,8 @@
 // ~270 TFLOP/s with a second pass over every output for the epilogue (profiles/r02_step_breakdown.txt).
 //
 // Structure (cdna_hip_programming.md section 5):
-//  * workgroup = 4 waves, tile 128 tokens x 128 outputs (x 64 outputs when N == 64); every wave owns 64 outputs x
-//    (64 | 32) tokens = 2 x (2 | 1) accumulator tiles of v_mfma_f32_32x32x16_bf16.  The WEIGHT is the A operand and the
+//  * workgroup = 4 waves, tile 64 tokens x 128 outputs (128 x 64 when N is not a multiple of 128); every wave owns 64
+//    outputs x 32 tokens = 2 accumulator tiles of v_mfma_f32_32x32x16_bf16.  The WEIGHT is the A operand and the
 //    activation the B operand, so a lane ends up with ONE token and -- rows of the A tile permuted by pi (as in
 //    ffn_mfma.hip) -- 16 CONSECUTIVE output channels per accumulator tile: 32 contiguous bytes per lane, bias / residual
 //    / ReLU in registers, two 16-byte stores.
@@ -153,12 +153,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs a) {
   constexpr int NS = 2;
   constexpr int WN = BN / 64;              // waves along the outputs
   constexpr int WM = 4 / WN;               // waves along the tokens
-  constexpr int BM = WM * MT * 32;         // 128
-  static_assert(BM == 128, "tile");
+  constexpr int BM = WM * MT * 32;         // 128, or 64 for <128, 1>
+  constexpr int XRB = BM / 64;             // 16-row activation blocks whose DMA this wave issues
   constexpr int PX = BM * 64, PW = BN * 64;          // bytes of one 32-k panel
   constexpr int STAGE = 2 * (PX + PW);
   constexpr int WRB = BN / 64;             // 16-row weight blocks whose DMA this wave issues (activation: always 2)
-  constexpr int LOADS = 2 * (2 + WRB);     // LDS-DMA instructions per wave and stage
+  constexpr int LOADS = 2 * (XRB + WRB);   // LDS-DMA instructions per wave and stage
   extern __shared__ __attribute__((aligned(16))) char smem[];      // NS stages
 
   const int lane = threadIdx.x & 63;
@@ -177,11 +177,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs a) {
   // ---- per-lane source pointers of the LDS-DMA: lane i of an instruction fills row (i >> 2), chunk position (i & 3)
   const int lr = lane >> 2;
   const int csw = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;      // logical chunk held at that position (bytes)
-  const char* xp[2];
+  const char* xp[XRB];
   const char* wp[WRB];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    long long m = m0 + (wave * 2 + j) * 16 + lr;
+  for (int j = 0; j < XRB; ++j) {
+    long long m = m0 + (wave * XRB + j) * 16 + lr;
     if (m >= a.M) m = a.M - 1;                                // rows past the end: any valid row, never stored
     long long row = m;
     if (a.s) {
@@ -201,11 +201,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs a) {
     char* sw = sx + 2 * PX;
     const int kb = kt * 128;                                  // bytes along K
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < XRB; ++j)
 #pragma unroll
       for (int p = 0; p < 2; ++p)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xp[j] + kb + p * 64),
-                                         (__attribute__((address_space(3))) void*)(sx + p * PX + (wave * 2 + j) * 1024),
+                                         (__attribute__((address_space(3))) void*)(sx + p * PX + (wave * XRB + j) * 1024),
                                          16, 0, 0);
 #pragma unroll
     for (int j = 0; j < WRB; ++j)
@@ -262,7 +262,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs a) {
 
 template <int BN, int MT>
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
-  constexpr int LDS = 2 * 2 * (128 * 64 + BN * 64);
+  constexpr int BM = (4 / (BN / 64)) * MT * 32;
+  constexpr int LDS = 2 * 2 * (BM * 64 + BN * 64);
   auto kern = gemm_nt_kernel<BN, MT>;
   int dev = 0;
   static bool done[64] = {};              // the attribute is per device: set it once on each
@@ -272,7 +273,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
       return fail(DSKD_ERR_LAUNCH, "dskd_gemm_nt: cannot reserve %d bytes of LDS", LDS);
     done[dev] = true;
   }
-  const long long tiles = ((a.M + 127) / 128) * (a.N / BN);
+  const long long tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
   if (tiles > 0x7FFFFFFFll) return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_nt: too many tiles");
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), LDS, st, a);
   return check_launch("dskd_gemm_nt");
@@ -301,6 +302,9 @@ extern "C" int dskd_gemm_nt(const void* x, const void* w, const void* bias, cons
   a.y = (__bf16*)y; a.M = M; a.N = N; a.K = K; a.relu = relu;
   a.s = stride; a.HoWo = stride ? Ho * Wo : 1; a.Wo = stride ? Wo : 1; a.Hi = Hi; a.Wi = Wi;
   hipStream_t st = (hipStream_t)stream;
-  if (N % 128 == 0) return launch_gemm<128, 2>(a, st);
-  return launch_gemm<64, 1>(a, st);
+  if (N % 128) return launch_gemm<64, 1>(a, st);
+  // 64 tokens x 128 outputs per workgroup (each wave 32 x 64): measured faster than 128 x 128 on every layer shape of the
+  // trunk (one model forward 1.20 against 1.32 ms, scratch/r03_conv1x1.py) -- three workgroups per CU instead of two, and
+  // the deep layers (4 200 .. 16 800 tokens: 132 .. 1 056 tiles of 128 x 128 for 256 CUs) load the CUs more evenly.
+  return launch_gemm<128, 1>(a, st);
 }

@@ -15,7 +15,8 @@ from typing import List, Optional, Sequence, Tuple
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_C", "libdskd_hip.so")
+# DSKD_HIP_LIB: another build of the same library (A/B runs of kernel variants built with different -D flags)
+_LIB_PATH = os.environ.get("DSKD_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "_C", "libdskd_hip.so")
 _lib: Optional[C.CDLL] = None
 
 DTYPE_F32, DTYPE_BF16 = 0, 1
