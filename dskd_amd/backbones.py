@@ -83,6 +83,10 @@ def _conv_epilogue(conv, x, w, b, relu, identity):
             (identity is None or identity.is_cuda):
         # 1x1 convolution + folded-BN shift + residual + ReLU as ONE hand-written MFMA launch (csrc/gemm_nt.hip)
         return native.conv1x1(x, w, b, identity, relu, conv.stride[0])
+    if _CONV1X1_MFMA and native.conv3x3_ok(x, w, conv) and (b is None or b.shape[0] == w.shape[0]) and \
+            (identity is None or identity.is_cuda):
+        # 3x3 convolution as an implicit GEMM on the same kernel, epilogue fused (dskd_conv3x3)
+        return native.conv3x3(x, w, b, identity, relu, conv.stride[0])
     chunk = _conv1x1_gemm_wgrad(conv, x, w) if os.environ.get("DSKD_CONV_WGRAD_GEMM") else None
     if chunk is not None:
         y = _Conv1x1Fn.apply(x, w, chunk)

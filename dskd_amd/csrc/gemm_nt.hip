@@ -49,7 +49,12 @@ struct GemmArgs {
   int N, K, relu;
   // row map: output row m = (img, ho, wo) reads the activation row ((img * Hi + s * ho) * Wi + s * wo); s == 0: row m
   int s, HoWo, Wo, Hi, Wi;
+  // 3 x 3 convolution (padding 1): K = 9 * C with k = tap * C + c (the channels_last weight [N][ky][kx][C] as it lies);
+  // tap (ky, kx) reads the pixel (s ho + ky - 1, s wo + kx - 1), rows outside the image come from a page of zeros
+  int C, cshift;         // channels per tap, log2(C / 64)
 };
+
+__device__ __attribute__((aligned(256))) char g_zero_page[256];
 
 __device__ __forceinline__ unsigned lds_offset(const void* p) {
   return (unsigned)(unsigned long)((const __attribute__((address_space(3))) char*)p);
@@ -148,7 +153,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& a, const f32x16 (&acc
 // one round of the chip -- and there tile quantisation (264 = 256 + 8) and the second resident workgroup matter more
 // than the per-stage latency.  SQ counters of the K = 1024, N = 256, 16 800-token layer: no LDS bank conflicts, MFMA
 // pipe busy 24 % of the wave's lifetime, 30 % in s_waitcnt / barrier.
-template <int BN, int MT>
+template <int BN, int MT, bool CONV3>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs a) {
   constexpr int NS = 2;
   constexpr int WN = BN / 64;              // waves along the outputs
@@ -179,19 +184,28 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs a) {
   const int csw = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;      // logical chunk held at that position (bytes)
   const char* xp[XRB];
   const char* wp[WRB];
+  unsigned vmask[XRB];                                          // CONV3: taps whose pixel lies inside the image
 #pragma unroll
   for (int j = 0; j < XRB; ++j) {
     long long m = m0 + (wave * XRB + j) * 16 + lr;
     if (m >= a.M) m = a.M - 1;                                // rows past the end: any valid row, never stored
     long long row = m;
+    vmask[j] = 0x1FFu;
     if (a.s) {
       const long long img = m / a.HoWo;
       const int rem = (int)(m - img * a.HoWo);
       const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-      row = (img * a.Hi + (long long)a.s * ho) * a.Wi + (long long)a.s * wo;
+      const int hi = a.s * ho, wi = a.s * wo;
+      row = (img * a.Hi + hi) * a.Wi + wi;
+      if constexpr (CONV3) {
+        const unsigned rowm = (hi > 0 ? 1u : 0u) | 2u | (hi + 1 < a.Hi ? 4u : 0u);      // ky = 0, 1, 2
+        const unsigned colm = (wi > 0 ? 1u : 0u) | 2u | (wi + 1 < a.Wi ? 4u : 0u);      // kx = 0, 1, 2
+        vmask[j] = ((rowm & 1u) ? colm : 0u) | ((rowm & 2u) ? colm << 3 : 0u) | ((rowm & 4u) ? colm << 6 : 0u);
+      }
     }
-    xp[j] = reinterpret_cast<const char*>(a.x) + row * a.K * 2 + csw;
+    xp[j] = reinterpret_cast<const char*>(a.x) + row * (CONV3 ? a.C : a.K) * 2 + csw;
   }
+  const char* const zp = g_zero_page + csw;
 #pragma unroll
   for (int j = 0; j < WRB; ++j)
     wp[j] = reinterpret_cast<const char*>(a.w) + (long long)(n0 + (wave * WRB + j) * 16 + lr) * a.K * 2 + csw;
@@ -200,13 +214,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs a) {
     char* sx = smem + (kt % NS) * STAGE;
     char* sw = sx + 2 * PX;
     const int kb = kt * 128;                                  // bytes along K
+    int tap = 0, xoff = kb;
+    if constexpr (CONV3) {                                    // stage kt = 64 channels of ONE tap (C is a multiple of 64)
+      tap = kt >> a.cshift;
+      const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;       // tap / 3 for tap < 9
+      xoff = ((ky - 1) * a.Wi + (kx - 1)) * a.C * 2 + (kt - (tap << a.cshift)) * 128;
+    }
 #pragma unroll
-    for (int j = 0; j < XRB; ++j)
+    for (int j = 0; j < XRB; ++j) {
+      const char* src = xp[j] + xoff;
+      if constexpr (CONV3) src = ((vmask[j] >> tap) & 1u) ? src : zp;
 #pragma unroll
       for (int p = 0; p < 2; ++p)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xp[j] + kb + p * 64),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * 64),
                                          (__attribute__((address_space(3))) void*)(sx + p * PX + (wave * XRB + j) * 1024),
                                          16, 0, 0);
+    }
 #pragma unroll
     for (int j = 0; j < WRB; ++j)
 #pragma unroll
@@ -260,11 +283,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs a) {
   store_tile<MT>(a, acc, m0 + wm * MT * 32 + r, n0 + wn * 64 + 16 * h);
 }
 
-template <int BN, int MT>
+template <int BN, int MT, bool CONV3>
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
   constexpr int BM = (4 / (BN / 64)) * MT * 32;
   constexpr int LDS = 2 * 2 * (BM * 64 + BN * 64);
-  auto kern = gemm_nt_kernel<BN, MT>;
+  auto kern = gemm_nt_kernel<BN, MT, CONV3>;
   int dev = 0;
   static bool done[64] = {};              // the attribute is per device: set it once on each
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -302,9 +325,34 @@ extern "C" int dskd_gemm_nt(const void* x, const void* w, const void* bias, cons
   a.y = (__bf16*)y; a.M = M; a.N = N; a.K = K; a.relu = relu;
   a.s = stride; a.HoWo = stride ? Ho * Wo : 1; a.Wo = stride ? Wo : 1; a.Hi = Hi; a.Wi = Wi;
   hipStream_t st = (hipStream_t)stream;
-  if (N % 128) return launch_gemm<64, 1>(a, st);
+  a.C = K; a.cshift = 0;
+  if (N % 128) return launch_gemm<64, 1, false>(a, st);
   // 64 tokens x 128 outputs per workgroup (each wave 32 x 64): measured faster than 128 x 128 on every layer shape of the
   // trunk (one model forward 1.20 against 1.32 ms, scratch/r03_conv1x1.py) -- three workgroups per CU instead of two, and
   // the deep layers (4 200 .. 16 800 tokens: 132 .. 1 056 tiles of 128 x 128 for 256 CUs) load the CUs more evenly.
-  return launch_gemm<128, 1>(a, st);
+  return launch_gemm<128, 1, false>(a, st);
+}
+
+extern "C" int dskd_conv3x3(const void* x, const void* w, const void* bias, const void* res, void* y, int B, int Hi, int Wi,
+                            int C, int N, int stride, int relu, int dtype, void* stream) {
+  if (dtype != DSKD_DTYPE_BF16) return fail(DSKD_ERR_INVALID_ARG, "dskd_conv3x3: bf16 only");
+  if (!x || !w || !y || B < 0 || Hi <= 0 || Wi <= 0) return fail(DSKD_ERR_INVALID_ARG, "dskd_conv3x3: null pointer or bad size");
+  int cshift = 0;
+  while ((64 << cshift) < C) ++cshift;
+  if (C <= 0 || (64 << cshift) != C || cshift > 4 || N <= 0 || (N & 63))
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_conv3x3: C must be 64 * 2^k (<= 1024) and N a multiple of 64 (got C=%d N=%d)", C, N);
+  if (stride != 1 && stride != 2) return fail(DSKD_ERR_INVALID_ARG, "dskd_conv3x3: stride 1 or 2 (got %d)", stride);
+  auto mis = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
+  if (mis(x) || mis(w) || mis(y) || (bias && mis(bias)) || (res && mis(res)))
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_conv3x3: pointers must be 16-byte aligned");
+  const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;        // kernel 3, padding 1
+  if ((long long)Hi * Wi * C * 2 >= 0x7FFFFFFFll) return fail(DSKD_ERR_INVALID_ARG, "dskd_conv3x3: image too large");
+  if (B == 0) return DSKD_OK;
+  GemmArgs a;
+  a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = (const __bf16*)bias; a.res = (const __bf16*)res;
+  a.y = (__bf16*)y; a.M = (long long)B * Ho * Wo; a.N = N; a.K = 9 * C; a.relu = relu;
+  a.s = stride; a.HoWo = Ho * Wo; a.Wo = Wo; a.Hi = Hi; a.Wi = Wi; a.C = C; a.cshift = cshift;
+  hipStream_t st = (hipStream_t)stream;
+  if (N % 128) return launch_gemm<64, 1, true>(a, st);
+  return launch_gemm<128, 1, true>(a, st);
 }

@@ -51,6 +51,7 @@ _SIGNATURES = {
     "dskd_lin256_pack": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_lin256_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_gemm_nt": (C.c_int, [_vp] * 5 + [_i64] + [C.c_int] * 9 + [_vp]),
+    "dskd_conv3x3": (C.c_int, [_vp] * 5 + [C.c_int] * 8 + [_vp]),
     "dskd_winattn_fwd": (C.c_int, [_vp] * 4 + [C.c_int] * 5 + [_f32, C.c_int, _vp]),
     "dskd_winattn_bwd": (C.c_int, [_vp] * 6 + [C.c_int] * 5 + [_f32, C.c_int, _vp]),
     "dskd_clip_adamw_chunk": (C.c_int, []),
@@ -791,6 +792,79 @@ def conv1x1(x, w, bias=None, identity=None, relu=False, stride=1):
     if identity is not None and (identity.dtype != x.dtype or not identity.is_contiguous(memory_format=torch.channels_last)):
         identity = identity.to(x.dtype).contiguous(memory_format=torch.channels_last)
     return _Conv1x1Function.apply(x, w, bias, identity, bool(relu), int(stride))
+
+
+def conv3x3_ok(x: torch.Tensor, w: torch.Tensor, conv) -> bool:
+    """Can dskd_conv3x3 take this convolution: 3x3, padding 1, stride 1 or 2, no dilation / groups, channels_last bf16 CUDA
+    activation and channels_last weight, C in {64, 128, .. 1024}, Cout a multiple of 64?"""
+    Cin = x.shape[1] if x.dim() == 4 else 0
+    return (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+            and conv.kernel_size == (3, 3) and conv.stride in ((1, 1), (2, 2)) and conv.padding == (1, 1)
+            and conv.dilation == (1, 1) and conv.groups == 1 and Cin in (64, 128, 256, 512, 1024) and w.shape[0] % 64 == 0
+            and x.numel() > 0 and x.is_contiguous(memory_format=torch.channels_last) and x.data_ptr() % 16 == 0
+            and w.is_contiguous(memory_format=torch.channels_last) and w.data_ptr() % 16 == 0
+            and x.shape[2] * x.shape[3] * Cin * 2 < 2 ** 31 - 1)
+
+
+def conv3x3_raw(x, w, bias, res, relu, stride, out=None):
+    """Raw launch of dskd_conv3x3 (no autograd): x [B, C, H, W] channels_last, w [N, C, 3, 3] channels_last."""
+    B, Cin, H, W = x.shape
+    N = w.shape[0]
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    if out is None:
+        out = torch.empty((B, N, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    rc = load().dskd_conv3x3(x.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(),
+                             None if res is None else res.data_ptr(), out.data_ptr(), B, H, W, Cin, N, stride,
+                             1 if relu else 0, DTYPE_BF16, _stream(x))
+    _check(rc, "dskd_conv3x3")
+    global _ffn_flops
+    _ffn_flops += 2 * B * Ho * Wo * N * 9 * Cin
+    return out
+
+
+class _Conv3x3Function(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, identity, relu, stride):
+        y = conv3x3_raw(x, w, bias, identity, relu, stride)
+        ctx.relu, ctx.stride = relu, stride
+        ctx.save_for_backward(x, w, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, y = ctx.saved_tensors
+        if not g.is_contiguous(memory_format=torch.channels_last):
+            g = g.contiguous(memory_format=torch.channels_last)
+        if ctx.relu:
+            g = torch.ops.aten.threshold_backward(g, y, 0)
+        need = ctx.needs_input_grad
+        gx = gw = gb = None
+        N, Cin = w.shape[0], w.shape[1]
+        if need[0]:
+            if ctx.stride == 1 and N in (64, 128, 256, 512, 1024) and Cin % 64 == 0:
+                # dX = conv3x3(dY, W') with the taps flipped and the channel roles swapped: W'[c][ky][kx][n] = W[n][2-ky][2-kx][c]
+                wt = w.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
+                gx = conv3x3_raw(g, wt, None, None, False, 1)
+            else:
+                gx = torch.ops.aten.convolution_backward(g, x, w, None, [ctx.stride] * 2, [1, 1], [1, 1], False, [0, 0], 1,
+                                                         [True, False, False])[0]
+        if need[1]:
+            gw = torch.ops.aten.convolution_backward(g, x, w, None, [ctx.stride] * 2, [1, 1], [1, 1], False, [0, 0], 1,
+                                                     [False, True, False])[1]
+        if need[2]:
+            gb = g.sum((0, 2, 3))
+        return gx, gw, gb, (g if need[3] else None), None, None
+
+
+def conv3x3(x, w, bias=None, identity=None, relu=False, stride=1):
+    """``act(conv2d(x, w, stride, padding=1) + bias (+ identity))`` for a 3x3 convolution that :func:`conv3x3_ok` accepts:
+    one implicit-GEMM MFMA launch (csrc/gemm_nt.hip) with the epilogue fused; dX (stride 1) through the same kernel, dW
+    through the library.  Reference: conv2 -> bn2 -> relu of Bottleneck.forward, resnet.py:283-288."""
+    if bias is not None and (bias.dtype != torch.bfloat16 or not bias.is_contiguous()):
+        bias = bias.to(torch.bfloat16).contiguous()
+    if identity is not None and (identity.dtype != x.dtype or not identity.is_contiguous(memory_format=torch.channels_last)):
+        identity = identity.to(x.dtype).contiguous(memory_format=torch.channels_last)
+    return _Conv3x3Function.apply(x, w, bias, identity, bool(relu), int(stride))
 
 
 # --------------------------------------------------------------------------- Swin window attention (MFMA kernels)

@@ -378,6 +378,17 @@ int dskd_gemm_nt(const void* x, const void* w, const void* bias, const void* res
                  int relu, int stride, int Ho, int Wo, int Hi, int Wi, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * y = act(conv3x3(x, w, stride, padding 1) + bias (+ res)) on a channels_last bf16 activation x [B, Hi, Wi, C] with the
+ * channels_last weight w [N][3][3][C] -- conv2 of every Bottleneck (mmdet/models/backbones/resnet.py:283-288: conv2 ->
+ * bn2 -> relu, BN folded) as an implicit GEMM on the kernel of dskd_gemm_nt: K = 9 C, stage = 64 channels of one tap, the
+ * activation rows of a tap addressed in place (a page of zeros outside the image), same fused epilogue.  With the taps
+ * flipped and the weight transposed it is the stride-1 input-gradient convolution.  C = 64 * 2^k, N a multiple of 64.
+ *   y [B, Ho, Wo, N], Ho = (Hi - 1) / stride + 1 (same for Wo);  bias bf16 [N] or NULL;  res bf16 [B, Ho, Wo, N] or NULL
+ * ------------------------------------------------------------------------- */
+int dskd_conv3x3(const void* x, const void* w, const void* bias, const void* res, void* y, int B, int Hi, int Wi, int C, int N,
+                 int stride, int relu, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------
  * Window attention of the Swin backbone (BASELINE configs[3]): softmax(q k^T * scale + bias (+ shift mask)) v for
  * windows of 49 tokens and head dimension 32 -- WindowMSA.forward of the reference between its qkv Linear and its output
  * projection (mmdet/models/backbones/swin.py:81-126; the mask of ShiftWindowMSA :180-286) -- and its backward, one wave

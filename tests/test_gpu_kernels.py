@@ -1366,3 +1366,42 @@ def test_shift_window_msa_module_uses_the_mfma_kernel(shift):
     assert _close(yd, yc.detach(), 3e-2)
     for a, r in zip(gd, gc):
         assert _close(a, r, 5e-2), (tuple(r.shape), float((a.float().cpu() - r).abs().max()) / float(r.abs().max()))
+
+
+@pytest.mark.parametrize("B,C,N,H,W,stride,relu", [
+    (2, 64, 64, 23, 37, 1, True),           # layer1 conv2, odd sizes (borders on every side)
+    (1, 128, 128, 20, 33, 2, True),         # first block of a stage: stride 2, odd input width
+    (2, 256, 256, 9, 11, 1, True),
+    (1, 512, 512, 13, 21, 1, False),
+    (1, 128, 192, 5, 4, 1, False),          # N = 192: the 64-wide tile variant; tiny map
+    (3, 64, 128, 1, 1, 1, True),            # a 1 x 1 map: only the centre tap is inside the image
+])
+def test_conv3x3_mfma_vs_float_reference(B, C, N, H, W, stride, relu):
+    """dskd_conv3x3 behind native.conv3x3: ``act(conv2d(x, w, stride, padding=1) + bias)`` and its input gradient against
+    F.conv2d + autograd in fp32 on the CPU from the same bf16-rounded inputs (conv2 -> bn2 -> relu of the Bottleneck,
+    mmdet/models/backbones/resnet.py:283-288, BN folded); zero padding on every border, stride 2, ragged M."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(C + N + H)
+    x = torch.randn(B, C, H, W, generator=g).bfloat16()
+    w = (torch.randn(N, C, 3, 3, generator=g) / (9 * C) ** 0.5).bfloat16()
+    b = (torch.randn(N, generator=g) * 0.3).bfloat16()
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    up = torch.randn(B, N, Ho, Wo, generator=g).bfloat16()
+    xr, wr = x.float().requires_grad_(True), w.float().requires_grad_(True)
+    yr = F.conv2d(xr, wr, b.float(), stride=stride, padding=1)
+    if relu:
+        yr = torch.relu(yr)
+    gr = torch.autograd.grad(yr, [xr, wr], up.float())
+    conv = torch.nn.Conv2d(C, N, 3, stride=stride, padding=1, bias=False)
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wd = w.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    assert native.conv3x3_ok(xd, wd, conv)
+    guard = torch.full((4096,), 5.0, dtype=torch.bfloat16, device=DEV)
+    y = native.conv3x3(xd, wd, b.to(DEV), None, relu, stride)
+    assert y.shape == (B, N, Ho, Wo) and y.is_contiguous(memory_format=torch.channels_last)
+    assert _close(y, yr.detach(), 8e-3)
+    gd = torch.autograd.grad(y, [xd, wd], up.to(DEV).contiguous(memory_format=torch.channels_last))
+    for name, a, r in zip(("dx", "dw"), gd, gr):
+        assert _close(a, r, 1.2e-2), (name, float((a.float().cpu() - r).abs().max()), float(r.abs().max()))
+    torch.cuda.synchronize()
+    assert bool((guard == 5.0).all())
