@@ -302,6 +302,175 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
   return check_launch("dskd_gemm_nt");
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradients: C[N, K] += G[M, N]^T X[M, K]  (dW = dY^T X of a Linear layer / 1x1 convolution), bf16 in, f32 out.
+// The reduction runs over the ROWS (tokens) of both operands, so neither is K-contiguous for the matrix cores: the
+// [tokens][channels] tiles go global -> LDS as they lie (256-byte row pieces, LDS-DMA) and the fragments come out of them
+// with ds_read_b64_tr_b16 (4 tokens x 16 channels per 16-lane group, delivered token-contiguous: cdna_hip_programming.md
+// T10).  The output is tiny (64 .. 2048 squared) and M is 4 200 .. 267 200: the tokens are split over `splits`
+// workgroups per output tile, each adding its 128 x 128 f32 tile with global atomics into the zero-filled result (the
+// atomic volume is splits x N x K x 4 bytes: the host picks the split so that it stays ~16 MB).
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#ifndef DSKD_TN_TOK
+#define DSKD_TN_TOK 64
+#endif
+#ifndef DSKD_TN_NS
+#define DSKD_TN_NS 2
+#endif
+#ifndef DSKD_TN_ATOMIC_MB
+#define DSKD_TN_ATOMIC_MB 16.0
+#endif
+
+struct TnArgs {
+  const __bf16* g;       // [M, ldg]: columns [0, N) used
+  const __bf16* x;       // [M, ldx]: columns [0, K) used
+  float* c;              // [N, K] f32, += (zero-filled by the caller)
+  long long M;
+  int N, K, ldg, ldx;
+  int splits;            // workgroups along M per output tile
+  long long chunk;       // tokens per split (a multiple of 32)
+};
+
+__device__ __forceinline__ bf16x8 tr_pair(unsigned a0, unsigned a1) {      // tokens t .. t+3 (a0) and t+4 .. t+7 (a1) of one channel column
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(unsigned long)a0);
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(unsigned long)a1);
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+__global__ __launch_bounds__(256, 1) void gemm_tn_kernel(const TnArgs a) {
+  constexpr int ROWB = 256;                  // bytes of one token's 128 channels
+  constexpr int TOK = DSKD_TN_TOK;           // tokens per stage
+  constexpr int TILE = TOK * ROWB;           // one operand's tile of a stage
+  constexpr int STAGE = 2 * TILE;
+  constexpr int NS = DSKD_TN_NS;             // stages in LDS; the DMA runs NS - 1 stages ahead
+  constexpr int LD = TOK / 8;                // LDS-DMA instructions per wave and stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];      // NS stages
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wn = wave >> 1, wk = wave & 1;
+
+  const int tiles_k = a.K >> 7, tiles_n = a.N >> 7;
+  int vb = xcd_remap(blockIdx.x, gridDim.x);
+  const int sp = vb % a.splits; vb /= a.splits;
+  const int tk = vb % tiles_k, tn = vb / tiles_k;
+  (void)tiles_n;
+  const long long m_begin = (long long)sp * a.chunk;
+  const long long m_end = m_begin + a.chunk < a.M ? m_begin + a.chunk : a.M;
+  if (m_begin >= m_end) return;
+  const int nst = (int)((m_end - m_begin + TOK - 1) / TOK);
+
+  // LDS-DMA: one instruction = 4 token rows x 256 B; wave w fills rows (TOK / 4) w .. of both operands
+  // The 16-byte chunk ch of token row r sits at chunk position ch ^ (((r & 3) << 2) | ((r >> 2) & 3)) (guide T10, image (b):
+  // without it the four rows of a transposing read fall on the same banks) -- applied on the SOURCE address, the LDS
+  // image of one DMA instruction stays lane-linear.
+  const int lrow = lane >> 4;
+  const char* gp = reinterpret_cast<const char*>(a.g) + (long long)tn * 256;
+  const char* xp = reinterpret_cast<const char*>(a.x) + (long long)tk * 256;
+  const char* const zp = g_zero_page;
+  auto issue = [&](int st) {
+    char* sg = smem + (st % NS) * STAGE;
+    char* sx = sg + TILE;
+#pragma unroll
+    for (int j = 0; j < TOK / 16; ++j) {
+      const int row = wave * (TOK / 4) + j * 4 + lrow;
+      const long long m = m_begin + (long long)st * TOK + row;
+      const bool ok = m < m_end;                               // rows past this split's tokens contribute zeros
+      const int lcol = ((lane & 15) ^ ((lrow << 2) | ((wave * (TOK / 16) + j) & 3))) * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ok ? gp + m * a.ldg * 2 + lcol : zp),
+                                       (__attribute__((address_space(3))) void*)(sg + (wave * (TOK / 4) + j * 4) * ROWB), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ok ? xp + m * a.ldx * 2 + lcol : zp),
+                                       (__attribute__((address_space(3))) void*)(sx + (wave * (TOK / 4) + j * 4) * ROWB), 16, 0, 0);
+    }
+  };
+
+  // fragment addresses: 16-lane group g reads tokens 16 s + 8 h + q (+ 4) at the 16 channels 16 (g & 1) .. of its tile
+  const int q = (lane >> 2) & 3, p = lane & 3, h = lane >> 5, g1 = (lane >> 4) & 1;
+  const unsigned base = lds_offset(smem);
+  // rows 8 h + q (+ 4, + 16 s): row & 3 = q, (row >> 2) & 3 = 2 h (+ 1 for the second read of a pair; + 0 for the k-steps,
+  // which are 16 rows apart) -> the swizzle of the pair's second read differs in one bit: two addresses per fragment
+  unsigned ga[2][2], xa[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int row = 8 * h + q + 4 * e;
+      const int f = ((row & 3) << 2) | ((row >> 2) & 3);
+      const int cg = wn * 64 + t * 32 + 16 * g1 + 4 * p, cx = wk * 64 + t * 32 + 16 * g1 + 4 * p;
+      ga[t][e] = base + row * ROWB + ((((cg >> 3) ^ f)) << 4) + ((cg & 7) << 1);
+      xa[t][e] = base + TILE + row * ROWB + ((((cx >> 3) ^ f)) << 4) + ((cx & 7) << 1);
+    }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+#pragma unroll
+  for (int i = 0; i < NS - 1; ++i)
+    if (i < nst) issue(i);
+  for (int st = 0; st < nst; ++st) {
+    if (st + NS - 1 < nst) issue(st + NS - 1);
+    // stage st has landed (my part): all but the loads of the stages behind it are done
+    const int ahead = min(NS - 1, nst - 1 - st);
+    if (ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LD) : "memory");
+    else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LD) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const unsigned so = (st % NS) * STAGE;
+    // fragments of k-step s + 1 are requested before the MFMAs of k-step s (asm: hipcc would sink every read to its use,
+    // and with one wave per SIMD nothing else covers the LDS latency); LDS returns in order: counted waits
+    bf16x4 fr[2][8];                          // [buffer][g0.lo, g0.hi, g1.lo, g1.hi, x0.lo, x0.hi, x1.lo, x1.hi]
+    auto request = [&](int buf, int ks) {
+      const unsigned o = so + ks * 16 * ROWB;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fr[buf][2 * t + e]) : "v"(ga[t][e] + o));
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fr[buf][4 + 2 * t + e]) : "v"(xa[t][e] + o));
+        }
+    };
+    request(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < TOK / 16; ++ks) {
+      const int b = ks & 1;
+      if (ks + 1 < TOK / 16) {
+        request(b ^ 1, ks + 1);
+        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(fr[b][0]), "+v"(fr[b][1]), "+v"(fr[b][2]), "+v"(fr[b][3]), "+v"(fr[b][4]),
+                     "+v"(fr[b][5]), "+v"(fr[b][6]), "+v"(fr[b][7]));
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr[b][0]), "+v"(fr[b][1]), "+v"(fr[b][2]), "+v"(fr[b][3]), "+v"(fr[b][4]),
+                     "+v"(fr[b][5]), "+v"(fr[b][6]), "+v"(fr[b][7]));
+      }
+      bf16x8 gf[2], xf[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bf16x4 gl = fr[b][2 * t], gh = fr[b][2 * t + 1], xl = fr[b][4 + 2 * t], xh = fr[b][4 + 2 * t + 1];
+        gf[t] = bf16x8{gl[0], gl[1], gl[2], gl[3], gh[0], gh[1], gh[2], gh[3]};
+        xf[t] = bf16x8{xl[0], xl[1], xl[2], xl[3], xh[0], xh[1], xh[2], xh[3]};
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_barrier();
+  }
+  // acc[i][j]: rows = n (register index), column = k (lane): 32 consecutive k per half-wave -> 128-byte atomic rows
+  const int r = lane & 31;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float* cp = a.c + (long long)(tn * 128 + wn * 64 + i * 32 + 4 * h) * a.K + tk * 128 + wk * 64 + j * 32 + r;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) atomicAdd(cp + (long long)((e & 3) + 8 * (e >> 2)) * a.K, acc[i][j][e]);
+    }
+}
+
 }  // namespace
 }  // namespace dskd
 
@@ -355,4 +524,41 @@ extern "C" int dskd_conv3x3(const void* x, const void* w, const void* bias, cons
   hipStream_t st = (hipStream_t)stream;
   if (N % 128) return launch_gemm<64, 1, true>(a, st);
   return launch_gemm<128, 1, true>(a, st);
+}
+
+extern "C" int dskd_gemm_tn(const void* g, const void* x, float* c, int64_t M, int N, int K, int ldg, int ldx, int dtype,
+                            void* stream) {
+  if (dtype != DSKD_DTYPE_BF16) return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_tn: bf16 only");
+  if (!g || !x || !c || M < 0) return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_tn: null pointer or negative row count");
+  if (N <= 0 || K <= 0 || (N & 127) || (K & 127) || ldg < N || ldx < K || (ldg & 7) || (ldx & 7))
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_tn: N and K must be multiples of 128, row strides multiples of 8 (got N=%d K=%d "
+                "ldg=%d ldx=%d)", N, K, ldg, ldx);
+  if ((reinterpret_cast<uintptr_t>(g) & 15) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(c) & 15))
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_tn: pointers must be 16-byte aligned");
+  if (M == 0) return DSKD_OK;
+  TnArgs a;
+  a.g = (const __bf16*)g; a.x = (const __bf16*)x; a.c = c; a.M = M; a.N = N; a.K = K; a.ldg = ldg; a.ldx = ldx;
+  const long long tiles = (long long)(N >> 7) * (K >> 7);
+  // splits: one workgroup per CU (256 in all: each adds its 64 KB tile with atomics, 16 MB at ~1.3 TB/s), two per CU
+  // where that still leaves the atomic volume small and >= 1 024 tokens per workgroup; never fewer than 256 tokens each
+  long long sp = 256 / tiles;
+  if (sp < 1) sp = 1;
+  if (tiles * sp * 2 * 65536 <= (long long)(DSKD_TN_ATOMIC_MB * 1.0e6) && M / (2 * sp) >= 1024) sp *= 2;
+  const long long by_work = (M + 255) / 256;
+  if (sp > by_work) sp = by_work;
+  if (sp < 1) sp = 1;
+  a.chunk = (((M + sp - 1) / sp) + DSKD_TN_TOK - 1) / DSKD_TN_TOK * DSKD_TN_TOK;
+  sp = (M + a.chunk - 1) / a.chunk;
+  a.splits = (int)sp;
+  constexpr int lds = DSKD_TN_NS * 2 * DSKD_TN_TOK * 256;
+  static bool done[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!done[dev]) {
+    if (hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return fail(DSKD_ERR_LAUNCH, "dskd_gemm_tn: cannot reserve %d bytes of LDS", lds);
+    done[dev] = true;
+  }
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(tiles * sp)), dim3(256), lds, (hipStream_t)stream, a);
+  return check_launch("dskd_gemm_tn");
 }

@@ -52,6 +52,7 @@ _SIGNATURES = {
     "dskd_lin256_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_gemm_nt": (C.c_int, [_vp] * 5 + [_i64] + [C.c_int] * 9 + [_vp]),
     "dskd_conv3x3": (C.c_int, [_vp] * 5 + [C.c_int] * 8 + [_vp]),
+    "dskd_gemm_tn": (C.c_int, [_vp] * 3 + [_i64] + [C.c_int] * 5 + [_vp]),
     "dskd_winattn_fwd": (C.c_int, [_vp] * 4 + [C.c_int] * 5 + [_f32, C.c_int, _vp]),
     "dskd_winattn_bwd": (C.c_int, [_vp] * 6 + [C.c_int] * 5 + [_f32, C.c_int, _vp]),
     "dskd_clip_adamw_chunk": (C.c_int, []),
@@ -776,8 +777,16 @@ class _Conv1x1Function(torch.autograd.Function):
                 gx = torch.ops.aten.convolution_backward(g, x, w, None, [ctx.stride] * 2, [0, 0], [1, 1], False, [0, 0], 1,
                                                          [True, False, False])[0]
         if need[1]:
-            gw = torch.ops.aten.convolution_backward(g, x, w, None, [ctx.stride] * 2, [0, 0], [1, 1], False, [0, 0], 1,
-                                                     [False, True, False])[1]
+            g2, x2 = g.permute(0, 2, 3, 1).reshape(-1, N), x.permute(0, 2, 3, 1).reshape(-1, K)     # views: NHWC rows
+            if ctx.stride == 1 and gemm_tn_ok(g2, x2):
+                # dW = dY^T X over the B*H*W rows: the split-K MFMA kernel (the library's weight-gradient convolution comes
+                # with workspace zero-fill / cast helper launches around it)
+                gw = gemm_tn(g2, x2).to(w.dtype).view(N, K, 1, 1)
+                if w.stride() != gw.stride():
+                    gw = gw.as_strided(w.shape, w.stride())
+            else:
+                gw = torch.ops.aten.convolution_backward(g, x, w, None, [ctx.stride] * 2, [0, 0], [1, 1], False, [0, 0], 1,
+                                                         [False, True, False])[1]
         if need[2]:
             gb = g.sum((0, 2, 3))
         return gx, gw, gb, (g if need[3] else None), None, None
@@ -792,6 +801,29 @@ def conv1x1(x, w, bias=None, identity=None, relu=False, stride=1):
     if identity is not None and (identity.dtype != x.dtype or not identity.is_contiguous(memory_format=torch.channels_last)):
         identity = identity.to(x.dtype).contiguous(memory_format=torch.channels_last)
     return _Conv1x1Function.apply(x, w, bias, identity, bool(relu), int(stride))
+
+
+def gemm_tn_ok(g2: torch.Tensor, x2: torch.Tensor) -> bool:
+    """Can dskd_gemm_tn form ``g2^T @ x2`` ([M, N]^T [M, K], bf16 CUDA rows with unit column stride; N, K multiples of 128)?"""
+    return (g2.is_cuda and g2.dim() == 2 and x2.dim() == 2 and g2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16
+            and g2.shape[0] == x2.shape[0] and g2.shape[1] % 128 == 0 and x2.shape[1] % 128 == 0 and g2.stride(1) == 1
+            and x2.stride(1) == 1 and g2.stride(0) % 8 == 0 and x2.stride(0) % 8 == 0 and g2.shape[0] >= 1024
+            and g2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0)
+
+
+def gemm_tn(g2: torch.Tensor, x2: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``g2^T @ x2`` in f32 (the weight gradient of ``y = x W^T``: dW = dY^T X) as ONE split-K MFMA launch with transposing LDS
+    reads (csrc/gemm_nt.hip::gemm_tn_kernel).  ``out`` [N, K] f32: accumulated onto; default: a zero-filled buffer."""
+    M, N = g2.shape
+    K = x2.shape[1]
+    if out is None:
+        out = zeros((N, K), torch.float32, g2.device)
+    rc = load().dskd_gemm_tn(g2.data_ptr(), x2.data_ptr(), out.data_ptr(), M, N, K, g2.stride(0), x2.stride(0), DTYPE_BF16,
+                             _stream(g2))
+    _check(rc, "dskd_gemm_tn")
+    global _ffn_flops
+    _ffn_flops += 2 * M * N * K
+    return out
 
 
 def conv3x3_ok(x: torch.Tensor, w: torch.Tensor, conv) -> bool:

@@ -85,6 +85,19 @@ def _sum_partials(part, dtype):
     return part.sum(0, dtype=torch.float32).to(dtype)
 
 
+def _weight_grad(g2, x2, chunk, dtype):
+    """dW = g2^T x2 of a tall Linear ([tokens, N]^T [tokens, K]): the hand-written split-K MFMA kernel with transposing
+    LDS reads where it applies (native.gemm_tn: one launch, f32 result), else the library (token chunks as the batch of
+    one bmm + an f32 sum of the partial products, or one GEMM)."""
+    if native.gemm_tn_ok(g2, x2):
+        return native.gemm_tn(g2, x2).to(dtype)
+    if chunk is None:
+        return (g2.t() @ x2).to(dtype)
+    nb = x2.shape[0] // chunk
+    part = torch.bmm(g2.view(nb, chunk, -1).transpose(1, 2), x2.view(nb, chunk, -1))
+    return _sum_partials(part, dtype)
+
+
 class _TallLinearFn(torch.autograd.Function):
     """y = x W^T + b for a very tall x (tens of thousands of tokens, 256..1024 features).
     Forward and dX are ordinary GEMMs.  dW = dY^T X has a tiny output (<= 1024 x 256) and a
@@ -125,12 +138,7 @@ class _TallLinearFn(torch.autograd.Function):
             else:
                 gx = (g2 @ weight).view(x.shape)
         if ctx.needs_input_grad[1]:
-            if ctx.chunk is None:
-                gw = g2.t() @ x2
-            else:
-                nb = x2.shape[0] // ctx.chunk
-                part = torch.bmm(g2.view(nb, ctx.chunk, -1).transpose(1, 2), x2.view(nb, ctx.chunk, -1))
-                gw = _sum_partials(part, weight.dtype)
+            gw = _weight_grad(g2, x2, ctx.chunk, weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = bias_grad(g2)
         return gx, gw, gb, None, None
@@ -158,9 +166,7 @@ class _FFNInnerFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = g1 @ weight
         if ctx.needs_input_grad[1]:
-            nb = x.shape[0] // ctx.chunk
-            part = torch.bmm(g1.view(nb, ctx.chunk, -1).transpose(1, 2), x.view(nb, ctx.chunk, -1))
-            gw = _sum_partials(part, weight.dtype)
+            gw = _weight_grad(g1, x, ctx.chunk, weight.dtype)
         if colsum is not None:
             gb = colsum.to(g.dtype)
         return gx, gw, gb, None, None
@@ -189,16 +195,13 @@ class _FusedFFNFn(torch.autograd.Function):
         x, h, pb = ctx.saved_tensors
         gy = gy.contiguous()
         gh, gx, cs = native.ffn_bwd_raw(gy, h, pb, ctx.p, want_colsum=True, add_to_gx=add_to_gx)
-        nb = x.shape[0] // ctx.chunk
         gw1 = gb1 = gw2 = gb2 = None
         if ctx.needs_input_grad[1]:
-            part = torch.bmm(gh.view(nb, ctx.chunk, -1).transpose(1, 2), x.view(nb, ctx.chunk, -1))
-            gw1 = _sum_partials(part, ctx.dt)
+            gw1 = _weight_grad(gh, x, ctx.chunk, ctx.dt)
         if ctx.needs_input_grad[2]:
             gb1 = cs.to(ctx.dt)
         if ctx.needs_input_grad[3]:
-            part = torch.bmm(gy.view(nb, ctx.chunk, -1).transpose(1, 2), h.view(nb, ctx.chunk, -1))
-            gw2 = _sum_partials(part, ctx.dt)
+            gw2 = _weight_grad(gy, h, ctx.chunk, ctx.dt)
         if ctx.needs_input_grad[4]:
             gb2 = native.colsum(gy).to(ctx.dt)
         return (gx if ctx.needs_input_grad[0] else None), gw1, gb1, gw2, gb2, None, None

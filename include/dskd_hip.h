@@ -389,6 +389,15 @@ int dskd_conv3x3(const void* x, const void* w, const void* bias, const void* res
                  int stride, int relu, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * c[N, K] += g[M, N]^T x[M, K]  (bf16 in, f32 out; N, K multiples of 128): the weight gradient dW = dY^T X of an
+ * nn.Linear / 1x1 convolution over M tokens -- what autograd's mm / convolution_backward compute for the transformer's
+ * Linear layers (ext-mmcv FFN, MultiScaleDeformableAttention projections) and the Bottleneck's 1x1 convolutions
+ * (mmdet/models/backbones/resnet.py:271-303).  Split over the tokens; every workgroup adds its f32 tile with atomics:
+ * c must be zero-filled (or hold a value to accumulate onto).  ldg / ldx: row strides of g / x in elements.
+ * ------------------------------------------------------------------------- */
+int dskd_gemm_tn(const void* g, const void* x, float* c, int64_t M, int N, int K, int ldg, int ldx, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------
  * Window attention of the Swin backbone (BASELINE configs[3]): softmax(q k^T * scale + bias (+ shift mask)) v for
  * windows of 49 tokens and head dimension 32 -- WindowMSA.forward of the reference between its qkv Linear and its output
  * projection (mmdet/models/backbones/swin.py:81-126; the mask of ShiftWindowMSA :180-286) -- and its backward, one wave

@@ -1405,3 +1405,23 @@ def test_conv3x3_mfma_vs_float_reference(B, C, N, H, W, stride, relu):
         assert _close(a, r, 1.2e-2), (name, float((a.float().cpu() - r).abs().max()), float(r.abs().max()))
     torch.cuda.synchronize()
     assert bool((guard == 5.0).all())
+
+
+# --------------------------------------------------------------------------- weight-gradient GEMM (gemm_tn_kernel)
+@pytest.mark.parametrize("M,N,K", [(1024, 128, 128), (5000 + 37, 256, 384), (88892, 256, 256), (20011, 1024, 256),
+                                   (16800, 256, 1024), (4200, 512, 2048)])
+def test_gemm_tn_vs_float_reference(M, N, K):
+    """dskd_gemm_tn: ``g^T @ x`` (dW = dY^T X) in f32 against the f32 CPU product of the same bf16 inputs; token counts that
+    are no multiple of the 32-token stage or of the split, row strides larger than the used columns, accumulation onto
+    an existing buffer.  Tolerance 2e-3 of the largest magnitude (f32 accumulation in a different order; atomics)."""
+    g = torch.Generator().manual_seed(M % 97 + N + K)
+    gm = torch.randn(M, N + 64, generator=g).bfloat16()
+    xm = torch.randn(M, K, generator=g).bfloat16()
+    ref = gm[:, :N].float().t() @ xm.float()
+    gd, xd = gm.to(DEV)[:, :N], xm.to(DEV)
+    assert native.gemm_tn_ok(gd, xd)
+    out = native.gemm_tn(gd, xd)
+    assert out.dtype == torch.float32 and out.shape == (N, K)
+    assert _close(out, ref, 2e-3), float((out.cpu() - ref).abs().max()) / float(ref.abs().max())
+    out2 = native.gemm_tn(gd, xd, out=out.clone())                      # accumulates
+    assert _close(out2, 2 * ref, 2e-3)
