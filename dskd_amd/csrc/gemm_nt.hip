@@ -471,6 +471,17 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_kernel(const TnArgs a) {
     }
 }
 
+// dst (bf16) = src (f32), src = 0: hands a weight gradient over in the parameter's dtype and leaves the accumulator that
+// gemm_tn_kernel adds into zeroed for its next use -- one launch instead of a zero fill before and a cast after.
+__global__ __launch_bounds__(256) void cvt_clear_kernel(float* __restrict__ src, __bf16* __restrict__ dst, long long n4) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const f32x4 v = reinterpret_cast<f32x4*>(src)[i];
+    typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+    reinterpret_cast<bf16x4v*>(dst)[i] = bf16x4v{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    reinterpret_cast<f32x4*>(src)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
 }  // namespace
 }  // namespace dskd
 
@@ -561,4 +572,15 @@ extern "C" int dskd_gemm_tn(const void* g, const void* x, float* c, int64_t M, i
   }
   hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(tiles * sp)), dim3(256), lds, (hipStream_t)stream, a);
   return check_launch("dskd_gemm_tn");
+}
+
+extern "C" int dskd_cvt_clear(float* src, void* dst, int64_t n, int dtype, void* stream) {
+  if (dtype != DSKD_DTYPE_BF16) return fail(DSKD_ERR_INVALID_ARG, "dskd_cvt_clear: bf16 only");
+  if (!src || !dst || n < 0 || (n & 3) || (reinterpret_cast<uintptr_t>(src) & 15) || (reinterpret_cast<uintptr_t>(dst) & 7))
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_cvt_clear: null / misaligned pointer or a count that is no multiple of 4");
+  if (n == 0) return DSKD_OK;
+  const long long n4 = n / 4;
+  const unsigned blocks = (unsigned)((n4 + 255) / 256 < 1024 ? (n4 + 255) / 256 : 1024);
+  hipLaunchKernelGGL(cvt_clear_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst, n4);
+  return check_launch("dskd_cvt_clear");
 }

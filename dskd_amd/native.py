@@ -53,6 +53,7 @@ _SIGNATURES = {
     "dskd_gemm_nt": (C.c_int, [_vp] * 5 + [_i64] + [C.c_int] * 9 + [_vp]),
     "dskd_conv3x3": (C.c_int, [_vp] * 5 + [C.c_int] * 8 + [_vp]),
     "dskd_gemm_tn": (C.c_int, [_vp] * 3 + [_i64] + [C.c_int] * 5 + [_vp]),
+    "dskd_cvt_clear": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp]),
     "dskd_winattn_fwd": (C.c_int, [_vp] * 4 + [C.c_int] * 5 + [_f32, C.c_int, _vp]),
     "dskd_winattn_bwd": (C.c_int, [_vp] * 6 + [C.c_int] * 5 + [_f32, C.c_int, _vp]),
     "dskd_clip_adamw_chunk": (C.c_int, []),
@@ -290,7 +291,8 @@ def graph_pins(device):
     device = torch.device(device)
     if device.index is None and device.type == "cuda":
         device = torch.device("cuda", torch.cuda.current_device())
-    return [t for t in (_msda_ws_cache.get(device), _drop_epochs.get(device)) if t is not None]
+    return [t for t in (_msda_ws_cache.get(device), _drop_epochs.get(device)) if t is not None] + \
+        [t for k, t in _tn_acc.items() if k[2] == device]
 
 
 class _MSDAFunction(torch.autograd.Function):
@@ -781,7 +783,7 @@ class _Conv1x1Function(torch.autograd.Function):
             if ctx.stride == 1 and gemm_tn_ok(g2, x2):
                 # dW = dY^T X over the B*H*W rows: the split-K MFMA kernel (the library's weight-gradient convolution comes
                 # with workspace zero-fill / cast helper launches around it)
-                gw = gemm_tn(g2, x2).to(w.dtype).view(N, K, 1, 1)
+                gw = (gemm_tn_bf16(g2, x2) if w.dtype == torch.bfloat16 else gemm_tn(g2, x2).to(w.dtype)).view(N, K, 1, 1)
                 if w.stride() != gw.stride():
                     gw = gw.as_strided(w.shape, w.stride())
             else:
@@ -823,6 +825,27 @@ def gemm_tn(g2: torch.Tensor, x2: torch.Tensor, out: Optional[torch.Tensor] = No
     _check(rc, "dskd_gemm_tn")
     global _ffn_flops
     _ffn_flops += 2 * M * N * K
+    return out
+
+
+_tn_acc = {}
+
+
+def gemm_tn_bf16(g2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
+    """``(g2^T @ x2).to(bf16)`` -- a weight gradient in the low-precision parameter's dtype -- in two launches: the split-K
+    kernel adds into a PERSISTENT f32 accumulator of that shape (kept zeroed between uses), ``dskd_cvt_clear`` hands the
+    result over as bf16 and zeroes the accumulator again.  (A fresh accumulator per call costs a zero fill before and a
+    cast after: 2 x 109 small launches per step.)  Calls on one stream only: the accumulator is shared per shape."""
+    N, K = g2.shape[1], x2.shape[1]
+    key = (N, K, g2.device)
+    acc = _tn_acc.get(key)
+    if acc is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise NativeError("gemm_tn_bf16: the accumulator must exist before a hipGraph capture (run one eager step)")
+        acc = _tn_acc[key] = torch.zeros((N, K), dtype=torch.float32, device=g2.device)
+    gemm_tn(g2, x2, out=acc)
+    out = torch.empty((N, K), dtype=torch.bfloat16, device=g2.device)
+    _check(load().dskd_cvt_clear(acc.data_ptr(), out.data_ptr(), N * K, DTYPE_BF16, _stream(g2)), "dskd_cvt_clear")
     return out
 
 

@@ -90,7 +90,7 @@ def _weight_grad(g2, x2, chunk, dtype):
     LDS reads where it applies (native.gemm_tn: one launch, f32 result), else the library (token chunks as the batch of
     one bmm + an f32 sum of the partial products, or one GEMM)."""
     if native.gemm_tn_ok(g2, x2):
-        return native.gemm_tn(g2, x2).to(dtype)
+        return native.gemm_tn_bf16(g2, x2) if dtype == torch.bfloat16 else native.gemm_tn(g2, x2).to(dtype)
     if chunk is None:
         return (g2.t() @ x2).to(dtype)
     nb = x2.shape[0] // chunk

@@ -396,6 +396,9 @@ int dskd_conv3x3(const void* x, const void* w, const void* bias, const void* res
  * c must be zero-filled (or hold a value to accumulate onto).  ldg / ldx: row strides of g / x in elements.
  * ------------------------------------------------------------------------- */
 int dskd_gemm_tn(const void* g, const void* x, float* c, int64_t M, int N, int K, int ldg, int ldx, int dtype, void* stream);
+/* dst (bf16, n elements) = src (f32); src = 0 -- the accumulator of dskd_gemm_tn handed over in the parameter's dtype and
+ * left zeroed for its next use (n a multiple of 4). */
+int dskd_cvt_clear(float* src, void* dst, int64_t n, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Window attention of the Swin backbone (BASELINE configs[3]): softmax(q k^T * scale + bias (+ shift mask)) v for

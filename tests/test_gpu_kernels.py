@@ -1425,3 +1425,8 @@ def test_gemm_tn_vs_float_reference(M, N, K):
     assert _close(out, ref, 2e-3), float((out.cpu() - ref).abs().max()) / float(ref.abs().max())
     out2 = native.gemm_tn(gd, xd, out=out.clone())                      # accumulates
     assert _close(out2, 2 * ref, 2e-3)
+    # the bf16 hand-over through the persistent accumulator (dskd_cvt_clear): same values, and the accumulator is zero again
+    b1 = native.gemm_tn_bf16(gd, xd)
+    b2 = native.gemm_tn_bf16(gd, xd)
+    assert b1.dtype == torch.bfloat16 and _close(b1, ref, 6e-3) and _close(b2, ref, 6e-3)
+    assert float(native._tn_acc[(N, K, gd.device)].abs().max()) == 0.0
