@@ -25,54 +25,7 @@ class FrozenAffineBN(nn.BatchNorm2d):
         return x * scale.to(x.dtype).view(1, -1, 1, 1) + shift.to(x.dtype).view(1, -1, 1, 1)
 
 
-class _Conv1x1Fn(torch.autograd.Function):
-    """1x1 stride-1 convolution on a channels_last bf16 activation whose WEIGHT gradient is a split-K GEMM.
-    MIOpen's weight-gradient algorithms for these shapes accumulate in an f32 workspace: every call comes with a
-    workspace zero fill and a cast kernel (``SubTensorOpWithScalar1d`` / ``SubTensorOpWithCastTensor1d``: ~300 helper
-    launches and 3.9 ms per step at B=4).  With NHWC memory the activation IS the [N*H*W, Cin] matrix, so
-    dW = dY^T X is computed like the tall Linear layers' (transformer._TallLinearFn): token chunks as the batch of one
-    bmm, f32 sum of the partial products.  Forward and dX stay on the library's convolution kernels.
-    Measured in the B=4 step (r2, A/B twice): 38.3-38.7 ms with this path against 37.9-38.0 ms with MIOpen's -- the
-    helper launches go, but the bmm + f32 reduction cost more than they did -- so it is OFF unless DSKD_CONV_WGRAD_GEMM=1."""
-
-    @staticmethod
-    def forward(ctx, x, w, chunk):
-        ctx.chunk = chunk
-        ctx.save_for_backward(x, w)
-        return F.conv2d(x, w)
-
-    @staticmethod
-    def backward(ctx, g):
-        x, w = ctx.saved_tensors
-        gx = gw = None
-        if ctx.needs_input_grad[0]:
-            gx = torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
-                                                     [True, False, False])[0]
-        if ctx.needs_input_grad[1]:
-            g2 = g.permute(0, 2, 3, 1).reshape(-1, g.shape[1])          # views: channels_last memory is [N*H*W, C]
-            x2 = x.permute(0, 2, 3, 1).reshape(-1, x.shape[1])
-            nb = x2.shape[0] // ctx.chunk
-            part = torch.bmm(g2.view(nb, ctx.chunk, -1).transpose(1, 2), x2.view(nb, ctx.chunk, -1))
-            gw = part.sum(0, dtype=torch.float32).to(w.dtype).view(w.shape)
-            if w.stride() != gw.stride():
-                gw = gw.as_strided(w.shape, w.stride())
-        return gx, gw, None
-
-
-def _conv1x1_gemm_wgrad(conv, x, w):
-    """The chunk size for :class:`_Conv1x1Fn`, or None when the convolution does not qualify."""
-    if not (x.is_cuda and torch.is_grad_enabled() and w.requires_grad and w.dtype == torch.bfloat16 and x.dtype == w.dtype
-            and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
-            and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)):
-        return None
-    tokens = x.shape[0] * x.shape[2] * x.shape[3]
-    if tokens < 16384:
-        return None
-    from .transformer import _token_chunk
-    return _token_chunk(tokens, w.numel())
-
-
-_CONV1X1_MFMA = not os.environ.get("DSKD_CONV1X1_LIB")      # A/B switch: the library convolution + bias_act pass
+_CONV1X1_MFMA = not os.environ.get("DSKD_CONV_LIB")      # A/B switch: library convolutions + the bias_act pass
 
 
 def _conv_epilogue(conv, x, w, b, relu, identity):
@@ -87,11 +40,7 @@ def _conv_epilogue(conv, x, w, b, relu, identity):
             (identity is None or identity.is_cuda):
         # 3x3 convolution as an implicit GEMM on the same kernel, epilogue fused (dskd_conv3x3)
         return native.conv3x3(x, w, b, identity, relu, conv.stride[0])
-    chunk = _conv1x1_gemm_wgrad(conv, x, w) if os.environ.get("DSKD_CONV_WGRAD_GEMM") else None
-    if chunk is not None:
-        y = _Conv1x1Fn.apply(x, w, chunk)
-    else:
-        y = F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+    y = F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
     if b is None and identity is None:
         return F.relu(y, inplace=True) if relu else y
     if not y.is_cuda:                       # host tensors: the same arithmetic with PyTorch ops

@@ -1859,22 +1859,6 @@ inline int pick_qpb(int B, int Nq, int dtype) {
   return qpb < min_qpb ? min_qpb : qpb;
 }
 
-// Staging phases of the bf16 gather kernels (stage_points): two bf16 queries per wave make the
-// single-phase LDS slices the occupancy limit.  DSKD_MSDA_PHASES=1|2|4 overrides the default (A/B
-// tests; results are bit-identical for every value).  f32 keeps one phase (one query per wave).
-constexpr int kDefaultPhases = 1;
-inline int pick_phases(int LP, int dtype, int max_ph) {
-  if (dtype != DSKD_DTYPE_BF16) return 1;
-  int ph = kDefaultPhases;
-  if (const char* e = getenv("DSKD_MSDA_PHASES")) {
-    const int v = atoi(e);
-    if (v == 1 || v == 2 || v == 4) ph = v;
-  }
-  if (ph > max_ph) ph = max_ph;
-  while (ph > 1 && LP % ph != 0) ph >>= 1;
-  return ph;
-}
-
 }  // namespace
 }  // namespace dskd
 
@@ -1906,29 +1890,19 @@ extern "C" int dskd_msda_fwd(const void* value, const int64_t* spatial_shapes,
                      points, qpb, bpi)
     // Encoder shape (queries == pixels, 4 levels x 4 points): windowed forward in MIXED mode -- the coarse levels
     // 2+3 of one head in LDS, the fine levels on the buffer-load path, 8 waves per workgroup (two workgroups per
-    // CU): bit-identical to the plain kernel and 13-15 % faster.  DSKD_MSDA_FWD=plain forces the
-    // plain kernel; DSKD_MSDA_FWD_LV0 (first level held in LDS, 0..3) / DSKD_MSDA_FWD_NW (waves, 0 = automatic)
-    // are A/B knobs.
-    const char* fv = getenv("DSKD_MSDA_FWD");
-    if (!(fv && fv[0] == 'p') && Nq == Nv) {
-      const char* e_lv0 = getenv("DSKD_MSDA_FWD_LV0");
-      const char* e_nw = getenv("DSKD_MSDA_FWD_NW");
-      int lv0 = e_lv0 ? atoi(e_lv0) : 2;
-      if (lv0 < 0 || lv0 > 3) lv0 = 2;
+    // CU): bit-identical to the plain kernel and 13-15 % faster (other splits / wave counts measured
+    // slower in round 1-2 and removed).
+    if (Nq == Nv) {
       ValueGeom vg;
       FwdWinGeom fw;
       size_t lds = 0;
-      if (make_fwd_win_geom(g, levels, points, Nq, lv0, e_nw ? atoi(e_nw) : 8, &vg, &fw, &lds)) {
+      if (make_fwd_win_geom(g, levels, points, Nq, 2, 8, &vg, &fw, &lds)) {
         if (int rc = launch_fwd_win((const __bf16*)value, loc, attn, (__bf16*)out, vg, fw, lds, B, Nq, points, st))
           return rc;
         return check_launch("dskd_msda_fwd");
       }
     }
-    switch (pick_phases(levels * points, dtype, 4)) {
-      case 4: DSKD_FWD_BF16(4); break;
-      case 2: DSKD_FWD_BF16(2); break;
-      default: DSKD_FWD_BF16(1); break;
-    }
+    DSKD_FWD_BF16(1);
 #undef DSKD_FWD_BF16
   }
   return check_launch("dskd_msda_fwd");
@@ -1954,10 +1928,6 @@ extern "C" int dskd_msda_fwd_fused(const void* value, const int64_t* spatial_sha
     hipLaunchKernelGGL((msda_fwd_kernel<float, true, 1>), grid, block, 0, st, (const float*)value,
                        (const float*)nullptr, (const float*)nullptr, (const float*)both, ref, (float*)out, g, Nv,
                        Nq, 16, points, qpb, bpi);
-  else if (pick_phases(16, dtype, 2) == 2)
-    hipLaunchKernelGGL((msda_fwd_kernel<__bf16, true, 2>), grid, block, 0, st, (const __bf16*)value,
-                       (const float*)nullptr, (const float*)nullptr, (const __bf16*)both, ref, (__bf16*)out, g,
-                       Nv, Nq, 16, points, qpb, bpi);
   else
     hipLaunchKernelGGL((msda_fwd_kernel<__bf16, true, 1>), grid, block, 0, st, (const __bf16*)value,
                        (const float*)nullptr, (const float*)nullptr, (const __bf16*)both, ref, (__bf16*)out, g,
@@ -1990,10 +1960,7 @@ int msda_bwd_impl(const void* value, const int64_t* spatial_shapes, const int64_
   ValueGeom vg;
   VarGeom var[kNumVar];
   size_t lds[kNumVar];
-  const char* env = getenv("DSKD_MSDA_BWD");   // A/B runs: "v1" = plain global atomics, "r2" = round 2's four launches
-  const bool force_v1 = env && env[0] == 'v' && env[1] == '1';
-  const bool legacy = env && env[0] == 'r' && env[1] == '2';
-  bool windowed = !force_v1 && Nq == Nv && make_value_geom(g, levels, points, Nq, &vg, var, lds);
+  bool windowed = Nq == Nv && make_value_geom(g, levels, points, Nq, &vg, var, lds);
   int pull_mask = 0;
   MsdaLevels ml;
   // The bf16 workspace path: gather kernel on the fine levels only (+ the statistics behind the fixed-point scales),
@@ -2010,7 +1977,7 @@ int msda_bwd_impl(const void* value, const int64_t* spatial_shapes, const int64_
     if (pull_mask && !pull_supported(ml, levels, points, Nv, Nq, dtype, pull_mask)) pull_mask = 0;
   }
   if (windowed && dtype == DSKD_DTYPE_BF16) {
-    fuse23 = workspace && !legacy && (pull_mask >> 2) == 0;     // levels 2+3 on the windowed kernel (the default split)
+    fuse23 = workspace && (pull_mask >> 2) == 0;     // levels 2+3 on the windowed kernel (the default split)
     const int gnw = 8;      // waves per gather workgroup (4: 175 us, 8: 152-159 us, 12 / 16: 200-206 us)
     // fused path: the gather keeps levels 0+1 -- level 1's windows (23 KB) in LDS, level 0 on the buffer-load path
     // (measured: 152 us against 168 us with no window and 203 us with both levels' windows)

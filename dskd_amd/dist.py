@@ -40,7 +40,7 @@ def hipgraphs_allowed():
     RCCL.  ``DSKD_FORCE_GRAPHS=1`` / ``DSKD_NO_GRAPHS=1`` override."""
     if os.environ.get("DSKD_NO_GRAPHS"):
         return False
-    if os.environ.get("DSKD_FORCE_GRAPHS") or os.environ.get("DSKD_FORCE_GRAPHED_LOSSES"):
+    if os.environ.get("DSKD_FORCE_GRAPHS"):
         return True
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return True

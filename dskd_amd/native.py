@@ -236,7 +236,11 @@ def msda_forward_raw(value, shapes, loc, attn):
     return out
 
 
-def msda_backward_raw(value, shapes, loc, attn, grad_out):
+def msda_backward_raw(value, shapes, loc, attn, grad_out, use_workspace=True):
+    """(grad_value f32, grad_loc, grad_attn) of the sampling step.  The encoder shape (queries == pixels, 4 levels x 4
+    points) goes through ``dskd_msda_bwd_ws`` (tiled pull for level 0, fused levels-2+3 launch, statistics by-product;
+    grad_value written, not accumulated -> no zero fill); ``use_workspace=False`` (tests) and every other shape through the
+    plain entry point ``dskd_msda_bwd`` (windowed LDS accumulation for the encoder shape, global atomics otherwise)."""
     _need_gpu(value, loc, attn, grad_out)
     B, Nv, heads, ch = value.shape
     _, Nq, _, L, P, _ = loc.shape
@@ -246,9 +250,7 @@ def msda_backward_raw(value, shapes, loc, attn, grad_out):
     grad_out = grad_out.contiguous().to(value.dtype)
     gl = torch.empty_like(loc)
     ga = torch.empty_like(attn)
-    # Encoder shape: the workspace entry point (fine levels through the tiled pull kernel, grad_value written, not
-    # accumulated -> no zero fill).  DSKD_MSDA_BWD=v1|win keeps the older kernels for A/B runs.
-    if Nq == Nv and L == 4 and P == 4 and os.environ.get("DSKD_MSDA_BWD", "") == "":
+    if Nq == Nv and L == 4 and P == 4 and use_workspace:
         ws = _msda_bwd_workspace(value.device, B, Nv, Nq, heads, L, P)
         gv = torch.empty((B, Nv, heads, ch), dtype=torch.float32, device=value.device)
         with _timed("msda_bwd_enc"):
@@ -685,12 +687,15 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------- tall Linear with 256 inputs (MFMA kernel)
+LIN256_ENABLED = True      # tests set this to False to get the library GEMMs (the control of the kernel's parity tests)
+
+
 def lin256_ok(x: torch.Tensor, n_out: int, k_in: int) -> bool:
     """Can csrc/ffn_mfma.hip::lin256_kernel take ``x [tokens, 256] @ W^T`` (tall contiguous bf16 CUDA input, 256 inputs,
     32..512 outputs in steps of 32)?"""
     return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and k_in == 256 and x.shape[1] == 256
             and n_out % 32 == 0 and 32 <= n_out <= 512 and x.shape[0] >= 16384 and x.is_contiguous()
-            and x.data_ptr() % 16 == 0 and not os.environ.get("DSKD_LIN256_OFF"))
+            and x.data_ptr() % 16 == 0 and LIN256_ENABLED)
 
 
 def lin256_pack(w: torch.Tensor, transposed: bool = False) -> torch.Tensor:
@@ -1059,7 +1064,7 @@ def group_norm_cl_ok(x: torch.Tensor, gn: torch.nn.GroupNorm) -> bool:
     """Can csrc/gn.hip take this GroupNorm call (CUDA, channels_last rows, 256 channels in 32 groups, affine)?"""
     return (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16) and gn.affine
             and gn.num_channels == 256 and gn.num_groups == 32 and x.shape[1] == 256 and x.numel() > 0
-            and not os.environ.get("DSKD_GN_ATEN") and _cl_rows(x) == x.shape[1] * x.shape[2] * x.shape[3])
+            and _cl_rows(x) == x.shape[1] * x.shape[2] * x.shape[3])
 
 
 def group_norm_cl(x: torch.Tensor, gn: torch.nn.GroupNorm, relu: bool = False) -> torch.Tensor:

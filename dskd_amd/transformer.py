@@ -189,12 +189,10 @@ class _FusedFFNFn(torch.autograd.Function):
         return y
 
     @staticmethod
-    def backward(ctx, gy, add_to_gx=None):
-        """``add_to_gx``: another gradient of ``x`` (bf16, same shape) folded into the kernel's epilogue; only
-        :class:`_FFNBlockFn` passes it."""
+    def backward(ctx, gy):
         x, h, pb = ctx.saved_tensors
         gy = gy.contiguous()
-        gh, gx, cs = native.ffn_bwd_raw(gy, h, pb, ctx.p, want_colsum=True, add_to_gx=add_to_gx)
+        gh, gx, cs = native.ffn_bwd_raw(gy, h, pb, ctx.p, want_colsum=True)
         gw1 = gb1 = gw2 = gb2 = None
         if ctx.needs_input_grad[1]:
             gw1 = _weight_grad(gh, x, ctx.chunk, ctx.dt)
@@ -207,77 +205,6 @@ class _FusedFFNFn(torch.autograd.Function):
         return (gx if ctx.needs_input_grad[0] else None), gw1, gb1, gw2, gb2, None, None
 
 
-class _ShimCtx:
-    """Stand-in for an autograd context, so that one Function can drive another's static forward / backward."""
-
-    def __init__(self, needs_input_grad):
-        self.needs_input_grad = needs_input_grad
-        self.saved_tensors = ()
-
-    def save_for_backward(self, *tensors):
-        self.saved_tensors = tensors
-
-    def set_materialize_grads(self, flag):
-        pass
-
-
-class _FFNBlockFn(torch.autograd.Function):
-    """``LayerNorm(x + dropout(FFN(x)))`` (and ``q = y + pos`` for the next layer) -- the FFN sub-layer of a post-norm
-    encoder layer -- as ONE autograd node.  As two nodes (:class:`_FusedFFNFn`, native._AddLNFunction) ``x`` has two
-    consumers and autograd adds their gradients with a separate pass over [tokens, 256] (27 us per layer at B=4); here
-    the LayerNorm's residual gradient goes into the FFN backward kernel's epilogue (``dskd_ffn_bwd(grad_x_add=)``).
-    Measured in the step: no gain (36.2-36.4 ms against 36.0-36.2 ms for the two nodes: the epilogue's 32-byte reads cost
-    what the add pass did), so it is only taken with DSKD_FFN=block."""
-
-    @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, pos, p_ffn, p_tail, eps, chunk, want_q):
-        c1 = _ShimCtx((True,) * 5 + (False, False))
-        y = _FusedFFNFn.forward(c1, x, w1, b1, w2, b2, p_ffn, chunk)
-        c2 = _ShimCtx((True, True, True, True, pos is not None and pos.requires_grad, False, False, False))
-        out, q = native._AddLNFunction.forward(c2, y, x, gamma, beta, pos, eps, p_tail, want_q)
-        ctx.c1, ctx.c2 = c1, c2
-        if q is None:
-            q = out.new_empty(0)
-            ctx.mark_non_differentiable(q)
-        return out, q
-
-    @staticmethod
-    def backward(ctx, dout, dq):
-        c1, c2 = ctx.c1, ctx.c2
-        want_q = c2.meta[-1]
-        c1.needs_input_grad = tuple(ctx.needs_input_grad[:5]) + (False, False)
-        c2.needs_input_grad = (True, True, True, True, bool(ctx.needs_input_grad[7]), False, False, False)
-        dh, dres, dgamma, dbeta, dpos = native._AddLNFunction.backward(c2, dout, dq if want_q else None)[:5]
-        gx, gw1, gb1, gw2, gb2 = _FusedFFNFn.backward(c1, dh, add_to_gx=dres if ctx.needs_input_grad[0] else None)[:5]
-        ctx.c1 = ctx.c2 = None
-        return gx, gw1, gb1, gw2, gb2, dgamma, dbeta, dpos, None, None, None, None, None
-
-
-def ffn_block(x, ffn, norm, p_tail, pos=None, want_q=False):
-    """``y = norm(x + dropout_{p_tail}(ffn.core(x)))`` and, with ``want_q``, ``q = y + pos`` through
-    :class:`_FFNBlockFn` when the fused MFMA FFN applies and gradients are being recorded; None otherwise (the caller
-    composes the two ops itself).  Returns (y, q or None)."""
-    first = ffn.layers[0] if len(ffn.layers) else None
-    if not (torch.is_grad_enabled() and ffn.num_fcs == 2 and isinstance(first, nn.Sequential) and isinstance(first[1], nn.ReLU)
-            and isinstance(ffn.layers[1], nn.Linear) and first[0].weight.requires_grad and norm.elementwise_affine
-            and os.environ.get("DSKD_FFN") == "block"):
-        return None                                  # opt-in: measured 0-0.2 ms SLOWER per step than the two nodes (r2)
-    (w1, b1), (w2, b2) = first[0].lp(), ffn.layers[1].lp()
-    if not ffn_fused_ok(x, w1, w2, b1, b2):
-        return None
-    tokens = x.numel() // x.shape[-1]
-    chunk = _token_chunk(tokens, w1.numel())
-    if chunk is None:
-        return None
-    bf = torch.bfloat16
-    with torch.autocast(x.device.type, enabled=False):
-        out, q = _FFNBlockFn.apply(x.reshape(tokens, x.shape[-1]).to(bf), w1.to(bf).contiguous(), b1.to(bf),
-                                   w2.to(bf).contiguous(), b2.to(bf), norm.weight, norm.bias, pos if want_q else None,
-                                   float(first[2].p if first[2].training else 0.0), float(p_tail), float(norm.eps), chunk,
-                                   bool(want_q))
-    return out.view(x.shape), (q.view(x.shape) if want_q else None)
-
-
 def _frozen_packed(owner, w1, w2):
     """Fragment-order image of FROZEN bf16 FFN weights (the teacher's), packed once per weight version and kept ON the
     owning module (a global keyed by data_ptr could hand out another model's image when the allocator reuses an address)."""
@@ -288,10 +215,13 @@ def _frozen_packed(owner, w1, w2):
     return hit[1]
 
 
+FFN_FUSED = True      # tests set this to False to get the library GEMM chain (the control of the fused kernel's parity tests)
+
+
 def ffn_fused_ok(x, w1, w2, b1, b2):
     """Can csrc/ffn_mfma.hip take this FFN (tall bf16 CUDA tokens, d_model 256 / hidden 1024, both biases)?"""
     dev = x.device.type
-    if not x.is_cuda or os.environ.get("DSKD_FFN") == "chain" or b1 is None or b2 is None:
+    if not x.is_cuda or not FFN_FUSED or b1 is None or b2 is None:
         return False
     dtype = torch.get_autocast_dtype(dev) if torch.is_autocast_enabled(dev) else x.dtype
     tokens = x.numel() // max(x.shape[-1], 1)
@@ -925,10 +855,6 @@ class BaseTransformerLayer(nn.Module):
         for op, mod, norm in plan:
             p = mod.tail_dropout_p()
             if op == "ffn":
-                blk = ffn_block(x, mod, norm, p)
-                if blk is not None:
-                    x = blk[0]
-                    continue
                 h = mod.core(x, final_dropout=False)
             elif op == "self_attn":
                 h = mod(x, x, x, None, query_pos=query_pos, key_pos=query_pos, attn_mask=attn_masks[ai],
@@ -1075,10 +1001,6 @@ class DetrTransformerEncoder(TransformerLayerSequence):
             h = att.core(q, x, reference_points, spatial_shapes, query_key_padding_mask)
             x1, _ = native.add_layer_norm(h, x, layer.norms[0], p=att.dropout.p if att.training else 0.0)
             p_tail = ffn.layers[-1].p if ffn.training else 0.0
-            blk = ffn_block(x1, ffn, layer.norms[1], p_tail, pos=None if i == last else pos, want_q=i != last)
-            if blk is not None:                      # FFN + LayerNorm (+ next q) as one autograd node
-                x, q = blk
-                continue
             f = ffn.core(x1, final_dropout=False)
             x, q = native.add_layer_norm(f, x1, layer.norms[1], p=p_tail, pos=None if i == last else pos, want_q=i != last)
         return x

@@ -507,14 +507,75 @@ def test_teacher_ahead_is_invalidated_by_set_teacher():
     assert ahead2.pending is None
 
 
-def test_graphed_student_head_equals_eager():
-    """The student's transformer + branches replayed as hipGraphs (forward and backward, utils.GraphedFunction with the
-    parameters read from persistent low-precision buffers) against the eager launches of the same kernels, on the SAME
-    weights and a NEW image every step: same losses, same gradients (float atomics: to rounding).  (Training
-    trajectories are not compared: an untrained detector sits on assignment near-ties, so two runs that differ by
-    atomic-order rounding drift apart after a few updates.)  With dropout on, a replay draws new masks every step."""
+def _head_only_run(m, feats, data, ti, graphed):
+    """Student head (transformer + branches + loss) forward and backward on GIVEN neck features: log_vars, the gradient of
+    every head parameter and of the features."""
+    m.bbox_head.graph_head = graphed
+    for p in m.parameters():
+        p.grad = None
+    x = [f.detach().clone().requires_grad_(True) for f in feats]
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        losses = m.bbox_head.forward_train(x, data["img_metas"], data["gt_bboxes"], data["gt_labels"], None,
+                                           proposal_cfg=None, teacher_info=ti, task_labels=m.LableInPCNTask)
+        loss, log_vars = m._parse_losses(losses)
+    loss.backward()
+    grads = {n: p.grad.detach().float().clone() for n, p in m.bbox_head.named_parameters() if p.grad is not None}
+    grads.update({f"feat{i}": t.grad.detach().float().clone() for i, t in enumerate(x)})
+    return log_vars, grads
+
+
+def test_graphed_student_head_equals_eager_on_identical_features():
+    """The graphed region is the student HEAD (transformer + branches: two hipGraph replays, utils.GraphedFunction with the
+    parameters read from persistent low-precision buffers), so the comparison is made on the head alone: ``extract_feat`` and
+    the teacher run ONCE per step and the SAME neck features go to the graphed and to the eager head.  The head's forward
+    kernels are deterministic (no float atomics), so every loss term must agree to 1e-3 (bit-equal in practice); the backward
+    has float atomics (MSDA grad_value, bias-gradient column sums): every gradient's cosine >= 0.9999.  Two un-padded
+    shapes are captured and then ALTERNATED: a replay of the first signature must not read tensors a cache freed when
+    the second shape arrived (positional encodings, reference points, ones rows, the MSDA workspace)."""
     dev = torch.device("cuda:0")
     cfg, m = _build(seed=13)                  # 300 queries: _batch()'s injected keepid (305) addresses 2 x 300 rows
+    m.to(dev).train()
+    g = torch.Generator().manual_seed(31)
+    shapes = [(192, 256), (160, 224)]
+    batches = {hw: _batch(dev, H=hw[0], W=hw[1]) for hw in shapes}
+    order = [0, 0, 0, 0, 1, 1, 1, 1, 0, 1, 0, 1]        # per shape: two eager calls, capture, replay; then alternate
+    worst = 0.0
+    for step, si in enumerate(order):
+        hw = shapes[si]
+        data, inj = batches[hw]
+        img = torch.randn(2, 3, *hw, generator=g).to(dev)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            tfeats, touts, *_ = m.out_teacher(img, data["img_metas"])
+            ti = dict(neck_feats=tfeats, head_outs=touts, pred_keepid=inj["pred_keepid"], pred_logits=None,
+                      pred_scores=None, pred_labels=inj["pred_labels"], pred_bboxes=inj["pred_bboxes"])
+            feats = [f.detach() for f in m.extract_feat(img)]
+        lg, gg = _head_only_run(m, feats, data, ti, True)
+        le, ge = _head_only_run(m, feats, data, ti, False)
+        assert set(lg) == set(le) and set(gg) == set(ge)
+        for k in le:
+            assert lg[k] == pytest.approx(le[k], rel=1e-3, abs=1e-5), (step, hw, k, le[k], lg[k])
+            worst = max(worst, abs(lg[k] - le[k]) / max(abs(le[k]), 1e-5))
+        for n in ge:
+            if float(ge[n].norm()) > 1e-8 and ge[n].numel() >= 64:
+                c = float(torch.dot(ge[n].flatten(), gg[n].flatten()) / (ge[n].norm() * gg[n].norm() + 1e-30))
+                assert c >= 0.9999, (step, hw, n, c)
+    hg = m.bbox_head.__dict__.get("_head_graphs", {})
+    assert len(hg) == 2 and all(v not in (None, False) for v in hg.values()), hg
+    print("worst relative loss-term difference graphed vs eager:", worst)
+
+
+def test_graphed_student_head_equals_eager(monkeypatch):
+    """Whole-step companion of the head-only test above (backbone, neck and teacher run twice, once per path).  Two EAGER
+    whole steps on the same image are not bit-equal by default: at this small image MIOpen runs the trunk's convolutions on
+    its split-K ``igemm_fwd_gtcx35_nhwc_bf16`` kernels, which accumulate through float atomics in an f32 workspace
+    (profiles/r03_determinism_convs.log: 7 of 7 repeated calls differ), and an untrained detector sits on assignment
+    near-ties, so the rounding flips an assignment in one decoder layer now and then (the 2-5 % per-term spread seen in
+    round 2).  ``torch.backends.cudnn.deterministic`` pins the library to its deterministic solvers
+    (profiles/r03_determinism_flag.log: 0 of 213 module outputs differ), so the comparison is tight again: every loss term
+    to 2e-3, every gradient's cosine > 0.999.  With dropout on, a replay draws new masks every step."""
+    monkeypatch.setattr(torch.backends.cudnn, "deterministic", True)
+    dev = torch.device("cuda:0")
+    cfg, m = _build(seed=13)
     m.to(dev).train()
     g = torch.Generator().manual_seed(31)
     data, inj = _batch(dev)
@@ -531,30 +592,17 @@ def test_graphed_student_head_equals_eager():
         out["loss"].backward()
         return out["log_vars"], {n: p.grad.detach().float().clone() for n, p in m.named_parameters() if p.grad is not None}
 
-    # One untested call first: the libraries choose their convolution / GEMM algorithms on the first call of a shape,
-    # and that call's result can differ in the last bits from every later one -- enough to flip an assignment near-tie
-    # of this untrained detector (seen once, 2 % on one decoder layer's loss_cls, in a full-suite run).
-    run(torch.randn(2, 3, 192, 256, generator=g).to(dev), False)
+    run(torch.randn(2, 3, 192, 256, generator=g).to(dev), False)      # the libraries pick their algorithms on the first call
     for step in range(6):
         img = torch.randn(2, 3, 192, 256, generator=g).to(dev)
         lg, gg = run(img, True)               # eager for the first two calls, then captured and replayed
         le, ge = run(img, False)
         assert set(lg) == set(le) and set(gg) == set(ge)
-        # Tolerances: the libraries' convolution / GEMM choices are made per box, and on some boxes two EAGER forwards of
-        # the same input already differ by ~1e-3 relative in the per-layer losses (scratch/determinism_dbg.py), with an
-        # occasional assignment flip in one decoder layer (seen: 0.3 %, 2 %, 4.6 % on that layer's loss_cls; < 0.3 % of
-        # the total).  A graph that replays stale inputs or weights is off by O(1) in every term and in the gradient
-        # directions, so 10 % per term, 1 % on the total and the cosines below still separate the two.
         for k in le:
-            assert lg[k] == pytest.approx(le[k], rel=1e-1, abs=1e-4), (step, k, le[k], lg[k])
-        assert lg["loss"] == pytest.approx(le["loss"], rel=1e-2), (step, le["loss"], lg["loss"])
-        cos = []
-        for n in ge:
-            if float(ge[n].norm()) > 1e-8 and ge[n].numel() >= 64:
-                cos.append((float(torch.dot(ge[n].flatten(), gg[n].flatten()) / (ge[n].norm() * gg[n].norm() + 1e-30)), n))
-        cos.sort()
-        assert cos[0][0] > 0.99, (step, cos[:5])
-        assert cos[len(cos) // 2][0] > 0.999
+            assert lg[k] == pytest.approx(le[k], rel=2e-3, abs=1e-5), (step, k, le[k], lg[k])
+        cos = sorted(float(torch.dot(ge[n].flatten(), gg[n].flatten()) / (ge[n].norm() * gg[n].norm() + 1e-30))
+                     for n in ge if float(ge[n].norm()) > 1e-8 and ge[n].numel() >= 64)
+        assert cos[0] > 0.999, (step, cos[:5])
     hg = m.bbox_head.__dict__.get("_head_graphs", {})
     assert len(hg) == 1 and all(v not in (None, False) for v in hg.values()), hg
 
@@ -648,30 +696,3 @@ def test_gfl_distillation_step_on_gpu_vs_cpu_oracle(oracle_checker):
                                                   pred_labels=None)))
     out["loss"].backward()
     assert out["log_vars"]["loss_fg_feature"] > 0 and all(v == v for v in out["log_vars"].values())
-
-
-def test_conv1x1_gemm_weight_gradient_on_gpu(monkeypatch):
-    """Opt-in (DSKD_CONV_WGRAD_GEMM=1; measured slower in the step): ResNet 1x1 convolutions with the weight gradient from
-    a split-K GEMM (backbones._Conv1x1Fn) instead of MIOpen's workspace algorithms: same bf16 output, dX and dW (to bf16
-    accumulation-order noise) as the library path."""
-    import torch.nn as nn
-    from dskd_amd import backbones
-    torch.manual_seed(5)
-    conv = nn.Conv2d(256, 64, 1, bias=False).to("cuda", torch.bfloat16)
-    x = torch.randn(4, 256, 100, 168, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    up = torch.randn(4, 64, 100, 168, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    assert backbones._conv1x1_gemm_wgrad(conv, x, conv.weight) is not None
-    res = []
-    for force_lib in (False, True):
-        if force_lib:
-            monkeypatch.delenv("DSKD_CONV_WGRAD_GEMM")
-        else:
-            monkeypatch.setenv("DSKD_CONV_WGRAD_GEMM", "1")
-        xi = x.clone().requires_grad_(True)
-        y = backbones._conv_epilogue(conv, xi, conv.weight, None, False, None)
-        gx, gw = torch.autograd.grad(y, (xi, conv.weight), up)
-        res.append((y.float(), gx.float(), gw.float()))
-    (y0, gx0, gw0), (y1, gx1, gw1) = res
-    assert torch.equal(y0, y1)
-    assert torch.allclose(gx0, gx1, rtol=2e-2, atol=2e-2 * float(gx1.abs().max()))
-    assert float((gw0 - gw1).abs().max()) <= 2e-2 * float(gw1.abs().max())

@@ -423,21 +423,3 @@ def test_train_increment_command_line_is_the_reference_drivers(cpu_ops, tmp_path
     assert r3[0].epoch == 3 and r3[0].iter == 3 and [h["epoch"] for h in r3[0].history] == [3]
     with pytest.raises(FileNotFoundError):
         ti.main([f"--config={OWN_CFG}", f"--work-dir={tmp_path}", "--resume-from=/nonexistent.pth"] + small)
-
-
-def test_conv1x1_gemm_weight_gradient_equals_the_convolution_backward():
-    """backbones._Conv1x1Fn (1x1 convolution whose weight gradient is a split-K GEMM over the NHWC activation):
-    same output and gradients as F.conv2d's autograd, fp32 on the CPU."""
-    import torch.nn.functional as F
-    from dskd_amd.backbones import _Conv1x1Fn
-    g = torch.Generator().manual_seed(3)
-    x = torch.randn(2, 24, 16, 12, generator=g).contiguous(memory_format=torch.channels_last).requires_grad_(True)
-    w = torch.randn(40, 24, 1, 1, generator=g, requires_grad=True)
-    up = torch.randn(2, 40, 16, 12, generator=g).contiguous(memory_format=torch.channels_last)
-    y0 = F.conv2d(x, w)
-    gx0, gw0 = torch.autograd.grad(y0, (x, w), up)
-    y1 = _Conv1x1Fn.apply(x, w, 64)                       # 384 positions = 6 chunks of 64
-    gx1, gw1 = torch.autograd.grad(y1, (x, w), up)
-    assert torch.equal(y0, y1)
-    assert torch.allclose(gx0, gx1, rtol=1e-5, atol=1e-5) and gw1.shape == w.shape
-    assert torch.allclose(gw0, gw1, rtol=1e-4, atol=1e-4)
