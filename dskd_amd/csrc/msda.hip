@@ -29,23 +29,14 @@
 //    come from per-head dot products reduced with DPP inside 8- / 4-lane groups.
 #include "common.h"
 #include "msda_internal.h"
+#include "msda_geom.h"
 #include <stdlib.h>
 
 namespace dskd {
 namespace {
 
-constexpr int kHeads = 8;
-constexpr int kCh = 32;
 constexpr int kWaves = 4;       // waves per workgroup
-constexpr int kMaxLevels = 4;
 constexpr int kMaxLP = 16;      // levels * points
-constexpr int kOOB = 0x7F000000;  // byte offset beyond every descriptor range
-
-struct LevelGeom {
-  int H[kMaxLevels];
-  int W[kMaxLevels];
-  int start[kMaxLevels];
-};
 
 // Per-lane selection among four scalars.  Arrays inside kernel-argument structs must only be
 // indexed with compile-time constants (a runtime index sends the whole struct to scratch).
@@ -114,14 +105,6 @@ __device__ __forceinline__ void point_params(float lx_n, float ly_n, float a, in
     aux.y = ly;
   }
 }
-
-// NOTE: __builtin_bit_cast applied directly to a vector ELEMENT lvalue (v.y, v[1]) reads
-// element 0 with this compiler (hipcc 7.2); always go through a scalar by-value helper.
-__device__ __forceinline__ float as_f32(unsigned u) { return __builtin_bit_cast(float, u); }
-__device__ __forceinline__ int as_i32(float f) { return __builtin_bit_cast(int, f); }
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ bf16x2 as_bf16x2(unsigned u) { return __builtin_bit_cast(bf16x2, u); }
-using i32x2 = __attribute__((ext_vector_type(2))) int;
 
 __device__ __forceinline__ void unpack_bf16x8(const u32x4& v, float* f) {
   f[0] = as_f32(v.x << 16);
@@ -546,51 +529,6 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_kernel(
 //    the 32 lanes of a half-wave (4 corners x 8 channel lanes) hit 32 distinct banks.
 //  * the per-point arithmetic (floor, weights, window address) is done once per point by one
 //    lane and broadcast through the wave's LDS slice.
-constexpr int kRegion = 32;     // largest region edge, level-0 pixels (edges are balanced: ceil(S0 / ceil(S0/32)))
-constexpr int kMarginLo = 5;    // window margin below / above the region footprint
-constexpr int kMarginHi = 6;
-constexpr int kMaxReg = 16;     // regions per axis
-constexpr int kSkip = 0x7FFFFFF0;
-
-struct ValueGeom {
-  int H[kMaxLevels], W[kMaxLevels], start[kMaxLevels];
-  int ww[kMaxLevels], wh[kMaxLevels];
-  int RX, RY, EX, EY, levels;
-};
-
-// floor(x + 0.5) in ONE VALU instruction (v_cvt_rpi_i32_f32; checked on gfx950).  Plain
-// truncation would bias every contribution towards zero, which shows on the coarse levels
-// where a cell sums hundreds of them.
-__device__ __forceinline__ int cvt_round(float x) {
-  int r;
-  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
-  return r;
-}
-
-__host__ __device__ inline int floor_div(int a, int b) {  // b > 0
-  const int q = a / b;
-  return (a % b != 0 && a < 0) ? q - 1 : q;
-}
-
-// Region r of an axis (edge E level-0 pixels, finest extent S0) on a level of extent Sl:
-//  * the query x belongs to region floor(((2x+1) * S0) / (2 * Sl)) / E, so its query range starts
-//    at ceil((2 * E * r * Sl - S0) / (2 * S0)), clamped to [0, Sl];
-//  * its window starts at floor(r * E * Sl / S0 - 0.5) - kMarginLo.
-// Both are evaluated in exact integer arithmetic in the kernel prologue.
-
-// Global query index of the qi-th query of a region (queries ordered level by level, row by row
-// inside the region's footprint on that level); rows of the lookup table as filled below.
-__device__ __forceinline__ int region_query(const i32x4* s_tab, const int* cum, int qi) {
-  int lq = 0;
-#pragma unroll
-  for (int l = 1; l < kMaxLevels; ++l) lq += qi >= cum[l];
-  const i32x4 qa = s_tab[4 * lq], qb = s_tab[4 * lq + 1];
-  const int rem = qi - qa.x;
-  // exact: the fractional part of (rem + 0.5) / dx is at least 0.5/dx away from an integer
-  const int yy = (int)(((float)rem + 0.5f) * as_f32((unsigned)qb.x));
-  return qb.y + (qa.z + yy) * qb.z + qa.y + (rem - yy * qa.w);
-}
-
 // One launch per LEVEL GROUP (variant).  A workgroup owns (image, region, head, channel group)
 // and only the sampling points of its levels, so the per-point arithmetic (floor, bilinear
 // weights, window address) is done 20 times per (query, head) over the three launches instead
@@ -1160,6 +1098,19 @@ __global__ void zero_rows_kernel(float* __restrict__ gv, int Nv, int row0, int n
 // against 197 us at B=4); from level 1 on a cell sums 85 / 340 / 1 300 contributions and accumulating in LDS windows
 // (scatter form) is faster (level 1: 175 us windowed, 209 us pulled -- profiles/r02_msda_bwd_pull_ab.txt).
 // DSKD_MSDA_PULL_LEVELS=<digits> overrides ("" or "none": no pull; levels 2 and 3 only together).
+// Levels on the matrix-core kernel (msda_mm.hip).  DSKD_MSDA_MM=<digits> overrides for A/B runs ("0": none).
+inline int mm_level_mask() {
+  int mask = 2 | 4;
+  if (const char* e = getenv("DSKD_MSDA_MM")) {
+    mask = 0;
+    for (const char* c = e; *c; ++c) {
+      if (*c == '1') mask |= 2;
+      if (*c == '2' || *c == '3') mask |= 4;
+    }
+  }
+  return mask;
+}
+
 inline int pull_level_mask() {
   int mask = 1;
   if (const char* e = getenv("DSKD_MSDA_PULL_LEVELS")) {
@@ -1962,9 +1913,11 @@ int msda_bwd_impl(const void* value, const int64_t* spatial_shapes, const int64_
   size_t lds[kNumVar];
   bool windowed = Nq == Nv && make_value_geom(g, levels, points, Nq, &vg, var, lds);
   int pull_mask = 0;
+  int mm = 0;               // bit 1: level 1, bit 2: levels 2+3: grad_value on the matrix-core kernel (msda_mm.hip)
   MsdaLevels ml;
-  // The bf16 workspace path: gather kernel on the fine levels only (+ the statistics behind the fixed-point scales),
-  // the levels-2+3 launch forms its own samples' grad_loc / grad_attn.
+  // The bf16 workspace path: grad_value of the coarse levels on the matrix-core kernel, every level's grad_loc / grad_attn
+  // in the gather kernel.  Where the matrix-core kernel does not take levels 2+3, the windowed levels-2+3 launch forms
+  // its own samples' gradients (bound from the gather kernel's statistics) and the gather keeps levels 0+1.
   ValueGeom wg;
   FwdWinGeom fw;
   size_t wl = 0;
@@ -1975,10 +1928,31 @@ int msda_bwd_impl(const void* value, const int64_t* spatial_shapes, const int64_
     pull_mask = pull_level_mask();
     // every level's tile geometry is validated here, before the first launch of this call
     if (pull_mask && !pull_supported(ml, levels, points, Nv, Nq, dtype, pull_mask)) pull_mask = 0;
+    if (dtype == DSKD_DTYPE_BF16) {
+      mm = mm_level_mask();
+      if (pull_mask & 2) mm &= ~2;
+      if (pull_mask >> 2) mm &= ~4;
+      if ((mm & 2) && !mm_supported(ml, levels, points, Nv, Nq, dtype, 1, 1)) mm &= ~2;
+      if ((mm & 4) && !mm_supported(ml, levels, points, Nv, Nq, dtype, 2, 2)) mm &= ~4;
+    }
   }
   if (windowed && dtype == DSKD_DTYPE_BF16) {
-    fuse23 = workspace && (pull_mask >> 2) == 0;     // levels 2+3 on the windowed kernel (the default split)
     const int gnw = 8;      // waves per gather workgroup (4: 175 us, 8: 152-159 us, 12 / 16: 200-206 us)
+    if (mm) {
+      // the gather forms every level's grad_loc / grad_attn (levels 2+3 of one head in LDS, the fine levels on the
+      // buffer-load path) and the statistics
+      gather_win = make_fwd_win_geom(g, levels, points, Nq, 2, gnw, &wg, &fw, &wl);
+      if (gather_win) {
+        wl += (size_t)fw.waves * 16 * 16 * 12 + (size_t)fw.waves * 16;
+        gather_win = wl <= kMaxLds;
+      }
+      stats_bytes = (size_t)B * wg.RY * wg.RX * kHeads * 16;      // the f16 scale of the matrix-core kernel comes from them
+      if (!gather_win || workspace_bytes < kPullWsHeader + stats_bytes + kPullWsEntry) { mm = 0; stats_bytes = 0; }
+    }
+  }
+  if (windowed && dtype == DSKD_DTYPE_BF16 && !mm) {
+    fuse23 = workspace && (pull_mask >> 2) == 0;     // levels 2+3 on the windowed kernel (the default split)
+    const int gnw = 8;
     // fused path: the gather keeps levels 0+1 -- level 1's windows (23 KB) in LDS, level 0 on the buffer-load path
     // (measured: 152 us against 168 us with no window and 203 us with both levels' windows)
     gather_win = make_fwd_win_geom(g, levels, points, Nq, fuse23 ? 1 : 2, gnw, &wg, &fw, &wl, fuse23 ? 2 : kMaxLevels);
@@ -2006,9 +1980,9 @@ int msda_bwd_impl(const void* value, const int64_t* spatial_shapes, const int64_
     }
   }
   // statistics at the END of the workspace; the stray list of the pull kernel keeps the front
-  float* stats = fuse23 ? reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ((workspace_bytes - stats_bytes) & ~(size_t)15))
+  float* stats = (fuse23 || mm) ? reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ((workspace_bytes - stats_bytes) & ~(size_t)15))
                         : nullptr;
-  if (fuse23) stats_bytes = workspace_bytes - (size_t)(reinterpret_cast<char*>(stats) - reinterpret_cast<char*>(workspace));
+  if (fuse23 || mm) stats_bytes = workspace_bytes - (size_t)(reinterpret_cast<char*>(stats) - reinterpret_cast<char*>(workspace));
   if (workspace) {
     // zero what the atomics of the remaining kernels add into, and the stray-list header
     unsigned* hdr = reinterpret_cast<unsigned*>(workspace);
@@ -2027,7 +2001,7 @@ int msda_bwd_impl(const void* value, const int64_t* spatial_shapes, const int64_
       if (hdr) zero_fill(workspace, kPullWsHeader, st);       // every level pulled: nothing else zeroes it
     }
   }
-  const int variants = (pull_mask & 1 ? 0 : 1) | (pull_mask & 2 ? 0 : 2) | ((pull_mask >> 2) == 3 ? 0 : 4);
+  const int variants = (pull_mask & 1 ? 0 : 1) | ((pull_mask & 2) || (mm & 2) ? 0 : 2) | ((pull_mask >> 2) == 3 || (mm & 4) ? 0 : 4);
   if (windowed) {
     ValueExtra ex;
     ex.value = value; ex.grad_loc = grad_loc; ex.grad_attn = grad_attn; ex.stats = stats;
@@ -2052,6 +2026,13 @@ int msda_bwd_impl(const void* value, const int64_t* spatial_shapes, const int64_
       if (int rc = launch_value<__bf16>(loc, attn, (const __bf16*)grad_out, grad_value, vg, var, lds, B, Nq, LP,
                                         points, ex, st, variants)) return rc;
     }
+    const int sgrid[4] = {wg.RX, wg.RY, wg.EX, wg.EY};
+    if (mm & 4)
+      if (int rc = launch_bwd_mm(loc, attn, grad_out, grad_value, stats, sgrid, ml, 2, 2, B, Nq, points, st))
+        return rc;
+    if (mm & 2)
+      if (int rc = launch_bwd_mm(loc, attn, grad_out, grad_value, stats, sgrid, ml, 1, 1, B, Nq, points, st))
+        return rc;
     if (pull_mask)
       if (int rc = launch_pull(loc, attn, grad_out, grad_value, ml, pull_mask, B, Nq, dtype, workspace,
                                workspace_bytes - stats_bytes, st)) return rc;

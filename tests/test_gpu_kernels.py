@@ -155,6 +155,29 @@ def test_msda_bwd_windowed_encoder_shape(shapes, sigma, dtype):
     torch.testing.assert_close(ga.cpu(), a.grad, **tol)
 
 
+def test_msda_bwd_matrix_core_unusual_attention_weights():
+    """csrc/msda_mm.hip accumulates the S image in 16-bit fixed point, which assumes the four attention weights of a
+    (query, head, level) are >= 0 and sum to <= 1.5 (softmax outputs are); every other quad of samples must take the
+    per-lane path: weights that are negative, large, NaN-free but unnormalised -- against the oracle on the rounded
+    inputs, bf16 tolerances."""
+    shapes = [(25, 42), (13, 21), (7, 11), (4, 6)]
+    value, loc, attn, go = _encoder_like_inputs(shapes, 2, 91, 2.0, torch.bfloat16)
+    g = torch.Generator().manual_seed(92)
+    attn = attn.clone()
+    Nq = attn.shape[1]
+    attn[:, : Nq // 3] = torch.randn(attn[:, : Nq // 3].shape, generator=g)                 # signed
+    attn[:, Nq // 3: 2 * Nq // 3] = torch.rand(attn[:, Nq // 3: 2 * Nq // 3].shape, generator=g) * 3.0   # sums far above 1.5
+    v = value.float().requires_grad_(True)
+    l = loc.clone().requires_grad_(True)
+    a = attn.clone().requires_grad_(True)
+    msda_ref.msda_grid_sample(v, shapes, l, a).backward(go.float())
+    gv, gl, ga = native.msda_backward_raw(value.to(DEV), shapes, loc.to(DEV), attn.to(DEV), go.to(DEV))
+    scale = float(v.grad.abs().max())
+    torch.testing.assert_close(gv.cpu(), v.grad, atol=4e-3 * max(scale, 1.0), rtol=4e-3)
+    torch.testing.assert_close(ga.cpu(), a.grad, atol=4e-3, rtol=4e-3)
+    torch.testing.assert_close(gl.cpu(), l.grad, atol=4e-3 * 20 * max(float(l.grad.abs().max()) / 50.0, 1.0), rtol=4e-3)
+
+
 def test_msda_bwd_workspace_entry_matches_plain_entry_full_size():
     """BASELINE size, f32: the workspace entry point (dskd_msda_bwd_ws: pull on level 0) against the plain one
     (dskd_msda_bwd: windowed LDS accumulation on every level); grad_loc / grad_attn come from the same gather kernel."""
@@ -264,10 +287,10 @@ def test_msda_bwd_heavy_tailed_gradient():
 
 
 def test_msda_bwd_pull_matches_windowed_full_size():
-    """BASELINE size, B=2, bf16 (the benchmark's mode): the workspace entry point (pull on level 0; levels 2+3 with their
-    grad_loc / grad_attn dot products inside the windowed kernel, bound from the gather kernel's statistics) against the
-    plain entry point (dskd_msda_bwd: all-windowed grad_value, every level's dot products in the gather kernel); the
-    dot products sum the same 32 products in a different order: equal to f32 rounding, and bit-identical run to run."""
+    """BASELINE size, B=2, bf16 (the benchmark's mode): the workspace entry point (pull on level 0; levels 1-3 -- grad_value
+    and their samples' grad_loc / grad_attn -- on the matrix-core kernel csrc/msda_mm.hip) against the plain entry point
+    (dskd_msda_bwd: all-windowed fixed-point grad_value, every level's dot products in the gather kernel); the dot
+    products sum the same 32 products in a different order: equal to f32 rounding, and bit-identical run to run."""
     value, loc, attn, go = _encoder_like_inputs(SHAPES_FULL, 2, 49, 2.5, torch.bfloat16)
     args = (value.to(DEV), SHAPES_FULL, loc.to(DEV), attn.to(DEV), go.to(DEV))
     gv2, gl2, ga2 = native.msda_backward_raw(*args)
@@ -277,8 +300,9 @@ def test_msda_bwd_pull_matches_windowed_full_size():
     torch.testing.assert_close(gv2, gv1, atol=4e-3, rtol=4e-3)
     for a, r in ((gl2, gl1), (ga2, ga1)):
         assert float((a - r).abs().max()) <= 2e-6 * float(r.abs().max()), (float((a - r).abs().max()), float(r.abs().max()))
-    # levels 0+1 come from the same gather kernel with the same arithmetic in both
-    assert torch.equal(gl2[..., :2, :, :], gl1[..., :2, :, :]) and torch.equal(ga2[..., :2, :], ga1[..., :2, :])
+    # level 0 comes from the same gather kernel with the same arithmetic in both (levels 1-3: matrix-core kernel, f32
+    # accumulation of the same exact products in another order)
+    assert torch.equal(gl2[..., :1, :, :], gl1[..., :1, :, :]) and torch.equal(ga2[..., :1, :], ga1[..., :1, :])
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -378,9 +402,10 @@ def test_msda_windowed_forward_is_bit_identical(shapes, B, sigma):
 @pytest.mark.parametrize("shapes,B,sigma", _WIN_CASES)
 def test_msda_windowed_gather_matches_plain_kernel(shapes, B, sigma):
     """grad_loc / grad_attn of the encoder shape (bf16) against the plain gather kernel (reached with the last query
-    dropped): levels 0+1 come from msda_bwd_win_kernel -- same channels per lane, same DPP reduction, same final
-    arithmetic: identical bits, borders / rejected / NaN / far samples included; levels 2+3 are formed inside the windowed
-    grad_value kernel (8-channel v_dot2c partial sums instead of FMA chains): equal to f32 rounding."""
+    dropped): level 0 comes from msda_bwd_win_kernel -- same channels per lane, same DPP reduction, same final
+    arithmetic: identical bits, borders / rejected / NaN / far samples included; levels 1-3 come from the matrix-core
+    kernel (csrc/msda_mm.hip: the same exact bf16 products summed in f32 by the MFMA instead of FMA chains): equal to
+    f32 rounding."""
     value, loc, attn, go = _encoder_like_inputs(shapes, B, 83, sigma, torch.bfloat16)
     loc[0, :7] = torch.tensor([-0.2, 0.0, 0.5, 1.0, 1.3, float("nan"), 0.999]).view(7, 1, 1, 1, 1)
     vd, ld, ad, gd = value.to(DEV), loc.to(DEV), attn.to(DEV), go.to(DEV)
@@ -389,7 +414,7 @@ def test_msda_windowed_gather_matches_plain_kernel(shapes, B, sigma):
     torch.cuda.synchronize()
     gl1, ga1 = gl1[:, :-1], ga1[:, :-1]
     same = lambda a, b: torch.equal(a.nan_to_num(nan=12345.0), b.nan_to_num(nan=12345.0))      # noqa: E731
-    assert same(ga1[..., :2, :], ga0[..., :2, :]) and same(gl1[..., :2, :, :], gl0[..., :2, :, :])
+    assert same(ga1[..., :1, :], ga0[..., :1, :]) and same(gl1[..., :1, :, :], gl0[..., :1, :, :])
     for a, r in ((gl1, gl0), (ga1, ga0)):
         a, r = a.nan_to_num(nan=0.0), r.nan_to_num(nan=0.0)
         assert float((a - r).abs().max()) <= 4e-6 * float(r.abs().max()) + 1e-7
