@@ -421,6 +421,7 @@ class GFLDeformableDETRHead_il(nn.Module):
 
     # replay the dense detection losses as hipGraphs on the GPU (utils.GraphedFunction); DSKD_EAGER_LOSSES=1 disables
     graph_dense_losses = not os.environ.get("DSKD_EAGER_LOSSES")
+    fused_dense_losses = True      # tests set this to False: the PyTorch formulation (graphed or eager) as the control
 
     def _masked_memory_kl(self, info_all, student_feat, teacher_info, img_metas, gt_bboxes_original, sg_out):
         """``sg_out`` (:860-925) and ``fg_only`` (:1082-1129): the encoder memories, cut back into
@@ -496,6 +497,18 @@ class GFLDeformableDETRHead_il(nn.Module):
         repeated: 378 tiny launches become ~6.  Eager when gradients are off, on the CPU, inside
         another capture, or if capture fails."""
         # Not when several ranks share one GPU (the one-GPU rehearsal of the multi-process path): dist.ranks_share_a_device
+        if self.fused_dense_losses and cls_scores.is_cuda and native.dense_losses_ok(
+                cls_scores, bbox_cxcywh, bbox_lrtb, getattr(self.loss_cls, "beta", None) or 0.0,
+                getattr(self.loss_iou, "eps", None) or 0.0, self.reg_max + 1) and \
+                type(self.loss_cls).__name__ == "QualityFocalLoss" and type(self.loss_bbox).__name__ == "L1Loss" and \
+                type(self.loss_iou).__name__ == "GIoULoss" and type(self.loss_dfl).__name__ == "DistributionFocalLoss":
+            # the four terms of every layer in two launches (csrc/denseloss.hip) instead of 368 (147 forward, 221 backward)
+            if not torch.is_tensor(avg_pos):
+                avg_pos = device_const(float(avg_pos), torch.float32, cls_scores.device)
+            with torch.autocast(cls_scores.device.type, enabled=False):
+                return native.dense_losses(cls_scores, bbox_cxcywh, bbox_lrtb, labels, bbox_targets, pos, factors, avg_pos,
+                                           (self.loss_cls.loss_weight, self.loss_bbox.loss_weight, self.loss_iou.loss_weight,
+                                            self.loss_dfl.loss_weight))
         if not (self.graph_dense_losses and cls_scores.is_cuda and torch.is_grad_enabled() and cls_scores.requires_grad
                 and _graphs_allowed() and not torch.cuda.is_current_stream_capturing()):
             return self.loss_layers_dense(cls_scores, bbox_cxcywh, bbox_lrtb, labels, bbox_targets, pos, factors, avg_pos)

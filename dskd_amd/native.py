@@ -65,6 +65,8 @@ _SIGNATURES = {
     "dskd_lsap_host": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "dskd_lsap_batched": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "dskd_match_cost": (C.c_int, [_vp] * 7 + [C.c_int] * 3 + [_f32] * 3 + [_vp]),
+    "dskd_dense_loss_fwd": (C.c_int, [_vp] * 13 + [C.c_int] * 4 + [_f32] * 4 + [_vp]),
+    "dskd_dense_loss_bwd": (C.c_int, [_vp] * 8 + [C.c_int] * 4 + [_f32] * 4 + [_vp]),
     "dskd_proto_corr_workspace": (_i64, [C.c_int, C.c_int]),
     "dskd_proto_corr_fwd": (C.c_int, [_vp] * 6 + [C.c_int] * 5 + [_f32] + [_vp] * 4),
     "dskd_fgkd_workspace": (_i64, [C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int]),
@@ -1182,6 +1184,63 @@ def match_cost(bbox_pred: torch.Tensor, cls_pred: torch.Tensor, gt_bboxes: torch
                                 P, Q, Cn, w_cls, w_reg, w_iou, _stream(bbox_pred))
     _check(rc, "dskd_match_cost")
     return cost
+
+
+# --------------------------------------------------------------------------- dense detection losses (csrc/denseloss.hip)
+class _DenseLossFunction(torch.autograd.Function):
+    """(loss_cls, loss_bbox, loss_iou, loss_dfl), each [nl], of ``GFLDeformableDETRHead_il.loss_layers_dense`` in two
+    launches; backward in one (``dskd_dense_loss_fwd`` / ``_bwd``)."""
+
+    @staticmethod
+    def forward(ctx, cls, box, lrtb, labels, tgt, pos, factors, avg_pos, weights):
+        nl, N, Cn = cls.shape
+        R1 = lrtb.shape[-1] // 4
+        dev = cls.device
+        f32 = torch.float32
+        losses = torch.empty((4, nl), dtype=f32, device=dev)
+        row_loss = torch.empty((4, nl * N), dtype=f32, device=dev)
+        d_cls = torch.empty((nl * N, Cn), dtype=f32, device=dev)
+        d_box = torch.empty((3, nl * N, 4), dtype=f32, device=dev)
+        d_lrtb = torch.empty((nl * N, 4 * R1), dtype=f32, device=dev)
+        rc = load().dskd_dense_loss_fwd(cls.data_ptr(), box.data_ptr(), lrtb.data_ptr(), labels.data_ptr(), tgt.data_ptr(),
+                                        pos.data_ptr(), factors.data_ptr(), avg_pos.data_ptr(), losses.data_ptr(),
+                                        row_loss.data_ptr(), d_cls.data_ptr(), d_box.data_ptr(), d_lrtb.data_ptr(), nl, N, Cn, R1,
+                                        *weights, _stream(cls))
+        _check(rc, "dskd_dense_loss_fwd")
+        ctx.save_for_backward(d_cls, d_box, d_lrtb, avg_pos)
+        ctx.meta = (nl, N, Cn, R1, weights)
+        return losses[0], losses[1], losses[2], losses[3]
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2, g3):
+        d_cls, d_box, d_lrtb, avg_pos = ctx.saved_tensors
+        nl, N, Cn, R1, weights = ctx.meta
+        g = torch.stack([t if t is not None else torch.zeros(nl, device=d_cls.device) for t in (g0, g1, g2, g3)]).float().contiguous()
+        g_cls = torch.empty((nl, N, Cn), dtype=torch.float32, device=d_cls.device)
+        g_box = torch.empty((nl, N, 4), dtype=torch.float32, device=d_cls.device)
+        g_lrtb = torch.empty((nl, N, 4 * R1), dtype=torch.float32, device=d_cls.device)
+        rc = load().dskd_dense_loss_bwd(g.data_ptr(), avg_pos.data_ptr(), d_cls.data_ptr(), d_box.data_ptr(), d_lrtb.data_ptr(),
+                                        g_cls.data_ptr(), g_box.data_ptr(), g_lrtb.data_ptr(), nl, N, Cn, R1, *weights,
+                                        _stream(d_cls))
+        _check(rc, "dskd_dense_loss_bwd")
+        return g_cls, g_box, g_lrtb, None, None, None, None, None, None
+
+
+def dense_losses_ok(cls, box, lrtb, beta, eps_iou, reg_max1) -> bool:
+    """Can csrc/denseloss.hip take these dense losses (CUDA f32 tensors, QFL beta 2, GIoU eps 1e-6, <= 128 classes)?"""
+    return (cls.is_cuda and cls.dtype == box.dtype == lrtb.dtype == torch.float32 and cls.dim() == 3 and float(beta) == 2.0
+            and abs(float(eps_iou) - 1e-6) < 1e-12 and cls.shape[-1] <= 128 and 2 <= reg_max1 <= 64
+            and lrtb.shape[-1] == 4 * reg_max1)
+
+
+def dense_losses(cls, box, lrtb, labels, tgt, pos, factors, avg_pos, weights):
+    """cls [nl, N, C], box [nl, N, 4] cxcywh, lrtb [nl, N, 4 * (reg_max + 1)], labels [nl, N] int64, tgt [nl, N, 4],
+    pos [nl, N] bool, factors [N, 4], avg_pos 0-dim f32 tensor, weights = (w_cls, w_bbox, w_iou, w_dfl).
+    Returns (loss_cls, loss_bbox, loss_iou, loss_dfl), each [nl]; differentiable w.r.t. cls, box, lrtb."""
+    _need_gpu(cls, box, lrtb, labels, tgt, pos, factors, avg_pos)
+    return _DenseLossFunction.apply(cls.contiguous(), box.contiguous(), lrtb.contiguous(), labels.contiguous().long(),
+                                    tgt.contiguous().float(), pos.contiguous(), factors.contiguous().float(),
+                                    avg_pos.detach().reshape(1).float().contiguous(), tuple(float(w) for w in weights))
 
 
 # --------------------------------------------------------------------------- DSKD loss 1

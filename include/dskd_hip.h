@@ -24,6 +24,10 @@
  *       (gfl_hungarian_assigner.py:120-140) = BBoxL1Cost + IoUCost +
  *       QualityFocalLossCost (mmdet/core/bbox/match_costs/match_cost.py:34-51,
  *       :193-230, :460-476).
+ *   dskd_dense_loss_fwd / dskd_dense_loss_bwd
+ *       `loss_single_split` for all decoder layers: QFL / L1 / GIoU / DFL and their gradients
+ *       (gfl_deformable_detr_head_il.py:1453-1529, mmdet/models/losses/gfocal_loss.py,
+ *       iou_loss.py, smooth_l1_loss.py).
  *   dskd_proto_corr_fwd
  *       prototype accumulation + `correlation_mat` + MSELoss
  *       (mmdet/models/dense_heads/gfl_deformable_detr_head_il.py:525-555,
@@ -195,6 +199,37 @@ int dskd_match_cost(const float* bbox_pred, const float* cls_pred,
                     const int64_t* gt_start, const float* img_wh, float* cost,
                     int nprob, int Q, int C, float w_cls, float w_reg, float w_iou,
                     void* stream);
+
+/* ---------------------------------------------------------------------------
+ * The dense detection losses of all decoder layers x images at once: the per-layer arithmetic of
+ * `GFLDeformableDETRHead_il.loss_single_split` (gfl_deformable_detr_head_il.py:1453-1529) on
+ * precomputed dense targets -- QualityFocalLoss beta = 2 with the IoU of the positives as
+ * target score AND its gradient into the boxes (mmdet/models/losses/gfocal_loss.py:12-53),
+ * L1Loss on normalised cxcywh, GIoULoss eps = 1e-6 on pixel boxes (losses/iou_loss.py,
+ * core/bbox/iou_calculators/iou2d_calculator.py:190-261), DistributionFocalLoss
+ * (gfocal_loss.py:103-125) with the reference's targets (w/2, w/2, h/2, h/2) -- each reduced
+ * per layer as loss_weight * sum / (avg_factor + eps_f32) (losses/utils.py weight_reduce_loss;
+ * avg_factor = avg_pos, 4 * avg_pos for DFL).  Rows r = layer * N + query, R = nl * N.
+ *
+ * cls      device [R, C] f32 logits                 box   device [R, 4] f32 cxcywh in [0, 1]
+ * lrtb     device [R, 4 * R1] f32 (R1 = reg_max+1)   labels device [R] int64 (background = C)
+ * tgt      device [R, 4] f32 cxcywh targets          pos   device [R] bool (1 byte)
+ * factors  device [N, 4] f32 (w, h, w, h) of the query's image
+ * avg_pos  device [1] f32 = clamp(mean over ranks of num_total_pos, 1)
+ * losses   device [4, nl] f32 OUT: loss_cls, loss_bbox, loss_iou, loss_dfl per layer
+ * row_loss device [4, R] f32 workspace; d_cls [R, C], d_box [3, R, 4], d_lrtb [R, 4 * R1] f32 OUT:
+ *          unit-upstream gradients, consumed by dskd_dense_loss_bwd
+ * dskd_dense_loss_bwd: grad_losses device [4, nl] f32 (upstream gradients of `losses`) ->
+ *          grad_cls [R, C], grad_box [R, 4], grad_lrtb [R, 4 * R1].
+ * Deterministic (no atomics).  C <= 128, 2 <= R1 <= 64; tie / clamp conventions of PyTorch autograd.
+ * ------------------------------------------------------------------------- */
+int dskd_dense_loss_fwd(const float* cls, const float* box, const float* lrtb, const int64_t* labels,
+                        const float* tgt, const unsigned char* pos, const float* factors, const float* avg_pos,
+                        float* losses, float* row_loss, float* d_cls, float* d_box, float* d_lrtb, int nl, int N,
+                        int C, int R1, float w_cls, float w_bbox, float w_iou, float w_dfl, void* stream);
+int dskd_dense_loss_bwd(const float* grad_losses, const float* avg_pos, const float* d_cls, const float* d_box,
+                        const float* d_lrtb, float* grad_cls, float* grad_box, float* grad_lrtb, int nl, int N, int C,
+                        int R1, float w_cls, float w_bbox, float w_iou, float w_dfl, void* stream);
 
 /* ---------------------------------------------------------------------------
  * DSKD loss 1: between-class distance-matrix distillation.

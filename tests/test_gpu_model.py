@@ -617,6 +617,49 @@ def test_graphed_student_head_equals_eager(monkeypatch):
     assert len(set(round(v, 6) for v in vals[3:])) == 2, vals       # replays (calls 4, 5) draw different masks
 
 
+@pytest.mark.parametrize("case", ["random", "ties_and_misses", "no_positive"])
+def test_fused_dense_losses_match_the_pytorch_formulation(case):
+    """csrc/denseloss.hip (QFL / L1 / GIoU / DFL of all decoder layers in two launches, gradients in one) against
+    ``loss_layers_dense`` written with PyTorch ops (the formulation the reference goldens pin on the CPU): the four
+    per-layer losses and the gradients w.r.t. logits, boxes and distribution logits under random upstream weights.
+    Cases: random boxes; predictions equal to / disjoint from their targets (max / min ties, clamped overlaps and
+    enclosing boxes); a batch with no positive at all."""
+    dev = torch.device("cuda:0")
+    cfg, m = _build(seed=3)
+    head = m.bbox_head.to(dev)
+    g = torch.Generator().manual_seed(17)
+    nl, N, C, R1 = 6, 2 * 300, head.cls_out_channels, head.reg_max + 1
+    cls = (torch.randn(nl, N, C, generator=g) * 2).to(dev)
+    cxy = torch.rand(nl, N, 2, generator=g) * 0.6 + 0.2
+    wh = torch.rand(nl, N, 2, generator=g) * 0.3 + 0.05
+    box = torch.cat([cxy, wh], -1).to(dev)
+    lrtb = (torch.randn(nl, N, 4 * R1, generator=g) * 1.5).to(dev)
+    pos = (torch.rand(nl, N, generator=g) < (0.0 if case == "no_positive" else 0.08)).to(dev)
+    labels = torch.where(pos, torch.randint(0, C, (nl, N), generator=g).to(dev), torch.full((nl, N), C, device=dev))
+    tgt = torch.cat([cxy + (torch.rand(nl, N, 2, generator=g) - 0.5) * 0.2, wh * (0.6 + 0.8 * torch.rand(nl, N, 2, generator=g))], -1).to(dev)
+    if case == "ties_and_misses":
+        sel = pos.nonzero()
+        tgt[sel[0::3, 0], sel[0::3, 1]] = box[sel[0::3, 0], sel[0::3, 1]]                       # identical boxes: ties everywhere
+        tgt[sel[1::3, 0], sel[1::3, 1], :2] = box[sel[1::3, 0], sel[1::3, 1], :2] + 0.5           # disjoint: overlap clamped to 0
+    tgt = torch.where(pos[..., None], tgt, torch.zeros_like(tgt))
+    factors = torch.tensor([[1333., 800., 1333., 800.]] * 300 + [[1200., 750., 1200., 750.]] * 300, device=dev)
+    avg_pos = torch.tensor(max(float(pos.sum()) / nl, 1.0), device=dev)
+    up = [torch.rand(nl, generator=g).to(dev) + 0.5 for _ in range(4)]
+    res = []
+    for fused in (True, False):
+        head.fused_dense_losses = fused
+        head.graph_dense_losses = False
+        ins = [t.clone().requires_grad_(True) for t in (cls, box, lrtb)]
+        out = head._dense_losses(ins[0], ins[1], ins[2], labels, tgt, pos, factors, avg_pos)
+        total = sum((o * u).sum() for o, u in zip(out, up))
+        grads = torch.autograd.grad(total, ins)
+        res.append(([o.detach() for o in out], grads))
+    for a, b in zip(res[0][0], res[1][0]):
+        torch.testing.assert_close(a, b, rtol=2e-5, atol=1e-6)
+    for name, a, b in zip(("cls", "box", "lrtb"), res[0][1], res[1][1]):
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-7 + 2e-5 * float(b.abs().max()), msg=lambda s_: f"{name}: {s_}")
+
+
 def test_gfl_distillation_step_on_gpu_vs_cpu_oracle(oracle_checker):
     """BASELINE.json configs[4] (GFL R50-FPN, CNN-head distillation path) on the GPU: the trunk's outputs against the
     CPU run of the same weights, then -- on identical head inputs -- the stock GFL losses (ATSS targets, QFL / DFL /
