@@ -176,8 +176,11 @@ def cpu_baseline(seed, num_prev, batch=1, timed=3):
 
 
 GEMM_CONV_PATTERNS = ("Cijk_", "ck::", "_ZN2ck", "igemm_", "miopen", "MIOpen", "gemm_xdl", "xdlops", "wrw_", "naive_conv",
-                      "attn_fwd", "bwd_kernel_dk_dv", "bwd_kernel_dq", "ffn_fused_kernel", "lin256_kernel")
-OWN_MFMA_KERNELS = ("ffn_fused_kernel", "lin256_kernel")      # csrc/ffn_mfma.hip: the hand-written MFMA kernels on the path
+                      "attn_fwd", "bwd_kernel_dk_dv", "bwd_kernel_dq", "ffn_fused_kernel", "lin256_kernel", "gemm_nt_kernel",
+                      "gemm_tn_kernel", "winattn_")
+# the hand-written MFMA kernels on the path: csrc/ffn_mfma.hip, csrc/gemm_nt.hip (1x1 / 3x3 convolutions, weight gradients),
+# csrc/winattn.hip (Swin window attention)
+OWN_MFMA_KERNELS = ("ffn_fused_kernel", "lin256_kernel", "gemm_nt_kernel", "gemm_tn_kernel", "winattn_")
 MFMA_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 
 
@@ -218,8 +221,9 @@ def mfma_utilisation(step_fn, dtype):
         return None
     own = None
     if own_us > 0:
-        own = {"kernel": "dskd::ffn_fused_kernel (encoder FFN: forward, training forward, backward) + dskd::lin256_kernel (tall "
-                         "256-input Linear layers and their dX), csrc/ffn_mfma.hip", "launches": own_n,
+        own = {"kernel": "dskd::ffn_fused_kernel (encoder FFN) + dskd::lin256_kernel (tall 256-input Linear layers and their "
+                         "dX), csrc/ffn_mfma.hip; dskd::gemm_nt_kernel (1x1 / 3x3 convolutions forward and dX) + "
+                         "dskd::gemm_tn_kernel (weight gradients), csrc/gemm_nt.hip", "launches": own_n,
                "flops_TFLOP": round(own_flops / 1e12, 3), "kernel_ms": round(own_us / 1e3, 2),
                "achieved_TFLOPs": round(own_flops / (own_us * 1e-6) / 1e12, 1),
                "frac": round(own_flops / (own_us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
@@ -230,9 +234,9 @@ def mfma_utilisation(step_fn, dtype):
             "gemm_conv_launches": n, "all_kernel_ms": round(total_us / 1e3, 2), "achieved_TFLOPs": round(tflops, 1),
             "peak_TFLOPs": peak, "frac": round(tflops / peak, 4),
             "counted": "aten mm/addmm/bmm/convolution/sdpa (FlopCounterMode) + the hand-written MFMA launches (fused FFN: 4 * "
-                       "tokens * 256 * 1024 each; lin256: 2 * tokens * 256 * N), forward + backward, teacher + student; time = "
-                       "device time of the hipBLASLt / CK / MIOpen / attention / ffn_fused / lin256 kernels in one profiled "
-                       "eager step",
+                       "tokens * 256 * 1024 each; lin256 / gemm_nt / gemm_tn: 2 M N K; conv3x3: 2 * pixels * N * 9 C), forward + "
+                       "backward, teacher + student; time = device time of the hipBLASLt / CK / MIOpen / attention kernels and of "
+                       "the hand-written MFMA kernels in one profiled eager step",
             "top_kernels_ms": {k: round(v / 1e3, 2) for k, v in top}, "hand_written": own}
 
 
