@@ -509,7 +509,7 @@ def main():
             # launch shape (profiles/r01_msda_pmc_hbm_B4_bf16.json: FETCH_SIZE doubled per the
             # gfx950 correction + WRITE_SIZE), valid for the default B=4 bf16 workload only.
             traffic = traffic_detail = None
-            pmc = os.path.join(ROOT, "profiles", "r02_msda_pmc_hbm_B4_bf16.json")
+            pmc = os.path.join(ROOT, "profiles", "r03_msda_pmc_hbm_B4_bf16.json")
             if not os.path.exists(pmc):
                 pmc = os.path.join(ROOT, "profiles", "r01_msda_pmc_hbm_B4_bf16.json")
             if args.batch == 4 and args.dtype == "bf16" and os.path.exists(pmc):

@@ -19,6 +19,17 @@ inline int check_launch(const char* what) {
   return DSKD_OK;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: set it once on every device a process launches on
+// (`done`: a zero-initialised static array of 64 flags owned by the call site).
+inline bool reserve_lds(const void* kernel, int bytes, bool* done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (done[dev]) return true;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+  done[dev] = true;
+  return true;
+}
+
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 using i32x4 = __attribute__((ext_vector_type(4))) int;

@@ -617,21 +617,16 @@ __global__ __launch_bounds__(kWaves * 64, DSKD_LIN_OCC) void lin256_kernel(const
 
 constexpr size_t kFfnLds = kBufs * kTileBytes + kF * sizeof(float) + kWaves * 2048 + kWaves * kF * sizeof(float);   // 156 KB
 
-// 140 KB of dynamic LDS needs the attribute on every instantiation; set once, outside any stream capture window the
-// first launch may be in.
+// 156 KB of dynamic LDS needs the attribute on every instantiation, on every device the process launches on.
 hipError_t ffn_attributes() {
-  static const hipError_t e = [] {
-    const void* fns[] = {reinterpret_cast<const void*>(&ffn_fused_kernel<kFwdTrain>),
-                         reinterpret_cast<const void*>(&ffn_fused_kernel<kFwdEval>),
-                         reinterpret_cast<const void*>(&ffn_fused_kernel<kBwd>),
-                         reinterpret_cast<const void*>(&ffn_fused_kernel<kFwdTrainDrop>)};
-    for (const void* f : fns) {
-      const hipError_t r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfnLds);
-      if (r != hipSuccess) return r;
-    }
-    return hipSuccess;
-  }();
-  return e;
+  static bool done[4][64] = {};
+  const void* fns[4] = {reinterpret_cast<const void*>(&ffn_fused_kernel<kFwdTrain>),
+                        reinterpret_cast<const void*>(&ffn_fused_kernel<kFwdEval>),
+                        reinterpret_cast<const void*>(&ffn_fused_kernel<kBwd>),
+                        reinterpret_cast<const void*>(&ffn_fused_kernel<kFwdTrainDrop>)};
+  for (int i = 0; i < 4; ++i)
+    if (!reserve_lds(fns[i], (int)kFfnLds, done[i])) return hipErrorInvalidValue;
+  return hipSuccess;
 }
 
 template <int MODE>
@@ -742,9 +737,9 @@ extern "C" int dskd_lin256_fwd(const void* x, const void* packed, const void* bi
   if (misaligned(x) || misaligned(packed) || misaligned(y)) return fail(DSKD_ERR_INVALID_ARG, "dskd_lin256_fwd: pointers must be 16-byte aligned");
   if (tokens == 0) return DSKD_OK;
   const size_t lds = kLinBufs * kLinTileBytes + (size_t)N * sizeof(float);
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&lin256_kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLinBufs * kLinTileBytes + 512 * 4);
-  if (attr != hipSuccess) return fail(DSKD_ERR_LAUNCH, "dskd_lin256_fwd: LDS attribute: %s", hipGetErrorString(attr));
+  static bool done[64] = {};
+  if (!reserve_lds(reinterpret_cast<const void*>(&lin256_kernel), kLinBufs * kLinTileBytes + 512 * 4, done))
+    return fail(DSKD_ERR_LAUNCH, "dskd_lin256_fwd: cannot reserve LDS");
   LinArgs a{};
   a.x = (const __bf16*)x; a.wp = (const __bf16*)packed; a.bias = (const __bf16*)bias; a.y = (__bf16*)y;
   a.T = tokens; a.N = N; a.relu = relu;

@@ -1459,9 +1459,8 @@ bool make_fwd_win_geom(const LevelGeom& lg, int levels, int points, int Nq, int 
 int launch_fwd_win(const __bf16* value, const float* loc, const float* attn, __bf16* out, const ValueGeom& g,
                    const FwdWinGeom& fw, size_t lds, int B, int Nq, int points, hipStream_t st) {
   auto kern = msda_fwd_win_kernel<__bf16>;
-  static const hipError_t attr = hipFuncSetAttribute(
-      (const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
-  if (attr != hipSuccess) return fail(DSKD_ERR_LAUNCH, "dskd_msda_fwd: cannot reserve LDS");
+  static bool done[64] = {};
+  if (!reserve_lds((const void*)kern, (int)kMaxLds, done)) return fail(DSKD_ERR_LAUNCH, "dskd_msda_fwd: cannot reserve LDS");
   const dim3 grid((unsigned)(B * g.RY * g.RX * kHeads)), block(fw.waves * 64);
   hipLaunchKernelGGL(kern, grid, block, lds, st, value, loc, attn, out, g, fw, Nq, points);
   return DSKD_OK;
@@ -1756,9 +1755,8 @@ int launch_bwd_win(const __bf16* value, const float* loc, const float* attn, con
                    float* grad_attn, float* stats, const ValueGeom& g, const FwdWinGeom& fw, size_t lds, int B, int Nq,
                    int points, hipStream_t st) {
   auto kern = msda_bwd_win_kernel<__bf16>;
-  static const hipError_t attr = hipFuncSetAttribute(
-      (const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
-  if (attr != hipSuccess) return fail(DSKD_ERR_LAUNCH, "dskd_msda_bwd: cannot reserve LDS");
+  static bool done[64] = {};
+  if (!reserve_lds((const void*)kern, (int)kMaxLds, done)) return fail(DSKD_ERR_LAUNCH, "dskd_msda_bwd: cannot reserve LDS");
   const dim3 grid((unsigned)(B * g.RY * g.RX * kHeads)), block(fw.waves * 64);
   hipLaunchKernelGGL(kern, grid, block, lds, st, value, loc, attn, grad_out, grad_loc, grad_attn, stats, g, fw, Nq, points);
   return DSKD_OK;

@@ -426,6 +426,8 @@ class GFLHead(nn.Module):
                       teacher_info=None, task_labels=None, **kwargs):
         outs = self.forward(x)
         losses = self.loss(*outs, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore)
+        if losses is None:         # no valid anchor in some image (get_targets returned None, as in the reference's loss())
+            return None
         if self.has_teacher and teacher_info and teacher_info.get("neck_feats") is not None and \
                 "fg_info" in self.feats_distill and "decode_v1" in self.feats_distill:
             losses["loss_fg_feature"] = self.fg_feature_loss(x, teacher_info, gt_bboxes, img_metas)

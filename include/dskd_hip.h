@@ -92,11 +92,8 @@ int dskd_device_count(void);
  * attn           device, [B, Nq, heads, levels, points]    f32
  * out            device, [B, Nq, heads*ch]    same dtype as value
  * Supported: heads == 8, ch == 32, levels <= 4, levels*points <= 16.
- * Diagnostic environment switches (A/B measurements; never needed for correct results, every
- * variant is bit-identical to the default): DSKD_MSDA_PHASES=1|2|4 (bf16 staging phases),
- * DSKD_MSDA_FWD=plain (the plain bf16 forward instead of the windowed one for Nq == Nv, 4 levels x 4 points;
- * DSKD_MSDA_FWD_LV0=0..3 first level held in LDS, DSKD_MSDA_FWD_NW=4..16 waves per workgroup),
- * DSKD_MSDA_BWD=v1 (plain-atomics backward).
+ * Nq == Nv with 4 levels x 4 points (the encoder) in bf16 takes the windowed kernel (coarse levels of one head in
+ * LDS), bit-identical to the plain one.
  * ------------------------------------------------------------------------- */
 int dskd_msda_fwd(const void* value, const int64_t* spatial_shapes,
                   const int64_t* level_start, const float* loc, const float* attn,
@@ -129,13 +126,15 @@ int dskd_msda_bwd(const void* value, const int64_t* spatial_shapes,
 /* The same with a caller-owned workspace, which unlocks the fastest encoder-shape path (Nq == Nv, 4 levels x 4
  * points): grad_value of the finest level is produced by a tiled gather ("pull") kernel with plain stores -- f32
  * accumulation in registers, no atomics, no fixed point -- and only samples that stray further than a few cells
- * from their query go through a list in the workspace and are added afterwards.
+ * from their query go through a list in the workspace and are added afterwards; in bf16, grad_value of levels 1-3 is
+ * formed on the matrix cores (csrc/msda_mm.hip: S^T G per window tile, scaled by the gather kernel's statistics,
+ * which also live in the workspace).
  * grad_value   need NOT be zeroed: it is overwritten.
- * workspace    device, 16-byte aligned, at least dskd_msda_bwd_workspace(...) bytes; its first 64 bytes must be
- *              zero before the FIRST call (the library leaves them zero); one workspace per stream in flight.
+ * workspace    device, 16-byte aligned, at least dskd_msda_bwd_workspace(...) bytes (its header is zeroed at the start
+ *              of every call); one workspace per stream in flight.
  * Environment (A/B measurements only): DSKD_MSDA_PULL_LEVELS=<digits> levels handled by the pull kernel (default
- * "0"; "none" = none), DSKD_MSDA_PULL_MARGIN=<cells> candidate margin (default 5), DSKD_MSDA_PULL_THREADS=256|512|1024
- * workgroup size (default 512). */
+ * "0"; "none" = none); DSKD_MSDA_MM=<digits> levels on the matrix-core kernel (default "123"; "0" = none: the
+ * windowed fixed-point kernels). */
 int64_t dskd_msda_bwd_workspace(int B, int Nv, int Nq, int heads, int levels, int points);
 int dskd_msda_bwd_ws(const void* value, const int64_t* spatial_shapes,
                      const int64_t* level_start, const float* loc, const float* attn,
