@@ -303,8 +303,9 @@ def test_teacher_ahead_graph_replay_tracks_eager_teacher():
 
 
 def test_graphed_dense_losses_equal_eager():
-    """The dense detection losses replayed as hipGraphs (forward + backward) against the eager
-    computation: new inputs every call, non-unit upstream gradients."""
+    """The dense detection losses in their PyTorch formulation (what runs where csrc/denseloss.hip does not apply: other
+    loss types / beta) replayed as hipGraphs (forward + backward) against the eager computation: new inputs every call,
+    non-unit upstream gradients."""
     cfg, m = _build(seed=9)
     head = m.bbox_head.to("cuda:0")
     nl, N, C = 6, 2 * 300, 80
@@ -320,6 +321,7 @@ def test_graphed_dense_losses_equal_eager():
         return cls, cx, lr, labels, tgt, labels < 80, factors
 
     head.graph_dense_losses = True
+    head.fused_dense_losses = False           # the PyTorch formulation (the fused kernels of csrc/denseloss.hip have their own test)
     for step in range(6):
         a = inputs()
         w = [torch.rand(nl, generator=g).to("cuda:0") + 0.5 for _ in range(4)]
