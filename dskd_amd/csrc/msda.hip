@@ -2025,12 +2025,8 @@ int msda_bwd_impl(const void* value, const int64_t* spatial_shapes, const int64_
                                         points, ex, st, variants)) return rc;
     }
     const int sgrid[4] = {wg.RX, wg.RY, wg.EX, wg.EY};
-    if (mm & 4)
-      if (int rc = launch_bwd_mm(loc, attn, grad_out, grad_value, stats, sgrid, ml, 2, 2, B, Nq, points, st))
-        return rc;
-    if (mm & 2)
-      if (int rc = launch_bwd_mm(loc, attn, grad_out, grad_value, stats, sgrid, ml, 1, 1, B, Nq, points, st))
-        return rc;
+    if (mm)
+      if (int rc = launch_bwd_mm(loc, attn, grad_out, grad_value, stats, sgrid, ml, mm, B, Nq, points, st)) return rc;
     if (pull_mask)
       if (int rc = launch_pull(loc, attn, grad_out, grad_value, ml, pull_mask, B, Nq, dtype, workspace,
                                workspace_bytes - stats_bytes, st)) return rc;

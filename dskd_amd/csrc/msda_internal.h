@@ -30,11 +30,11 @@ int launch_pull(const float* loc, const float* attn, const void* grad_out, float
                 const MsdaLevels& lg, int level_mask, int B, int Nq, int dtype, void* workspace,
                 size_t workspace_bytes, hipStream_t st);
 
-// Matrix-core grad_value of the coarse levels (msda_mm.hip; encoder shape, bf16): rows of levels [lv0, lv0 + nlv), lv0 >= 1,
-// nlv <= 2, added with atomics into rows the caller zeroed.  ``stats``: the gather kernel's per-(16 x 16 region, head)
+// Matrix-core grad_value of the coarse levels (msda_mm.hip; encoder shape, bf16): rows of level 1 (mask bit 1) and / or levels
+// 2+3 (mask bit 2) in ONE launch, added with atomics into rows the caller zeroed.  ``stats``: the gather kernel's per-(16 x 16 region, head)
 // by-product {max |grad_out|, ...}, written earlier on the same stream; ``sgrid`` = {RX, RY, EX, EY} of that kernel's grid.
 bool mm_supported(const MsdaLevels& lg, int levels, int points, int Nv, int Nq, int dtype, int lv0, int nlv);
 int launch_bwd_mm(const float* loc, const float* attn, const void* grad_out, float* grad_value, const float* stats,
-                  const int* sgrid, const MsdaLevels& lg, int lv0, int nlv, int B, int Nq, int points, hipStream_t st);
+                  const int* sgrid, const MsdaLevels& lg, int mask, int B, int Nq, int points, hipStream_t st);
 
 }  // namespace dskd

@@ -84,19 +84,11 @@ __device__ unsigned long long g_mmprof[32];
 __global__ __launch_bounds__(kMmWaves * 64, 4) void msda_bwd_mm_kernel(
     const float* __restrict__ loc, const float* __restrict__ attn, const __bf16* __restrict__ grad_out,
     float* __restrict__ grad_value, const float* __restrict__ stats, int sRX, int sRY, int sEX, int sEY, ValueGeom g,
-    MmGeom mg, int Nq, int points) {
+    MmGeom mga, MmGeom mgb, int ngroups, int Nq, int points) {
   constexpr int LP = 16;
   constexpr int NW = kMmWaves;
   constexpr int TPW = kMmTpw;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int NPX = mg.ntiles * 32;
-  char* s_S = smem;                                             // [2][NPX][16 q] u16 fixed point, swizzled (img16_off)
-  char* s_gt = s_S + 2 * NPX * 32;                              // [2][32 ch][16 q] f16 (scaled), swizzled
-  int* s_row = reinterpret_cast<int*>(s_gt + 2 * kCh * 32);     // [NPX] window position -> value row of the image | -1
-  i32x4* s_tab = reinterpret_cast<i32x4*>(s_row + NPX);         // [4][4] lookup rows (msda_geom.h)
-  int* s_geo = reinterpret_cast<int*>(s_tab + 4 * kMaxLevels);  // [24]
-  float* s_red = reinterpret_cast<float*>(s_geo + 6 * kMaxLevels);   // [4]
-
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -106,6 +98,26 @@ __global__ __launch_bounds__(kMmWaves * 64, 4) void msda_bwd_mm_kernel(
 #endif
 
   int vb = xcd_remap(blockIdx.x, gridDim.x);
+  // one launch serves both level groups (level 1 | levels 2+3): 2 x 768 workgroups fill 512 slots in 3 rounds where two
+  // launches of 768 took 2 x 2.  The group's geometry becomes scalars here (kernel-argument arrays must not be
+  // indexed at run time).
+  const bool second = ngroups > 1 && (vb & 1);
+  if (ngroups > 1) vb >>= 1;
+  struct { int lv0, nlv, npos, ntiles, base[kMaxLevels]; } mg;
+  mg.lv0 = second ? mgb.lv0 : mga.lv0;
+  mg.nlv = second ? mgb.nlv : mga.nlv;
+  mg.npos = second ? mgb.npos : mga.npos;
+  mg.ntiles = second ? mgb.ntiles : mga.ntiles;
+#pragma unroll
+  for (int l = 0; l < kMaxLevels; ++l) mg.base[l] = second ? mgb.base[l] : mga.base[l];
+  const int NPX = mg.ntiles * 32;
+  char* s_S = smem;                                             // [2][NPX][16 q] u16 fixed point, swizzled (img16_off)
+  char* s_gt = s_S + 2 * NPX * 32;                              // [2][32 ch][16 q] f16 (scaled), swizzled
+  int* s_row = reinterpret_cast<int*>(s_gt + 2 * kCh * 32);     // [NPX] window position -> value row of the image | -1
+  i32x4* s_tab = reinterpret_cast<i32x4*>(s_row + NPX);         // [4][4] lookup rows (msda_geom.h)
+  int* s_geo = reinterpret_cast<int*>(s_tab + 4 * kMaxLevels);  // [24]
+  float* s_red = reinterpret_cast<float*>(s_geo + 6 * kMaxLevels);   // [4]
+
   const int h = vb & 7; vb >>= 3;
   const int rx = vb % g.RX; vb /= g.RX;
   const int ry = vb % g.RY;
@@ -448,25 +460,32 @@ bool mm_supported(const MsdaLevels& lg, int levels, int points, int Nv, int Nq, 
 }
 
 int launch_bwd_mm(const float* loc, const float* attn, const void* grad_out, float* grad_value, const float* stats,
-                  const int* sgrid, const MsdaLevels& lg, int lv0, int nlv, int B, int Nq, int points, hipStream_t st) {
+                  const int* sgrid, const MsdaLevels& lg, int mask, int B, int Nq, int points, hipStream_t st) {
   if (!stats || !sgrid) return fail(DSKD_ERR_INVALID_ARG, "dskd_msda_bwd: matrix-core backward needs the gather kernel's statistics");
+  // mask: bit 1 = level 1, bit 2 = levels 2+3; both groups go out as ONE launch (interleaved workgroups)
   ValueGeom g;
-  MmGeom mg;
-  size_t lds;
-  if (!make_mm_geom(lg, 4, points, Nq, lv0, nlv, &g, &mg, &lds))
-    return fail(DSKD_ERR_INVALID_ARG, "dskd_msda_bwd: matrix-core backward does not take these levels");
-  auto kern = msda_bwd_mm_kernel;
-  int dev = 0;
-  static bool done[64] = {};              // the attribute is per device: set it once on each
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (!done[dev]) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMmMaxLds) != hipSuccess)
-      return fail(DSKD_ERR_LAUNCH, "dskd_msda_bwd: cannot reserve LDS");
-    done[dev] = true;
+  MmGeom mg[2];
+  size_t lds[2] = {0, 0};
+  int ng = 0;
+  if (mask & 2) {
+    if (!make_mm_geom(lg, 4, points, Nq, 1, 1, &g, &mg[ng], &lds[ng]))
+      return fail(DSKD_ERR_INVALID_ARG, "dskd_msda_bwd: matrix-core backward does not take level 1");
+    ++ng;
   }
-  const dim3 grid((unsigned)(B * g.RY * g.RX * kHeads)), block(kMmWaves * 64);
-  hipLaunchKernelGGL(kern, grid, block, lds, st, loc, attn, (const __bf16*)grad_out, grad_value, stats, sgrid[0], sgrid[1],
-                     sgrid[2], sgrid[3], g, mg, Nq, points);
+  if (mask & 4) {
+    if (!make_mm_geom(lg, 4, points, Nq, 2, 2, &g, &mg[ng], &lds[ng]))
+      return fail(DSKD_ERR_INVALID_ARG, "dskd_msda_bwd: matrix-core backward does not take levels 2+3");
+    ++ng;
+  }
+  if (ng == 0) return DSKD_OK;
+  if (ng == 1) mg[1] = mg[0];
+  const size_t lds_max = lds[0] > lds[1] ? lds[0] : lds[1];
+  auto kern = msda_bwd_mm_kernel;
+  static bool done[64] = {};
+  if (!reserve_lds((const void*)kern, (int)kMmMaxLds, done)) return fail(DSKD_ERR_LAUNCH, "dskd_msda_bwd: cannot reserve LDS");
+  const dim3 grid((unsigned)(B * g.RY * g.RX * kHeads * ng)), block(kMmWaves * 64);
+  hipLaunchKernelGGL(kern, grid, block, lds_max, st, loc, attn, (const __bf16*)grad_out, grad_value, stats, sgrid[0], sgrid[1],
+                     sgrid[2], sgrid[3], g, mg[0], mg[1], ng, Nq, points);
   return DSKD_OK;
 }
 
