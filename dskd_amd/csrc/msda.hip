@@ -1671,7 +1671,7 @@ __global__ __launch_bounds__(1024) void msda_bwd_win_kernel(
       const i32x4 lt = s_tab[4 * lvl + 1];
       const float Wf = (float)lt.z, Hf = (float)lt.w;
       // ---- consume: lane = (query, 16-B part)
-#pragma unroll 2
+#pragma unroll 4      // all 16 corner loads of a level in flight (2: 249 us, 4: 238 us; the forward spills at 4)
       for (int sl = 0; sl < 4; ++sl) {
         const i32x4 o = s_off[ql * kFwdHS + sl];
         u32x4 r0, r1, r2, r3;
