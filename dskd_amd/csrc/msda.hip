@@ -1988,14 +1988,17 @@ int msda_bwd_impl(const void* value, const int64_t* spatial_shapes, const int64_
       zero_fill(workspace, kPullWsHeader, st);
       zero_fill(grad_value, sizeof(float) * (size_t)B * Nv * (kHeads * kCh), st);
     } else {
-      for (int l = 0; l < levels; ++l)
-        if (!(pull_mask & (1 << l))) {
-          const int nrows = g.H[l] * g.W[l];
-          const int bx = (nrows * 64 + 255) / 256;
-          hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)(bx < 1024 ? bx : 1024), (unsigned)B), dim3(256), 0, st,
-                             grad_value, Nv, g.start[l], nrows, hdr);
-          hdr = nullptr;
-        }
+      // runs of consecutive un-pulled levels (their rows are contiguous) share one launch
+      for (int l = 0; l < levels;) {
+        if (pull_mask & (1 << l)) { ++l; continue; }
+        int e = l, nrows = 0;
+        while (e < levels && !(pull_mask & (1 << e)) && g.start[e] == g.start[l] + nrows) nrows += g.H[e] * g.W[e], ++e;
+        const int bx = (nrows * 64 + 255) / 256;
+        hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)(bx < 1024 ? bx : 1024), (unsigned)B), dim3(256), 0, st,
+                           grad_value, Nv, g.start[l], nrows, hdr);
+        hdr = nullptr;
+        l = e;
+      }
       if (hdr) zero_fill(workspace, kPullWsHeader, st);       // every level pulled: nothing else zeroes it
     }
   }

@@ -116,7 +116,6 @@ __global__ __launch_bounds__(kMmWaves * 64, 4) void msda_bwd_mm_kernel(
   int* s_row = reinterpret_cast<int*>(s_gt + 2 * kCh * 32);     // [NPX] window position -> value row of the image | -1
   i32x4* s_tab = reinterpret_cast<i32x4*>(s_row + NPX);         // [4][4] lookup rows (msda_geom.h)
   int* s_geo = reinterpret_cast<int*>(s_tab + 4 * kMaxLevels);  // [24]
-  float* s_red = reinterpret_cast<float*>(s_geo + 6 * kMaxLevels);   // [4]
 
   const int h = vb & 7; vb >>= 3;
   const int rx = vb % g.RX; vb /= g.RX;
@@ -127,27 +126,6 @@ __global__ __launch_bounds__(kMmWaves * 64, 4) void msda_bwd_mm_kernel(
   if (wave == 0) DSKD_REGION_TABLES(g, rx, ry, lane, MM_BASE, s_tab, s_geo);
 #undef MM_BASE
   for (int i = tid; i < NPX * 4; i += NW * 64) reinterpret_cast<u32x4*>(s_S)[i] = u32x4{0u, 0u, 0u, 0u};
-  // the region's max |grad_out|: the (16 x 16-pixel region, head) cells of the gather kernel that cover this region's
-  // level-0 pixel range (a query's region is its centre's level-0 pixel / edge in both kernels, so their union contains
-  // every query of ours)
-  if (wave == 1) {
-    const int px0 = rx * g.EX, px1 = min((rx + 1) * g.EX, g.W[0]) - 1;
-    const int py0 = ry * g.EY, py1 = min((ry + 1) * g.EY, g.H[0]) - 1;
-    const int gx0 = px0 / sEX, gx1 = min(px1 / sEX, sRX - 1), gy0 = py0 / sEY, gy1 = min(py1 / sEY, sRY - 1);
-    const int nx = gx1 - gx0 + 1, ncell = nx * (gy1 - gy0 + 1);
-    float m = 0.f;
-    for (int i = lane; i < ncell; i += 64) {
-      const int iy = i / nx, ix = i - iy * nx;
-      const float v = stats[((((size_t)b * sRY + gy0 + iy) * sRX + gx0 + ix) * kHeads + h) * 4];
-      m = (v != v) ? v : fmaxf(m, v);            // keep a NaN
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float m2 = __shfl_xor(m, o);
-      m = (m != m) ? m : ((m2 != m2) ? m2 : fmaxf(m, m2));
-    }
-    if (lane == 0) s_red[0] = m;
-  }
   __syncthreads();
   int cum[kMaxLevels];
 #pragma unroll
@@ -171,17 +149,35 @@ __global__ __launch_bounds__(kMmWaves * 64, 4) void msda_bwd_mm_kernel(
     s_row[p] = row;
   }
 
-  // power-of-two scale of grad_out for the f16 product: the region's max |grad_out| -> 2^13
+  // power-of-two scale of grad_out for the f16 product: the region's max |grad_out| -> 2^13.  The maximum comes from the
+  // (16 x 16-pixel region, head) cells of the gather kernel that cover this region's level-0 pixel range (a query's region
+  // is its centre's level-0 pixel / edge in both kernels, so their union contains every query of ours); every wave that
+  // needs the scale reads those few cells itself, where the load's latency hides behind its wait for the first chunk.
   float go_scale = 1.f, go_inv = 1.f;
-  {
-    const int eb = (int)((__builtin_bit_cast(unsigned, s_red[0]) >> 23) & 0xFFu);   // biased exponent
+  auto set_scale = [&]() {
+    const int px0 = rx * g.EX, px1 = min((rx + 1) * g.EX, g.W[0]) - 1;
+    const int py0 = ry * g.EY, py1 = min((ry + 1) * g.EY, g.H[0]) - 1;
+    const int gx0 = px0 / sEX, gx1 = min(px1 / sEX, sRX - 1), gy0 = py0 / sEY, gy1 = min(py1 / sEY, sRY - 1);
+    const int nx = gx1 - gx0 + 1, ncell = nx * (gy1 - gy0 + 1);
+    float m = 0.f;
+    for (int i = lane; i < ncell; i += 64) {
+      const int iy = i / nx, ix = i - iy * nx;
+      const float v = stats[((((size_t)b * sRY + gy0 + iy) * sRX + gx0 + ix) * kHeads + h) * 4];
+      m = (v != v) ? v : fmaxf(m, v);            // keep a NaN
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float m2 = __shfl_xor(m, o);
+      m = (m != m) ? m : ((m2 != m2) ? m2 : fmaxf(m, m2));
+    }
+    const int eb = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xFFu);          // biased exponent
     if (eb > 0 && eb < 255) {                                                       // finite, normal
       int se = 127 + 13 - (eb - 127);
       se = se < 27 ? 27 : (se > 227 ? 227 : se);
       go_scale = as_f32((unsigned)se << 23);
       go_inv = as_f32((unsigned)(254 - se) << 23);
     }
-  }
+  };
 
   const int nlv = mg.nlv;
   const bool sampler = wave < nlv;               // wave-uniform roles
@@ -317,6 +313,7 @@ __global__ __launch_bounds__(kMmWaves * 64, 4) void msda_bwd_mm_kernel(
     }
   } else if (stager) {
     // =================================================================== stager: grad_out image of chunk c during chunk c - 1
+    set_scale();
     int p_qg[kMmPre];
     u32x4 p_go[kMmPre];
     auto fetch = [&](int c, int& n_qg, u32x4& n_go) {      // asm load + counted wait, as in the sampler
@@ -350,6 +347,7 @@ __global__ __launch_bounds__(kMmWaves * 64, 4) void msda_bwd_mm_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the look-ahead loads of the last iterations land in dead registers
   } else {
     // =================================================================== product waves
+    set_scale();
     f32x16 acc[TPW];
 #pragma unroll
     for (int i = 0; i < TPW; ++i)
