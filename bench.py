@@ -355,8 +355,20 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # DSKD_BENCH_DDP1=1 (diagnostic, one GPU): a ONE-rank RCCL process group and the DDP wrap around the student, so that the
+    # production combination -- backend nccl, DDP's bucketed all-reduce hooks, head graphs, teacher graph on its side
+    # stream -- executes on a 1-GPU box (everything except the inter-GPU transfers themselves).
+    ddp1 = world == 1 and bool(os.environ.get("DSKD_BENCH_DDP1"))
+    json_out = sys.stdout
+    if (world > 1 or ddp1) and not rehearse:
+        # RCCL prints its version banner on stdout when the first communicator is created; the contract is ONE JSON line
+        # on stdout: everything a rank (or a library inside it) writes to fd 1 goes to stderr, the JSON line to the real stdout
+        sys.stdout.flush()
+        json_out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+    if world > 1 or ddp1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
         dist.init_process_group("gloo" if rehearse else "nccl", rank=rank, world_size=world)
     native.load()
 
@@ -412,9 +424,11 @@ def main():
                 p.grad = None
     if stepper is None:
         wrapped = model
-        if world > 1:
+        if world > 1 or ddp1:
             from dskd_amd.dist import wrap_ddp
             wrapped = wrap_ddp(model, device_ids=[local_rank])
+            if ddp1:
+                mode += "(1-rank rccl)"
         optimizer = build_optimizer(model, cfg.optimizer[0])
         ahead = None if (args.no_teacher_ahead or args.backbone == "gfl_r50") else model.teacher_ahead()
         if ahead is not None:
@@ -545,8 +559,8 @@ def main():
                "roofline": roofline, "mfma": mfma}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.seed, cfg.num_prev, batch=args.cpu_baseline_batch)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        print(json.dumps(out), file=json_out, flush=True)
+    if world > 1 or ddp1:
         dist.barrier()
         dist.destroy_process_group()
 
