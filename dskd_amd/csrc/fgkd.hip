@@ -48,6 +48,8 @@ struct FgLevels {
   int tiles[kMaxLevels];       // strips per row
   int blk_start[kMaxLevels + 1];  // first fgkd_kl block of the level
   long long own_start[kMaxLevels];  // first owner-map element of the level
+  int waves[kMaxLevels];          // fgkd_kl_reg: waves per (image, channel, strip) unit: 1, 2, 4 or 8
+  int rblk_start[kMaxLevels + 1]; // fgkd_kl_reg: first block of the level (8 / waves units per block)
 };
 
 constexpr int kMaxImages = 64;
@@ -305,6 +307,180 @@ __global__ __launch_bounds__(kStrip * kRowGroups) void fgkd_kl_kernel(
   }
 }
 
+// ---------------------------------------------------------------- fused KL + mask gradient, strips held in registers
+// exp(x) for x <= 0 (any finite x works): v_exp_f32 on the rounded product x * log2(e), the product's rounding error and
+// the low word of log2(e) applied to first order.  ~1 ulp, 7 instruction slots (the library's expf: ~25).
+__device__ __forceinline__ float exp_comp(float x) {
+  const float kL2eHi = 1.44269502162933349609375f, kL2eLo = 1.925963033500011e-8f, kLn2 = 0.693147182464599609375f;
+  const float t = x * kL2eHi;
+  float r = fmaf(x, kL2eHi, -t);
+  r = fmaf(x, kL2eLo, r);
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e, r * kLn2, e);
+}
+// expm1(d): Taylor polynomial to d^10 for |d| <= 0.5 (truncation < 4e-10 relative), the library's expm1f elsewhere.
+__device__ __forceinline__ float expm1_small(float d) {
+  float p = 2.7557319e-7f;             // 1/10!
+  p = fmaf(p, d, 2.7557319e-6f);       // 1/9!
+  p = fmaf(p, d, 2.4801587e-5f);       // 1/8!
+  p = fmaf(p, d, 1.9841270e-4f);       // 1/7!
+  p = fmaf(p, d, 1.3888889e-3f);       // 1/6!
+  p = fmaf(p, d, 8.3333333e-3f);       // 1/5!
+  p = fmaf(p, d, 4.1666667e-2f);       // 1/4!
+  p = fmaf(p, d, 1.6666667e-1f);       // 1/3!
+  p = fmaf(p, d, 0.5f);
+  float r = fmaf(d * d, p, d);
+  if (fabsf(d) > 0.5f) r = expm1f(d);
+  return r;
+}
+
+constexpr int kRegRows = 16;   // rows of a strip one lane holds; a unit of H <= 16 * 8 rows is split over 1, 2, 4 or 8 waves
+
+// One workgroup = 8 waves = 8 / G units, unit = (image, channel, 64-column strip) of one level, G waves per unit, each wave a
+// contiguous band of <= 16 rows: lane = column, the band's student / teacher / owner values sit in REGISTERS (all loads of
+// the band are issued before the first use: one HBM latency per workgroup instead of one per row), so the feature strips
+// are read from HBM once and never parked in LDS.  Three phases, two barriers: band maxima -> column maxima; the
+// exponentials ONCE per element against the column maxima (kept for the gradient) and the band sums -> column sums; the
+// gradient w.r.t. the mask per owner box.  Numerics as in fgkd_kl_kernel (the O(d) + O(d) -> O(d^2) form).
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void fgkd_kl_reg_kernel(FgLevels lv, FgImages im, int levels, int C, int D, float T,
+                                                          FgWs ws) {
+  __shared__ float s_x[6][8][kStrip];   // per wave and column: max a, max b, Za, S, Zb, U
+  extern __shared__ float s_dyn[];      // s_m[U][nb], s_g[U][nb]
+  int l = 0;
+  while (l + 1 < levels && (int)blockIdx.x >= lv.rblk_start[l + 1]) ++l;
+  const int H = lv.H[l], W = lv.W[l], tiles = lv.tiles[l];
+  const int G = lv.waves[l], U = 8 / G, CG = C / U;
+  int rel = blockIdx.x - lv.rblk_start[l];
+  const int tile = rel % tiles; rel /= tiles;
+  const int cg = rel % CG;
+  const int i = rel / CG;
+  const int col = threadIdx.x & (kStrip - 1), wave = threadIdx.x >> 6;
+  const int unit = wave / G, g = wave - unit * G;
+  const int c = cg * U + unit;
+  const int w = tile * kStrip + col;
+  const bool wv = w < W;
+  const int wc = wv ? w : W - 1;
+  const int R = (H + G - 1) / G;          // <= kRegRows (checked on the host)
+  const int h0 = g * R;
+  const int nrows = min(R, H - h0);       // may be <= 0 for a trailing wave
+
+  const size_t plane = ((size_t)i * C + c) * (size_t)H * W;
+  const float* fs = lv.fs[l] + plane;
+  const float* ft = lv.ft[l] + plane;
+  const short* own = ws.owner + lv.own_start[l] + (size_t)i * H * W;
+
+  // every load of the band up front, unconditional (clamped addresses): nothing waits on the newest one
+  float va[kRegRows], vb[kRegRows], vt[kRegRows];
+  int vo[kRegRows];
+#pragma unroll
+  for (int r = 0; r < kRegRows; ++r) {
+    const int h = min(h0 + r, H - 1);
+    const size_t e = (size_t)h * W + wc;
+    va[r] = __builtin_nontemporal_load(fs + e);
+    vt[r] = __builtin_nontemporal_load(ft + e);
+    vo[r] = own[e];
+  }
+
+  const int b0 = im.box_start[i], nb = im.box_start[i + 1] - b0;
+  float* s_m = s_dyn;
+  float* s_g = s_dyn + U * nb;
+  for (int j = threadIdx.x; j < U * nb; j += blockDim.x) {
+    const int u = j / nb, jj = j - u * nb;
+    s_m[j] = ws.m[(size_t)(b0 + jj) * D + cg * U + u];
+    s_g[j] = 0.f;
+  }
+  __syncthreads();
+
+  const float invT = 1.f / T;
+  const float* s_mu = s_m + unit * nb;
+  float A = -INFINITY, Bm = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < kRegRows; ++r) {
+    const int o = vo[r];
+    const float mk = o >= 0 ? s_mu[o] : 0.f;
+    const float a = (va[r] * mk) * invT;  // target logits: student * mask / T
+    const float b = (vt[r] * mk) * invT;  // pred logits:   teacher * mask / T
+    va[r] = a;
+    vb[r] = b;
+    if (r < nrows) {
+      A = fmaxf(A, a);
+      Bm = fmaxf(Bm, b);
+    }
+  }
+  s_x[0][wave][col] = A;
+  s_x[1][wave][col] = Bm;
+  __syncthreads();
+  A = s_x[0][unit * G][col];
+  Bm = s_x[1][unit * G][col];
+  for (int k = 1; k < G; ++k) {
+    A = fmaxf(A, s_x[0][unit * G + k][col]);
+    Bm = fmaxf(Bm, s_x[1][unit * G + k][col]);
+  }
+
+  float Za = 0.f, S = 0.f, Zb = 0.f, Uu = 0.f;
+#pragma unroll
+  for (int r = 0; r < kRegRows; ++r) {
+    float ea = 0.f, eb = 0.f;
+    if (r < nrows) {
+      const float d = va[r] - vb[r];
+      ea = exp_comp(va[r] - A);
+      eb = exp_comp(vb[r] - Bm);
+      Za += ea;
+      S = fmaf(ea, d, S);
+      Zb += eb;
+      Uu = fmaf(eb, expm1_small(d), Uu);
+    }
+    va[r] = ea;
+    vb[r] = eb;
+  }
+  s_x[2][wave][col] = Za;
+  s_x[3][wave][col] = S;
+  s_x[4][wave][col] = Zb;
+  s_x[5][wave][col] = Uu;
+  __syncthreads();
+  Za = s_x[2][unit * G][col]; S = s_x[3][unit * G][col]; Zb = s_x[4][unit * G][col]; Uu = s_x[5][unit * G][col];
+  for (int k = 1; k < G; ++k) {          // fixed order: every wave of the unit gets the same sums
+    Za += s_x[2][unit * G + k][col];
+    S += s_x[3][unit * G + k][col];
+    Zb += s_x[4][unit * G + k][col];
+    Uu += s_x[5][unit * G + k][col];
+  }
+
+  if (g == 0) {
+    // sum_h t_h (log t_h - log p_h) = sum_h t_h d_h - log1p(sum_h p_h expm1(d_h)), see fgkd_kl_kernel
+    float klcol = wv ? (S / Za - log1pf(Uu / Zb)) * (T * T / (float)H) : 0.f;
+    klcol = wave_sum(klcol);
+    if (col == 0) ws.partial[lv.blk_start[l] + ((size_t)i * C + c) * tiles + tile] = klcol;
+  }
+
+  // d loss / d mask[c] at (h, w) = (T/H) (p - t) * F_t, summed per owner over the band (runs of equal owners first)
+  if (wv && nb > 0) {
+    const float ca = T / (float)H / Za, cb = T / (float)H / Zb;
+    float* s_gu = s_g + unit * nb;
+    int cur = -1;
+    float acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < kRegRows; ++r) {
+      if (r < nrows) {
+        const int o = vo[r];
+        if (o != cur) {
+          if (cur >= 0 && acc != 0.f) atomicAdd(&s_gu[cur], acc);
+          cur = o;
+          acc = 0.f;
+        }
+        acc = fmaf(fmaf(vb[r], cb, -va[r] * ca), vt[r], acc);
+      }
+    }
+    if (cur >= 0 && acc != 0.f) atomicAdd(&s_gu[cur], acc);
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < U * nb; j += blockDim.x) {
+    const int u = j / nb, jj = j - u * nb;
+    const float gv = s_g[j];
+    if (gv != 0.f) atomicAdd(ws.gm + (size_t)(b0 + jj) * D + cg * U + u, gv);
+  }
+}
+
 // ---------------------------------------------------------------- finish
 // block 0: loss; blocks 1..: one wave per pair -> softmax / abs backward into grad_hs_s
 __global__ __launch_bounds__(256) void fgkd_finish_kernel(
@@ -350,12 +526,14 @@ struct FgPlan {
   long long nblocks;
   long long owner_elems;
   size_t lds_max;
+  long long rblocks;   // grid of fgkd_kl_reg_kernel; 0 = a level does not fit its registers (H > 128 or C % 8)
 };
 
 int make_plan(const float* const* fs, const float* const* ft, const int32_t* shapes, int levels,
               int B, int C, FgPlan* p) {
   if (levels < 1 || levels > kMaxLevels) return fail(DSKD_ERR_INVALID_ARG, "fgkd: levels=%d unsupported", levels);
-  long long blk = 0, own = 0;
+  long long blk = 0, own = 0, rblk = 0;
+  bool reg_ok = (C % 8) == 0;
   p->lds_max = 0;
   for (int l = 0; l < levels; ++l) {
     const int H = shapes[2 * l], W = shapes[2 * l + 1];
@@ -367,13 +545,23 @@ int make_plan(const float* const* fs, const float* const* ft, const int32_t* sha
     p->lv.tiles[l] = (W + kStrip - 1) / kStrip;
     p->lv.blk_start[l] = (int)blk;
     p->lv.own_start[l] = own;
+    int waves = 1;
+    while (waves < 8 && waves * kRegRows < H) waves *= 2;
+    if (waves * kRegRows < H) reg_ok = false;
+    p->lv.waves[l] = waves;
+    p->lv.rblk_start[l] = (int)rblk;
+    rblk += (long long)B * (C / (8 / waves)) * p->lv.tiles[l];
     blk += (long long)B * C * p->lv.tiles[l];
     own += (long long)B * H * W;
     const size_t lds = sizeof(float) * 2 * (size_t)H * kStrip + sizeof(short) * (((size_t)H * kStrip + 1) & ~(size_t)1);
     if (lds > p->lds_max) p->lds_max = lds;
   }
   p->lv.blk_start[levels] = (int)blk;
+  p->lv.rblk_start[levels] = (int)rblk;
+  p->rblocks = reg_ok ? rblk : 0;
   for (int l = levels; l < kMaxLevels; ++l) {
+    p->lv.waves[l] = 8;
+    if (l > levels) p->lv.rblk_start[l] = (int)rblk;
     p->lv.fs[l] = nullptr; p->lv.ft[l] = nullptr; p->lv.H[l] = 1; p->lv.W[l] = 1; p->lv.tiles[l] = 1;
     p->lv.own_start[l] = own;
     if (l > levels) p->lv.blk_start[l] = (int)blk;
@@ -424,9 +612,12 @@ extern "C" int dskd_fgkd_fwd(const float* const* feat_s, const float* const* fea
   }
   FgPlan plan;
   if (int rc = make_plan(feat_s, feat_t, shapes, levels, B, C, &plan)) return rc;
-  const size_t lds = plan.lds_max + sizeof(float) * 2 * (size_t)max_nb +
-                     sizeof(ColStat) * kRowGroups * kStrip + sizeof(float) * kRowGroups + 64;
-  if (lds > 160 * 1024)
+  // register-resident kernel whenever every level fits (H <= 128, C % 8 == 0), the LDS-strip kernel otherwise
+  const bool use_reg = plan.rblocks > 0;
+  const size_t lds = use_reg ? sizeof(float) * 2 * 8 * (size_t)max_nb
+                             : plan.lds_max + sizeof(float) * 2 * (size_t)max_nb +
+                                   sizeof(ColStat) * kRowGroups * kStrip + sizeof(float) * kRowGroups + 64;
+  if (lds + (use_reg ? sizeof(float) * 6 * 8 * kStrip : 0) > 160 * 1024)
     return fail(DSKD_ERR_INVALID_ARG, "dskd_fgkd_fwd: a level with H too large for the LDS strip (%zu B)", lds);
   hipStream_t st = (hipStream_t)stream;
   const FgWs ws = carve(workspace, M, D, plan.nblocks, nullptr);
@@ -450,12 +641,21 @@ extern "C" int dskd_fgkd_fwd(const float* const* feat_s, const float* const* fea
                        H, W, ws.owner + plan.lv.own_start[l]);
     if (int rc = check_launch("dskd_fgkd_fwd/owner")) return rc;
   }
-  if (lds > 48 * 1024 &&
-      hipFuncSetAttribute((const void*)fgkd_kl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)lds) != hipSuccess)
-    return fail(DSKD_ERR_LAUNCH, "dskd_fgkd_fwd: cannot reserve %zu B of LDS", lds);
-  hipLaunchKernelGGL(fgkd_kl_kernel, dim3((unsigned)plan.nblocks), dim3(kStrip * kRowGroups), lds, st,
-                     plan.lv, im, levels, C, D, T, ws);
+  if (use_reg) {
+    if (lds > 32 * 1024 &&
+        hipFuncSetAttribute((const void*)fgkd_kl_reg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return fail(DSKD_ERR_LAUNCH, "dskd_fgkd_fwd: cannot reserve %zu B of LDS", lds);
+    hipLaunchKernelGGL(fgkd_kl_reg_kernel, dim3((unsigned)plan.rblocks), dim3(512), lds, st, plan.lv, im, levels, C, D,
+                       T, ws);
+  } else {
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute((const void*)fgkd_kl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return fail(DSKD_ERR_LAUNCH, "dskd_fgkd_fwd: cannot reserve %zu B of LDS", lds);
+    hipLaunchKernelGGL(fgkd_kl_kernel, dim3((unsigned)plan.nblocks), dim3(kStrip * kRowGroups), lds, st,
+                       plan.lv, im, levels, C, D, T, ws);
+  }
   if (int rc = check_launch("dskd_fgkd_fwd/kl")) return rc;
   const float scale = loss_weight / (float)B;
   hipLaunchKernelGGL(fgkd_finish_kernel, dim3(1 + (M + 3) / 4), dim3(256), 0, st, hs_t, keepid_t, hs_s,

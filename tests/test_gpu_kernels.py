@@ -830,7 +830,9 @@ def _fg_inputs(B, shapes, seed, n_t, img_hw):
     return fs, ft, boxes, hs_s, hs_t, labels, keep, prev
 
 
-@pytest.mark.parametrize("B,shapes,n_t", [(1, [(13, 21), (7, 11)], 3), (2, [(25, 42), (13, 21), (7, 11), (4, 6)], 6)])
+@pytest.mark.parametrize("B,shapes,n_t", [(1, [(13, 21), (7, 11)], 3), (2, [(25, 42), (13, 21), (7, 11), (4, 6)], 6),
+                                          (1, [(100, 70), (50, 35), (33, 9), (17, 3)], 5),      # 8 / 4 / 4 / 2 waves per strip
+                                          (1, [(130, 5), (13, 21)], 3)])                       # H > 128: LDS-strip kernel
 def test_fgkd_vs_oracle(B, shapes, n_t):
     """The KL of two near-equal softmaxes is O(d^2) computed from O(log H) terms: the
     reference's own fp32 evaluation carries ~1% rounding noise at these magnitudes (asserted
