@@ -143,7 +143,28 @@ class Bottleneck(nn.Module):
         self.bn3 = _bn(planes * self.expansion, bn_requires_grad)
         self.downsample = downsample
 
+    input_is_relu = False       # set by ResNet: the block's input is the (ReLU) output of another Bottleneck
+
+    def _fused(self, x):
+        """The trainable block as ONE autograd node with the elementwise steps of its backward folded into the
+        input-gradient GEMMs (native.bottleneck); None when the block is not in that shape (frozen, host tensors, ...)."""
+        if not (_CONV1X1_MFMA and x.is_cuda and torch.is_grad_enabled()):
+            return None
+        convs = [self.conv1, self.conv2, self.conv3] + ([self.downsample[0]] if self.downsample is not None else [])
+        live = [c.__dict__.get("_folded_live") for c in convs]
+        if any(l is None for l in live):
+            return None
+        (w1, b1), (w2, b2), (w3, b3) = live[:3]
+        wd, bd = live[3] if self.downsample is not None else (None, None)
+        down = self.downsample[0] if self.downsample is not None else None
+        if not native.bottleneck_ok(x, w1, w2, w3, wd, self.conv1, self.conv2, self.conv3, down):
+            return None
+        return native.bottleneck(x, w1, b1, w2, b2, w3, b3, wd, bd, self.conv2.stride[0], self.input_is_relu)
+
     def forward(self, x):
+        out = self._fused(x)
+        if out is not None:
+            return out
         identity = x
         out = conv_bn(self.conv1, self.bn1, x, relu=True)
         out = conv_bn(self.conv2, self.bn2, out, relu=True)
@@ -218,6 +239,7 @@ class ResNet(nn.Module):
                     down = nn.Sequential(nn.Conv2d(inplanes, planes * block.expansion, 1, stride=stride, bias=False),
                                          _bn(planes * block.expansion, bn_rg))
                 layers.append(block(inplanes, planes, stride, dilations[i], down, style, bn_rg))
+                layers[-1].input_is_relu = not (i == 0 and j == 0)     # every block but the first follows a block's ReLU
                 inplanes = planes * block.expansion
             name = f"layer{i + 1}"
             self.add_module(name, nn.Sequential(*layers))

@@ -17,14 +17,17 @@
 //
 // MI355X mapping.  The reference materialises [B,C,H,W] masks and runs ~10 launches per box
 // and a KL chain per (level, image).  Here:
-//   fgkd_pairs   1 block: ordered compaction of the paired student rows + the M softmaxes
-//   fgkd_owner   owner map per pixel (int16), one thread per pixel
-//   fgkd_kl      one workgroup per (level, image, channel, 64-column strip): both feature
-//                strips are read from HBM exactly ONCE with coalesced 256-B row segments,
-//                parked in LDS (<= 51 KB at 100 rows), the per-column online-softmax
-//                statistics give the KL in the same sweep, and the second sweep (the
-//                gradient w.r.t. the mask, accumulated per owner box) runs out of LDS.
+//   fgkd_prep    one launch, roles by block range: owner map per pixel (int16, one thread per
+//                pixel); ordered compaction of the paired student rows + the M softmaxes (four
+//                pairs per block); zero fills of the two gradient buffers
+//   fgkd_kl_reg  (image, channel, 64-column strip) units, 1-8 waves each by level height: both
+//                feature strips are read from HBM exactly ONCE with coalesced 256-B row
+//                segments into REGISTERS (lane = column, <= 16 rows per lane), column softmax
+//                statistics through two small LDS exchanges, the gradient w.r.t. the mask
+//                accumulated per owner box from the same registers.
 //                HBM-bound: algorithmic bytes = 2 * sum(HW) * C * 4 per image (45.5 MB).
+//   fgkd_kl      the same per (level, image, channel, strip) with the strips parked in LDS and
+//                online-softmax statistics: levels higher than 128 rows
 //   fgkd_finish  softmax/abs backward into the dense grad_hs_s, fixed-order loss reduction
 #include "common.h"
 #include <vector>
@@ -81,78 +84,134 @@ FgWs carve(void* ws, int M, int D, long long nblocks, size_t* total) {
   return w;
 }
 
-// ---------------------------------------------------------------- pairs
-__global__ __launch_bounds__(256) void fgkd_pairs_kernel(
-    const float* __restrict__ hs_t, const int64_t* __restrict__ keepid_t,
-    const float* __restrict__ hs_s, const int64_t* __restrict__ labels_s,
-    const unsigned char* __restrict__ prev_mask, int N, int D, int NC, int M, FgWs ws,
-    int* __restrict__ status) {
+// ---------------------------------------------------------------- prep: owner maps + pairs + zero fills, ONE launch
+constexpr int kMaxQueries = 65536;      // N = B * queries (LDS hit bitmap of the compaction)
+
+struct FgPrep {
+  int oblk_start[kMaxLevels + 1];       // owner role: first block of the level (256 pixels of one image per block)
+  int oblk_per_img[kMaxLevels];
+  int pair_blk0, zero_blk0, nblk;       // role boundaries
+};
+
+// Role by block range.  [0, pair_blk0): owner map of 256 pixels (last covering box per pixel, int16).
+// [pair_blk0, zero_blk0): block k -> pairs 4k .. 4k+3: every such block repeats the ordered compaction of the student rows
+// whose label is a previous-task label (hit bitmap with all four waves -> exclusive offsets per 64-row chunk -> positions)
+// and keeps the four ids it needs; one wave per pair forms m_k = softmax_c |hs_t[keepid[k]] - hs_s[id_pred[k]]|.
+// [zero_blk0, nblk): zero fill of d loss / d m and of the dense grad_hs_s.
+__global__ __launch_bounds__(256) void fgkd_prep_kernel(
+    FgLevels lv, FgImages im, FgPrep pp, int levels, const float* __restrict__ boxes,
+    const float* __restrict__ hs_t, const int64_t* __restrict__ keepid_t, const float* __restrict__ hs_s,
+    const int64_t* __restrict__ labels_s, const unsigned char* __restrict__ prev_mask, int N, int D, int NC, int M,
+    FgWs ws, float* __restrict__ grad_hs, int* __restrict__ status) {
+  const int bid = blockIdx.x;
+  if (bid >= pp.zero_blk0) {
+    const size_t n_gm = (size_t)M * D / 4, n_gh = (size_t)N * D / 4;   // 16-byte units (D % 4 == 0)
+    const size_t stride = (size_t)(pp.nblk - pp.zero_blk0) * 256;
+    u32x4* gm4 = reinterpret_cast<u32x4*>(ws.gm);
+    u32x4* gh4 = reinterpret_cast<u32x4*>(grad_hs);
+    for (size_t k = (size_t)(bid - pp.zero_blk0) * 256 + threadIdx.x; k < n_gm + n_gh; k += stride) {
+      if (k < n_gm) gm4[k] = u32x4{0u, 0u, 0u, 0u};
+      else gh4[k - n_gm] = u32x4{0u, 0u, 0u, 0u};
+    }
+    return;
+  }
+  if (bid < pp.pair_blk0) {
+#pragma clang fp contract(off)
+    int l = 0;
+    while (l + 1 < levels && bid >= pp.oblk_start[l + 1]) ++l;
+    const int H = lv.H[l], W = lv.W[l];
+    const int rel = bid - pp.oblk_start[l];
+    const int i = rel / pp.oblk_per_img[l];
+    const int px = (rel - i * pp.oblk_per_img[l]) * 256 + threadIdx.x;
+    if (px >= H * W) return;
+    const int h = px / W, w = px - h * W;
+    const int b0 = im.box_start[i], b1 = im.box_start[i + 1];
+    const float ih = im.img_hw[2 * i], iw = im.img_hw[2 * i + 1];
+    int own = -1;
+    for (int j = b0; j < b1; ++j) {
+      const f32x4 bx = *reinterpret_cast<const f32x4*>(boxes + (size_t)j * 4);
+      // new = box / img * grid, floor / ceil, .int(); slices are [min, max) and clip at the edges
+      const int wmin = (int)floorf(bx.x / iw * (float)W);
+      const int wmax = (int)ceilf(bx.z / iw * (float)W);
+      const int hmin = (int)floorf(bx.y / ih * (float)H);
+      const int hmax = (int)ceilf(bx.w / ih * (float)H);
+      if (h >= hmin && h < hmax && w >= wmin && w < wmax) own = j - b0;  // later boxes overwrite
+    }
+    ws.owner[lv.own_start[l] + (size_t)i * H * W + px] = (short)own;
+    return;
+  }
+
+  // ---- pairs
+  __shared__ unsigned long long s_bits[kMaxQueries / 64];
+  __shared__ int s_off[kMaxQueries / 64];
+  __shared__ int s_ids[4];
   __shared__ int s_count;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k0 = (bid - pp.pair_blk0) * 4;
+  const int nchunk = (N + 63) >> 6;
+  for (int ch = wave; ch < nchunk; ch += 4) {
+    const int n = ch * 64 + lane;
+    bool hit = false;
+    if (n < N) {
+      const int64_t lab = labels_s[n];
+      hit = lab >= 0 && lab < NC && prev_mask[lab] != 0;
+    }
+    const unsigned long long mk = __ballot(hit);
+    if (lane == 0) s_bits[ch] = mk;
+  }
+  if (threadIdx.x < 4) s_ids[threadIdx.x] = 0;
+  __syncthreads();
   if (wave == 0) {
-    int cnt = 0;
-    for (int base = 0; base < N; base += 64) {
-      const int n = base + lane;
-      bool hit = false;
-      if (n < N) {
-        const int64_t lab = labels_s[n];
-        hit = lab >= 0 && lab < NC && prev_mask[lab] != 0;
+    int run = 0;
+    for (int base = 0; base < nchunk; base += 64) {
+      const int ch = base + lane;
+      const int cnt = ch < nchunk ? __popcll(s_bits[ch]) : 0;
+      int incl = cnt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
       }
-      const unsigned long long mk = __ballot(hit);
-      const int pos = cnt + __popcll(mk & ((1ull << lane) - 1ull));
-      if (hit && pos < M) ws.id_pred[pos] = n;
-      cnt += __popcll(mk);
+      if (ch < nchunk) s_off[ch] = run + incl - cnt;
+      run += __shfl(incl, 63);
     }
     if (lane == 0) {
-      s_count = cnt;
-      status[0] = cnt < M ? 1 : 0;
+      s_count = run;
+      if (bid == pp.pair_blk0) status[0] = run < M ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  for (int ch = wave; ch < nchunk; ch += 4) {
+    const unsigned long long mk = s_bits[ch];
+    if ((mk >> lane) & 1ull) {
+      const int pos = s_off[ch] + __popcll(mk & ((1ull << lane) - 1ull));
+      if (pos >= k0 && pos < k0 + 4 && pos < M) {
+        s_ids[pos - k0] = ch * 64 + lane;
+        ws.id_pred[pos] = ch * 64 + lane;
+      }
     }
   }
   __syncthreads();
   const int cnt = s_count;
-  for (int k = wave; k < M; k += 4) {
-    float* mk = ws.m + (size_t)k * D;
-    if (k >= cnt || (unsigned long long)keepid_t[k] >= (unsigned long long)N) {
-      // reference would raise IndexError; flagged through status (k >= cnt) / ignored (keepid outside [0, N): never
-      // read out of bounds)
-      for (int c = lane; c < D; c += 64) mk[c] = 0.f;
-      continue;
-    }
-    const float* t = hs_t + (size_t)keepid_t[k] * D;
-    const float* s = hs_s + (size_t)ws.id_pred[k] * D;
-    float mx = -INFINITY;
-    for (int c = lane; c < D; c += 64) mx = fmaxf(mx, fabsf(t[c] - s[c]));
+  const int k = k0 + wave;
+  if (k >= M) return;
+  float* mk = ws.m + (size_t)k * D;
+  if (k >= cnt || (unsigned long long)keepid_t[k] >= (unsigned long long)N) {
+    // reference would raise IndexError; flagged through status (k >= cnt) / ignored (keepid outside [0, N): never
+    // read out of bounds)
+    for (int c = lane; c < D; c += 64) mk[c] = 0.f;
+    return;
+  }
+  const float* t = hs_t + (size_t)keepid_t[k] * D;
+  const float* sr = hs_s + (size_t)s_ids[wave] * D;
+  float mx = -INFINITY;
+  for (int c = lane; c < D; c += 64) mx = fmaxf(mx, fabsf(t[c] - sr[c]));
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    float sum = 0.f;
-    for (int c = lane; c < D; c += 64) sum += expf(fabsf(t[c] - s[c]) - mx);
-    sum = wave_sum(sum);
-    for (int c = lane; c < D; c += 64) mk[c] = expf(fabsf(t[c] - s[c]) - mx) / sum;
-  }
-}
-
-// ---------------------------------------------------------------- owner map
-__global__ __launch_bounds__(256) void fgkd_owner_kernel(const float* __restrict__ boxes,
-                                                         FgImages im, int H, int W,
-                                                         short* __restrict__ owner) {
-#pragma clang fp contract(off)
-  const int i = blockIdx.y;
-  const int px = blockIdx.x * blockDim.x + threadIdx.x;
-  if (px >= H * W) return;
-  const int h = px / W, w = px - h * W;
-  const int b0 = im.box_start[i], b1 = im.box_start[i + 1];
-  const float ih = im.img_hw[2 * i], iw = im.img_hw[2 * i + 1];
-  int own = -1;
-  for (int j = b0; j < b1; ++j) {
-    const f32x4 bx = *reinterpret_cast<const f32x4*>(boxes + (size_t)j * 4);
-    // new = box / img * grid, floor / ceil, .int(); slices are [min, max) and clip at the edges
-    const int wmin = (int)floorf(bx.x / iw * (float)W);
-    const int wmax = (int)ceilf(bx.z / iw * (float)W);
-    const int hmin = (int)floorf(bx.y / ih * (float)H);
-    const int hmax = (int)ceilf(bx.w / ih * (float)H);
-    if (h >= hmin && h < hmax && w >= wmin && w < wmax) own = j - b0;  // later boxes overwrite
-  }
-  owner[(size_t)i * H * W + px] = (short)own;
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float sum = 0.f;
+  for (int c = lane; c < D; c += 64) sum += expf(fabsf(t[c] - sr[c]) - mx);
+  sum = wave_sum(sum);
+  for (int c = lane; c < D; c += 64) mk[c] = expf(fabsf(t[c] - sr[c]) - mx) / sum;
 }
 
 // ---------------------------------------------------------------- fused KL + mask gradient
@@ -354,7 +413,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int tile = rel % tiles; rel /= tiles;
   const int cg = rel % CG;
   const int i = rel / CG;
-  const int col = threadIdx.x & (kStrip - 1), wave = threadIdx.x >> 6;
+  const int col = threadIdx.x & (kStrip - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar
   const int unit = wave / G, g = wave - unit * G;
   const int c = cg * U + unit;
   const int w = tile * kStrip + col;
@@ -370,16 +429,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const short* own = ws.owner + lv.own_start[l] + (size_t)i * H * W;
 
   // every load of the band up front, unconditional (clamped addresses): nothing waits on the newest one
-  float va[kRegRows], vb[kRegRows], vt[kRegRows];
-  int vo[kRegRows];
+  float va[kRegRows], vt[kRegRows];       // student / teacher values, later t * F_t / p * F_t (unnormalised)
+  unsigned short vo16[kRegRows];
 #pragma unroll
   for (int r = 0; r < kRegRows; ++r) {
     const int h = min(h0 + r, H - 1);
-    const size_t e = (size_t)h * W + wc;
+    const unsigned e = (unsigned)(h * W + wc);   // < 2^31: the owner map of one image is indexed with int
     va[r] = __builtin_nontemporal_load(fs + e);
     vt[r] = __builtin_nontemporal_load(ft + e);
-    vo[r] = own[e];
+    vo16[r] = (unsigned short)own[e];
   }
+  unsigned vo2[(kRegRows + 1) / 2];        // owners of two rows per register
+#pragma unroll
+  for (int r = 0; r < kRegRows; r += 2)
+    vo2[r / 2] = (unsigned)vo16[r] | ((unsigned)vo16[r + 1 < kRegRows ? r + 1 : r] << 16);
+#define FG_OWNER(r) ((int)(short)(vo2[(r) >> 1] >> (((r) & 1) * 16)))
 
   const int b0 = im.box_start[i], nb = im.box_start[i + 1] - b0;
   float* s_m = s_dyn;
@@ -391,17 +455,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   }
   __syncthreads();
 
+  // logits: a = student * mask / T (target), b = teacher * mask / T (pred); outside every box the mask is 0
   const float invT = 1.f / T;
   const float* s_mu = s_m + unit * nb;
   float A = -INFINITY, Bm = -INFINITY;
+  unsigned owned = 0;                     // wave-uniform: rows of the band with at least one pixel inside a box
 #pragma unroll
   for (int r = 0; r < kRegRows; ++r) {
-    const int o = vo[r];
-    const float mk = o >= 0 ? s_mu[o] : 0.f;
-    const float a = (va[r] * mk) * invT;  // target logits: student * mask / T
-    const float b = (vt[r] * mk) * invT;  // pred logits:   teacher * mask / T
-    va[r] = a;
-    vb[r] = b;
+    const int o = FG_OWNER(r);
+    float a = 0.f, b = 0.f;
+    if (r < nrows && __builtin_amdgcn_ballot_w64(o >= 0) != 0ull) {
+      owned |= 1u << r;
+      const float mk = o >= 0 ? s_mu[o] : 0.f;
+      a = (va[r] * mk) * invT;
+      b = (vt[r] * mk) * invT;
+    }
     if (r < nrows) {
       A = fmaxf(A, a);
       Bm = fmaxf(Bm, b);
@@ -417,21 +485,48 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     Bm = fmaxf(Bm, s_x[1][unit * G + k][col]);
   }
 
+  // ea = exp(a - A), eb = exp(b - Bm) once per element (the logits are formed again rather than held).  Rows without a
+  // box: exp(-A) / exp(-Bm), d = 0.  Rows where every lane has |d| <= 1/8 (the usual case): expm1(d) as a short polynomial
+  // and ea = eb * exp(Bm - A) * (1 + expm1(d)) -- one v_exp per element; any other row takes the general forms.
+  const float eA0 = exp_comp(-A), eB0 = exp_comp(-Bm);
+  const bool kok = fabsf(Bm - A) < 32.f;
+  const float K = kok ? exp_comp(Bm - A) : 0.f;
   float Za = 0.f, S = 0.f, Zb = 0.f, Uu = 0.f;
 #pragma unroll
   for (int r = 0; r < kRegRows; ++r) {
-    float ea = 0.f, eb = 0.f;
     if (r < nrows) {
-      const float d = va[r] - vb[r];
-      ea = exp_comp(va[r] - A);
-      eb = exp_comp(vb[r] - Bm);
-      Za += ea;
-      S = fmaf(ea, d, S);
-      Zb += eb;
-      Uu = fmaf(eb, expm1_small(d), Uu);
+      if (!(owned & (1u << r))) {
+        Za += eA0;
+        Zb += eB0;
+      } else {
+        const int o = FG_OWNER(r);
+        const float mk = o >= 0 ? s_mu[o] : 0.f;
+        const float a = (va[r] * mk) * invT;
+        const float b = (vt[r] * mk) * invT;
+        const float d = a - b;
+        const float eb = exp_comp(b - Bm);
+        float em, ea;
+        if (__builtin_amdgcn_ballot_w64(!(fabsf(d) <= 0.125f) || !kok) == 0ull) {
+          float q = 1.3888889e-3f;         // 1/6!
+          q = fmaf(q, d, 8.3333333e-3f);   // 1/5!
+          q = fmaf(q, d, 4.1666667e-2f);   // 1/4!
+          q = fmaf(q, d, 1.6666667e-1f);   // 1/3!
+          q = fmaf(q, d, 0.5f);
+          em = fmaf(d * d, q, d);          // truncation < 1e-9 relative for |d| <= 1/8
+          const float ek = eb * K;
+          ea = fmaf(ek, em, ek);
+        } else {
+          em = expm1_small(d);
+          ea = exp_comp(a - A);
+        }
+        Za += ea;
+        S = fmaf(ea, d, S);
+        Zb += eb;
+        Uu = fmaf(eb, em, Uu);
+        va[r] = ea * vt[r];                // the gradient needs t * F_t and p * F_t only
+        vt[r] = eb * vt[r];
+      }
     }
-    va[r] = ea;
-    vb[r] = eb;
   }
   s_x[2][wave][col] = Za;
   s_x[3][wave][col] = S;
@@ -461,14 +556,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     float acc = 0.f;
 #pragma unroll
     for (int r = 0; r < kRegRows; ++r) {
-      if (r < nrows) {
-        const int o = vo[r];
+      if (owned & (1u << r)) {
+        const int o = FG_OWNER(r);
         if (o != cur) {
           if (cur >= 0 && acc != 0.f) atomicAdd(&s_gu[cur], acc);
           cur = o;
           acc = 0.f;
         }
-        acc = fmaf(fmaf(vb[r], cb, -va[r] * ca), vt[r], acc);
+        acc = fmaf(vt[r], cb, fmaf(-va[r], ca, acc));
       }
     }
     if (cur >= 0 && acc != 0.f) atomicAdd(&s_gu[cur], acc);
@@ -479,6 +574,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const float gv = s_g[j];
     if (gv != 0.f) atomicAdd(ws.gm + (size_t)(b0 + jj) * D + cg * U + u, gv);
   }
+#undef FG_OWNER
 }
 
 // ---------------------------------------------------------------- finish
@@ -629,18 +725,23 @@ extern "C" int dskd_fgkd_fwd(const float* const* feat_s, const float* const* fea
 
   if ((reinterpret_cast<uintptr_t>(grad_hs_s) & 15) || (D & 3))
     return fail(DSKD_ERR_INVALID_ARG, "dskd_fgkd_fwd: grad_hs_s must be 16-byte aligned and D a multiple of 4");
-  zero_fill(ws.gm, sizeof(float) * (size_t)M * D, st);          // kernels, not hipMemsetAsync (see common.h)
-  zero_fill(grad_hs_s, sizeof(float) * (size_t)N * D, st);
-
-  hipLaunchKernelGGL(fgkd_pairs_kernel, dim3(1), dim3(256), 0, st, hs_t, keepid_t, hs_s, labels_s,
-                     prev_mask, N, D, NC, M, ws, status);
-  if (int rc = check_launch("dskd_fgkd_fwd/pairs")) return rc;
-  for (int l = 0; l < levels; ++l) {
-    const int H = plan.lv.H[l], W = plan.lv.W[l];
-    hipLaunchKernelGGL(fgkd_owner_kernel, dim3((H * W + 255) / 256, B), dim3(256), 0, st, boxes, im,
-                       H, W, ws.owner + plan.lv.own_start[l]);
-    if (int rc = check_launch("dskd_fgkd_fwd/owner")) return rc;
+  if (N > kMaxQueries) return fail(DSKD_ERR_INVALID_ARG, "dskd_fgkd_fwd: N=%d exceeds %d query rows per call", N, kMaxQueries);
+  FgPrep pp;
+  int ob = 0;
+  for (int l = 0; l < kMaxLevels; ++l) {
+    pp.oblk_start[l] = ob;
+    pp.oblk_per_img[l] = l < levels ? (plan.lv.H[l] * plan.lv.W[l] + 255) / 256 : 1;
+    if (l < levels) ob += pp.oblk_per_img[l] * B;
   }
+  pp.oblk_start[kMaxLevels] = ob;
+  pp.pair_blk0 = ob;
+  pp.zero_blk0 = ob + (M > 0 ? (M + 3) / 4 : 1);   // at least one pairs block: it writes status
+  const size_t z16 = ((size_t)M * D + (size_t)N * D) / 4;
+  pp.nblk = pp.zero_blk0 + (int)((z16 + 255) / 256 < 256 ? (z16 + 255) / 256 : 256);
+  // owner maps, pairs and the zero fills (kernels, not hipMemsetAsync: see common.h) in one launch
+  hipLaunchKernelGGL(fgkd_prep_kernel, dim3(pp.nblk), dim3(256), 0, st, plan.lv, im, pp, levels, boxes, hs_t, keepid_t,
+                     hs_s, labels_s, prev_mask, N, D, NC, M, ws, grad_hs_s, status);
+  if (int rc = check_launch("dskd_fgkd_fwd/prep")) return rc;
   if (use_reg) {
     if (lds > 32 * 1024 &&
         hipFuncSetAttribute((const void*)fgkd_kl_reg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

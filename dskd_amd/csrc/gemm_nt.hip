@@ -44,6 +44,7 @@ struct GemmArgs {
   const __bf16* w;       // [N, K]
   const __bf16* bias;    // [N] or null
   const __bf16* res;     // [M, N] or null: added before the activation
+  const __bf16* gate;    // [M, N] or null: outputs where gate <= 0 are zeroed (the ReLU mask of a backward pass)
   __bf16* y;             // [M, N]
   long long M;
   int N, K, relu;
@@ -128,6 +129,15 @@ __device__ __forceinline__ void store_tile(const GemmArgs& a, const f32x16 (&acc
         const bf16x8 r0 = *reinterpret_cast<const bf16x8*>(rp), r1 = *reinterpret_cast<const bf16x8*>(rp + 8);
 #pragma unroll
         for (int i = 0; i < 8; ++i) { v[i] += (float)r0[i]; v[8 + i] += (float)r1[i]; }
+      }
+      if (a.gate) {
+        const __bf16* gp = a.gate + m * a.N + n;
+        const bf16x8 g0 = *reinterpret_cast<const bf16x8*>(gp), g1 = *reinterpret_cast<const bf16x8*>(gp + 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          v[i] = (float)g0[i] > 0.f ? v[i] : 0.f;
+          v[8 + i] = (float)g1[i] > 0.f ? v[8 + i] : 0.f;
+        }
       }
       bf16x8 o0, o1;
 #pragma unroll
@@ -487,14 +497,15 @@ __global__ __launch_bounds__(256) void cvt_clear_kernel(float* __restrict__ src,
 
 using namespace dskd;
 
-extern "C" int dskd_gemm_nt(const void* x, const void* w, const void* bias, const void* res, void* y, int64_t M, int N, int K,
-                            int relu, int stride, int Ho, int Wo, int Hi, int Wi, int dtype, void* stream) {
+static int gemm_nt_impl(const void* x, const void* w, const void* bias, const void* res, const void* gate, void* y,
+                        int64_t M, int N, int K, int relu, int stride, int Ho, int Wo, int Hi, int Wi, int dtype,
+                        void* stream) {
   if (dtype != DSKD_DTYPE_BF16) return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_nt: bf16 only");
   if (!x || !w || !y || M < 0) return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_nt: null pointer or negative row count");
   if (N <= 0 || K <= 0 || (N & 63) || (K & 63))
     return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_nt: N and K must be positive multiples of 64 (got N=%d K=%d)", N, K);
   auto mis = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
-  if (mis(x) || mis(w) || mis(y) || (bias && mis(bias)) || (res && mis(res)))
+  if (mis(x) || mis(w) || mis(y) || (bias && mis(bias)) || (res && mis(res)) || (gate && mis(gate)))
     return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_nt: pointers must be 16-byte aligned");
   if (stride < 0 || (stride > 0 && (Ho <= 0 || Wo <= 0 || Hi <= 0 || Wi <= 0 || M % ((int64_t)Ho * Wo) != 0 ||
                                     (int64_t)stride * (Ho - 1) >= Hi || (int64_t)stride * (Wo - 1) >= Wi)))
@@ -502,6 +513,7 @@ extern "C" int dskd_gemm_nt(const void* x, const void* w, const void* bias, cons
   if (M == 0) return DSKD_OK;
   GemmArgs a;
   a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = (const __bf16*)bias; a.res = (const __bf16*)res;
+  a.gate = (const __bf16*)gate;
   a.y = (__bf16*)y; a.M = M; a.N = N; a.K = K; a.relu = relu;
   a.s = stride; a.HoWo = stride ? Ho * Wo : 1; a.Wo = stride ? Wo : 1; a.Hi = Hi; a.Wi = Wi;
   hipStream_t st = (hipStream_t)stream;
@@ -513,8 +525,18 @@ extern "C" int dskd_gemm_nt(const void* x, const void* w, const void* bias, cons
   return launch_gemm<128, 1, false>(a, st);
 }
 
-extern "C" int dskd_conv3x3(const void* x, const void* w, const void* bias, const void* res, void* y, int B, int Hi, int Wi,
-                            int C, int N, int stride, int relu, int dtype, void* stream) {
+extern "C" int dskd_gemm_nt(const void* x, const void* w, const void* bias, const void* res, void* y, int64_t M, int N, int K,
+                            int relu, int stride, int Ho, int Wo, int Hi, int Wi, int dtype, void* stream) {
+  return gemm_nt_impl(x, w, bias, res, nullptr, y, M, N, K, relu, stride, Ho, Wo, Hi, Wi, dtype, stream);
+}
+
+extern "C" int dskd_gemm_nt_dx(const void* g, const void* wt, const void* res, const void* gate, void* y, int64_t M, int N,
+                               int K, int dtype, void* stream) {
+  return gemm_nt_impl(g, wt, nullptr, res, gate, y, M, N, K, 0, 0, 0, 0, 0, 0, dtype, stream);
+}
+
+static int conv3x3_impl(const void* x, const void* w, const void* bias, const void* res, const void* gate, void* y, int B,
+                        int Hi, int Wi, int C, int N, int stride, int relu, int dtype, void* stream) {
   if (dtype != DSKD_DTYPE_BF16) return fail(DSKD_ERR_INVALID_ARG, "dskd_conv3x3: bf16 only");
   if (!x || !w || !y || B < 0 || Hi <= 0 || Wi <= 0) return fail(DSKD_ERR_INVALID_ARG, "dskd_conv3x3: null pointer or bad size");
   int cshift = 0;
@@ -523,18 +545,29 @@ extern "C" int dskd_conv3x3(const void* x, const void* w, const void* bias, cons
     return fail(DSKD_ERR_INVALID_ARG, "dskd_conv3x3: C must be 64 * 2^k (<= 1024) and N a multiple of 64 (got C=%d N=%d)", C, N);
   if (stride != 1 && stride != 2) return fail(DSKD_ERR_INVALID_ARG, "dskd_conv3x3: stride 1 or 2 (got %d)", stride);
   auto mis = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
-  if (mis(x) || mis(w) || mis(y) || (bias && mis(bias)) || (res && mis(res)))
+  if (mis(x) || mis(w) || mis(y) || (bias && mis(bias)) || (res && mis(res)) || (gate && mis(gate)))
     return fail(DSKD_ERR_INVALID_ARG, "dskd_conv3x3: pointers must be 16-byte aligned");
   const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;        // kernel 3, padding 1
   if ((long long)Hi * Wi * C * 2 >= 0x7FFFFFFFll) return fail(DSKD_ERR_INVALID_ARG, "dskd_conv3x3: image too large");
   if (B == 0) return DSKD_OK;
   GemmArgs a;
   a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = (const __bf16*)bias; a.res = (const __bf16*)res;
+  a.gate = (const __bf16*)gate;
   a.y = (__bf16*)y; a.M = (long long)B * Ho * Wo; a.N = N; a.K = 9 * C; a.relu = relu;
   a.s = stride; a.HoWo = Ho * Wo; a.Wo = Wo; a.Hi = Hi; a.Wi = Wi; a.C = C; a.cshift = cshift;
   hipStream_t st = (hipStream_t)stream;
   if (N % 128) return launch_gemm<64, 1, true>(a, st);
   return launch_gemm<128, 1, true>(a, st);
+}
+
+extern "C" int dskd_conv3x3(const void* x, const void* w, const void* bias, const void* res, void* y, int B, int Hi, int Wi,
+                            int C, int N, int stride, int relu, int dtype, void* stream) {
+  return conv3x3_impl(x, w, bias, res, nullptr, y, B, Hi, Wi, C, N, stride, relu, dtype, stream);
+}
+
+extern "C" int dskd_conv3x3_dx(const void* g, const void* wt, const void* gate, void* y, int B, int Hi, int Wi, int C, int N,
+                               int dtype, void* stream) {
+  return conv3x3_impl(g, wt, nullptr, nullptr, gate, y, B, Hi, Wi, C, N, 1, 0, dtype, stream);
 }
 
 extern "C" int dskd_gemm_tn(const void* g, const void* x, float* c, int64_t M, int N, int K, int ldg, int ldx, int dtype,

@@ -52,6 +52,8 @@ _SIGNATURES = {
     "dskd_lin256_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_gemm_nt": (C.c_int, [_vp] * 5 + [_i64] + [C.c_int] * 9 + [_vp]),
     "dskd_conv3x3": (C.c_int, [_vp] * 5 + [C.c_int] * 8 + [_vp]),
+    "dskd_gemm_nt_dx": (C.c_int, [_vp] * 5 + [_i64] + [C.c_int] * 3 + [_vp]),
+    "dskd_conv3x3_dx": (C.c_int, [_vp] * 4 + [C.c_int] * 6 + [_vp]),
     "dskd_gemm_tn": (C.c_int, [_vp] * 3 + [_i64] + [C.c_int] * 5 + [_vp]),
     "dskd_cvt_clear": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp]),
     "dskd_winattn_fwd": (C.c_int, [_vp] * 4 + [C.c_int] * 5 + [_f32, C.c_int, _vp]),
@@ -927,6 +929,161 @@ def conv3x3(x, w, bias=None, identity=None, relu=False, stride=1):
     if identity is not None and (identity.dtype != x.dtype or not identity.is_contiguous(memory_format=torch.channels_last)):
         identity = identity.to(x.dtype).contiguous(memory_format=torch.channels_last)
     return _Conv3x3Function.apply(x, w, bias, identity, bool(relu), int(stride))
+
+
+# --------------------------------------------------------------------------- a whole Bottleneck, backward fused
+def gemm_nt_dx_raw(g, wt2d, res, gate, M, N, K, out):
+    """``out[M, N] = (gate > 0) ? g[M, K] wt2d[N, K]^T + res : 0`` -- raw launch of dskd_gemm_nt_dx (bf16, no autograd)."""
+    rc = load().dskd_gemm_nt_dx(g.data_ptr(), wt2d.data_ptr(), None if res is None else res.data_ptr(),
+                                None if gate is None else gate.data_ptr(), out.data_ptr(), M, N, K, DTYPE_BF16, _stream(g))
+    _check(rc, "dskd_gemm_nt_dx")
+    global _ffn_flops
+    _ffn_flops += 2 * M * N * K
+    return out
+
+
+def conv3x3_dx_raw(g, wt, gate):
+    """``(gate > 0) ? conv3x3(g, wt, stride 1, padding 1) : 0`` -- raw launch of dskd_conv3x3_dx; wt [C_out_of_dx, C_in_of_dx,
+    3, 3] channels_last = the forward weight with the taps flipped and the channel roles swapped."""
+    B, Cin, H, W = g.shape
+    N = wt.shape[0]
+    out = torch.empty((B, N, H, W), dtype=g.dtype, device=g.device, memory_format=torch.channels_last)
+    rc = load().dskd_conv3x3_dx(g.data_ptr(), wt.data_ptr(), None if gate is None else gate.data_ptr(), out.data_ptr(),
+                                B, H, W, Cin, N, DTYPE_BF16, _stream(g))
+    _check(rc, "dskd_conv3x3_dx")
+    global _ffn_flops
+    _ffn_flops += 2 * B * H * W * N * 9 * Cin
+    return out
+
+
+def _rows(t):          # [B, C, H, W] channels_last -> its NHWC rows [B*H*W, C] (a view)
+    return t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])
+
+
+def _dw1x1(g, x, w, stride):
+    """Weight gradient of a 1x1 convolution y = conv(x, w, stride) from g = dL/dy."""
+    N, K = w.shape[0], w.shape[1]
+    g2, x2 = _rows(g), _rows(x)
+    if stride == 1 and gemm_tn_ok(g2, x2):
+        gw = (gemm_tn_bf16(g2, x2) if w.dtype == torch.bfloat16 else gemm_tn(g2, x2).to(w.dtype)).view(N, K, 1, 1)
+        return gw.as_strided(w.shape, w.stride()) if w.stride() != gw.stride() else gw
+    return torch.ops.aten.convolution_backward(g, x, w, None, [stride] * 2, [0, 0], [1, 1], False, [0, 0], 1,
+                                               [False, True, False])[1]
+
+
+class _BottleneckFunction(torch.autograd.Function):
+    """conv1 (1x1) -> relu -> conv2 (3x3, stride s) -> relu -> conv3 (1x1) + identity -> relu of a ResNet Bottleneck with the
+    BatchNorms folded (mmdet/models/backbones/resnet.py:271-303), forward on the kernels of conv1x1 / conv3x3 and the
+    backward written out so that what autograd would run as separate passes over the activations rides in the epilogue of
+    the input-gradient GEMMs: the ReLU masks (``threshold_backward`` of y1, y2 and -- for a block fed by another block --
+    of the block input) and the sum of the identity path's gradient with conv1's.  The returned input gradient is then
+    already masked by ``x > 0``; it is tagged with the pointer of ``x`` so that the producing block (whose output IS x)
+    skips its own mask -- masking twice is the same as once, so a lost tag costs a pass, never correctness."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, wd, bd, stride, dstride, x_is_relu):
+        B, Cin, H, W = x.shape
+        P, N = w1.shape[0], w3.shape[0]
+        y1 = torch.empty((B, P, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        gemm_nt_raw(x, w1, b1, None, B * H * W, P, Cin, True, y1)
+        y2 = conv3x3_raw(y1, w2, b2, None, True, stride)
+        Ho, Wo = y2.shape[2], y2.shape[3]
+        if wd is not None:
+            idn = torch.empty((B, N, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            gemm_nt_raw(x, wd, bd, None, B * Ho * Wo, N, Cin, False, idn,
+                        *((0, 0, 0, 0, 0) if dstride == 1 else (dstride, Ho, Wo, H, W)))
+        else:
+            idn = x
+        y = torch.empty((B, N, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        gemm_nt_raw(y2, w3, b3, idn, B * Ho * Wo, N, P, True, y)
+        ctx.stride, ctx.dstride, ctx.x_is_relu, ctx.has_down = stride, dstride, x_is_relu, wd is not None
+        ctx.save_for_backward(x, y1, y2, y, w1, w2, w3, wd)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y1, y2, y, w1, w2, w3, wd = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        tag = getattr(g, "_dskd_relu_masked", None)
+        if not g.is_contiguous(memory_format=torch.channels_last):
+            g = g.contiguous(memory_format=torch.channels_last)
+        g3 = g if tag == y.data_ptr() else torch.ops.aten.threshold_backward(g, y, 0)
+        B, Cin, H, W = x.shape
+        P, N = w1.shape[0], w3.shape[0]
+        Ho, Wo = y.shape[2], y.shape[3]
+        s, ds = ctx.stride, ctx.dstride
+        gw1 = gw2 = gw3 = gwd = gb1 = gb2 = gb3 = gbd = gx = None
+        # conv3: dW3 = g3^T y2; dY2 = (g3 W3) masked by y2 > 0
+        if need[5]:
+            gw3 = _dw1x1(g3, y2, w3, 1)
+        if need[6]:
+            gb3 = g3.sum((0, 2, 3))
+        g2 = torch.empty_like(y2)
+        gemm_nt_dx_raw(g3, w3.reshape(N, P).t().contiguous(), None, y2, B * Ho * Wo, P, N, g2)
+        # conv2: dW2 from the library; dY1 = conv3x3(g2, W2') masked by y1 > 0 (stride 1), the library's data gradient else
+        if need[3]:
+            gw2 = torch.ops.aten.convolution_backward(g2, y1, w2, None, [s] * 2, [1, 1], [1, 1], False, [0, 0], 1,
+                                                      [False, True, False])[1]
+        if need[4]:
+            gb2 = g2.sum((0, 2, 3))
+        if s == 1 and P in (64, 128, 256, 512, 1024):
+            g1 = conv3x3_dx_raw(g2, w2.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last), y1)
+        else:
+            g1 = torch.ops.aten.convolution_backward(g2, y1, w2, None, [s] * 2, [1, 1], [1, 1], False, [0, 0], 1,
+                                                     [True, False, False])[0]
+            g1 = torch.ops.aten.threshold_backward(g1, y1, 0)
+        if need[1]:
+            gw1 = _dw1x1(g1, x, w1, 1)
+        if need[2]:
+            gb1 = g1.sum((0, 2, 3))
+        # the identity path: g3 itself, or through the downsample convolution
+        gid = g3
+        if ctx.has_down:
+            if need[7]:
+                gwd = _dw1x1(g3, x, wd, ds)
+            if need[8]:
+                gbd = g3.sum((0, 2, 3))
+            if need[0]:
+                if ds == 1:
+                    gid = torch.empty_like(x)
+                    gemm_nt_dx_raw(g3, wd.reshape(N, Cin).t().contiguous(), None, None, B * H * W, Cin, N, gid)
+                else:
+                    gid = torch.ops.aten.convolution_backward(g3, x, wd, None, [ds] * 2, [0, 0], [1, 1], False, [0, 0], 1,
+                                                              [True, False, False])[0]
+                    if not gid.is_contiguous(memory_format=torch.channels_last):
+                        gid = gid.contiguous(memory_format=torch.channels_last)
+        # conv1: dX = (g1 W1 + identity gradient) masked by x > 0 when x is a ReLU output whose producer masks anyway
+        if need[0]:
+            gx = torch.empty_like(x)
+            gemm_nt_dx_raw(g1, w1.reshape(P, Cin).t().contiguous(), gid, x if ctx.x_is_relu else None, B * H * W, Cin, P, gx)
+            if ctx.x_is_relu:
+                gx._dskd_relu_masked = x.data_ptr()
+        return gx, gw1, gb1, gw2, gb2, gw3, gb3, gwd, gbd, None, None, None
+
+
+def bottleneck_ok(x, w1, w2, w3, wd, conv1, conv2, conv3, down) -> bool:
+    """Can the fused Bottleneck take this block: every convolution one that conv1x1_ok / conv3x3_ok accept, conv1 and conv3
+    of stride 1 (the 'pytorch' style: the stride sits on conv2), channel counts the input-gradient launches can take?"""
+    if not (conv1x1_ok(x, w1, conv1) and conv1.stride == (1, 1) and conv3.stride == (1, 1) and conv3.kernel_size == (1, 1)
+            and w3.dtype == torch.bfloat16 and w1.shape[0] % 64 == 0 and w3.shape[0] % 64 == 0
+            and w3.shape[1] == w1.shape[0] and w2.shape[0] == w2.shape[1] == w1.shape[0]
+            and w1.shape[0] in (64, 128, 256, 512, 1024) and w2.dtype == torch.bfloat16
+            and conv2.kernel_size == (3, 3) and conv2.stride in ((1, 1), (2, 2)) and conv2.padding == (1, 1)
+            and conv2.dilation == (1, 1) and conv2.groups == 1 and w2.is_contiguous(memory_format=torch.channels_last)
+            and w2.data_ptr() % 16 == 0 and w3.data_ptr() % 16 == 0 and (w3.stride(1) == 1 or w3.is_contiguous())
+            and w3.stride(0) == w3.shape[1] and x.shape[2] * x.shape[3] * w1.shape[0] * 2 < 2 ** 31 - 1):
+        return False
+    if down is None:
+        return conv2.stride == (1, 1) and w3.shape[0] == x.shape[1]
+    return conv1x1_ok(x, wd, down) and down.stride == conv2.stride and wd.shape[0] == w3.shape[0]
+
+
+def bottleneck(x, w1, b1, w2, b2, w3, b3, wd=None, bd=None, stride=1, x_is_relu=False):
+    """One Bottleneck (folded BatchNorms) as ONE autograd node: see :class:`_BottleneckFunction`."""
+    def bf(b):
+        return b if b is None or (b.dtype == torch.bfloat16 and b.is_contiguous()) else b.to(torch.bfloat16).contiguous()
+    return _BottleneckFunction.apply(x, w1, bf(b1), w2, bf(b2), w3, bf(b3), wd, bf(bd), int(stride), int(stride),
+                                     bool(x_is_relu))
 
 
 # --------------------------------------------------------------------------- Swin window attention (MFMA kernels)

@@ -423,6 +423,20 @@ int dskd_conv3x3(const void* x, const void* w, const void* bias, const void* res
                  int stride, int relu, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * Input gradients of the two convolutions above with the neighbouring elementwise steps of a Bottleneck's backward
+ * (mmdet/models/backbones/resnet.py:271-303 run backwards by autograd: relu -> threshold_backward, `out += identity`
+ * -> a gradient add) folded into the epilogue:
+ *   dskd_gemm_nt_dx   y[M, N] = (gate > 0) ? g[M, K] wt[N, K]^T + res : 0      (1x1 convolution / Linear, stride 1)
+ *   dskd_conv3x3_dx   y       = (gate > 0) ? conv3x3(g, wt, stride 1, padding 1) : 0   (wt: taps flipped, roles swapped)
+ * gate = the ReLU OUTPUT that fed the convolution (its own input x, shape of y) or NULL; res = the gradient arriving over
+ * the identity path (shape of y) or NULL.  bf16, same alignment / size rules as the forward entry points.
+ * ------------------------------------------------------------------------- */
+int dskd_gemm_nt_dx(const void* g, const void* wt, const void* res, const void* gate, void* y, int64_t M, int N, int K,
+                    int dtype, void* stream);
+int dskd_conv3x3_dx(const void* g, const void* wt, const void* gate, void* y, int B, int Hi, int Wi, int C, int N, int dtype,
+                    void* stream);
+
+/* ---------------------------------------------------------------------------
  * c[N, K] += g[M, N]^T x[M, K]  (bf16 in, f32 out; N, K multiples of 128): the weight gradient dW = dY^T X of an
  * nn.Linear / 1x1 convolution over M tokens -- what autograd's mm / convolution_backward compute for the transformer's
  * Linear layers (ext-mmcv FFN, MultiScaleDeformableAttention projections) and the Bottleneck's 1x1 convolutions

@@ -1326,6 +1326,91 @@ def test_conv3x3_mfma_vs_float_reference(B, C, N, H, W, stride, relu):
     assert bool((guard == 5.0).all())
 
 
+@pytest.mark.parametrize("Cin,P,H,W,stride,down", [(512, 128, 20, 27, 1, False), (256, 128, 21, 30, 2, True),
+                                                   (1024, 256, 9, 14, 1, False)])
+def test_fused_bottleneck_chain_vs_float_reference(Cin, P, H, W, stride, down):
+    """native.bottleneck (one autograd node per Bottleneck; ReLU masks and the identity-path gradient add folded into the
+    input-gradient GEMMs: dskd_gemm_nt_dx / dskd_conv3x3_dx) on a chain of TWO blocks -- the second one hands the first a
+    gradient that is already masked and tagged -- against the same chain in fp32 on the CPU (F.conv2d + autograd) from the
+    same bf16-rounded inputs: output, input gradient and every weight gradient.  Reference:
+    mmdet/models/backbones/resnet.py:271-303 (BatchNorms folded into weight + bias)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(Cin + P + H)
+    B, N = 2, 4 * P
+
+    def mk(co, ci, k):
+        return (torch.randn(co, ci, k, k, generator=g) * (2.0 / (ci * k * k)) ** 0.5).bfloat16()
+
+    x = torch.randn(B, Cin, H, W, generator=g).relu().bfloat16()
+    blocks = [dict(w1=mk(P, Cin, 1), w2=mk(P, P, 3), w3=mk(N, P, 1), wd=mk(N, Cin, 1) if down else None, s=stride),
+              dict(w1=mk(P, N, 1), w2=mk(P, P, 3), w3=mk(N, P, 1), wd=None, s=1)]
+    if not down:
+        assert Cin == N
+    for blk in blocks:
+        for k in ("b1", "b2", "b3", "bd"):
+            co = P if k in ("b1", "b2") else N
+            blk[k] = (torch.randn(co, generator=g) * 0.1).bfloat16()
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    up = torch.randn(B, N, Ho, Wo, generator=g).bfloat16()
+
+    # fp32 reference
+    xr = x.float().requires_grad_(True)
+    leaves, h = [xr], xr
+    for blk in blocks:
+        ws = {k: blk[k].float().requires_grad_(True) for k in ("w1", "w2", "w3", "wd") if blk[k] is not None}
+        leaves += [ws[k] for k in ("w1", "w2", "w3", "wd") if k in ws]
+        o = F.relu(F.conv2d(h, ws["w1"], blk["b1"].float()))
+        o = F.relu(F.conv2d(o, ws["w2"], blk["b2"].float(), stride=blk["s"], padding=1))
+        idn = F.conv2d(h, ws["wd"], blk["bd"].float(), stride=blk["s"]) if "wd" in ws else h
+        h = F.relu(F.conv2d(o, ws["w3"], blk["b3"].float()) + idn)
+    gr = torch.autograd.grad(h, leaves, up.float())
+
+    def dev_w(w):
+        return w.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+
+    def run(fused):
+        xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        leaves_d, hd = [xd], xd
+        for bi, blk in enumerate(blocks):
+            ws = {k: dev_w(blk[k]) for k in ("w1", "w2", "w3", "wd") if blk[k] is not None}
+            leaves_d += [ws[k] for k in ("w1", "w2", "w3", "wd") if k in ws]
+            bs = {k: blk[k].to(DEV) for k in ("b1", "b2", "b3", "bd")}
+            if fused:
+                hd = native.bottleneck(hd, ws["w1"], bs["b1"], ws["w2"], bs["b2"], ws["w3"], bs["b3"], ws.get("wd"),
+                                       bs["bd"] if "wd" in ws else None, blk["s"], x_is_relu=True)
+            else:
+                o = native.conv1x1(hd, ws["w1"], bs["b1"], None, True, 1)
+                o = native.conv3x3(o, ws["w2"], bs["b2"], None, True, blk["s"])
+                idn = native.conv1x1(hd, ws["wd"], bs["bd"], None, False, blk["s"]) if "wd" in ws else hd
+                hd = native.conv1x1(o, ws["w3"], bs["b3"], idn, True, 1)
+        gd = torch.autograd.grad(hd, leaves_d, up.to(DEV).contiguous(memory_format=torch.channels_last))
+        return hd.detach(), gd
+
+    guard = torch.full((4096,), 5.0, dtype=torch.bfloat16, device=DEV)
+    y_f, g_f = run(True)
+    y_u, g_u = run(False)
+    assert y_f.shape == (B, N, Ho, Wo) and torch.equal(y_f, y_u)              # the same forward launches
+    assert float((y_f.float().cpu() - h.detach()).norm() / h.detach().norm()) <= 3e-2
+    xmask = (x.float() > 0).float()
+    for i, (a, u, r) in enumerate(zip(g_f, g_u, gr)):
+        assert a.shape == r.shape
+        if i == 0:          # the fused node returns the input gradient already masked by x > 0 (see the class docstring)
+            r, u = r * xmask, u * xmask.to(DEV)
+        # against the unfused chain on the same kernels: only the roundings the fusion removes may differ
+        assert _close(a, u.float().cpu(), 1.0e-2), (i, float((a.float() - u.float()).abs().max()), float(u.abs().max()))
+        # against fp32 only as a sanity bound, in the Frobenius norm: six ReLUs deep with every intermediate rounded to
+        # bf16, a fraction f ~ 0.3 % of the masks flips where a rounded pre-activation crosses zero, and over the identity
+        # path a flip toggles a whole upstream gradient entry: relative error ~ sqrt(f) (7 % measured, the unfused chain
+        # exactly the same).  Each convolution alone is pinned against fp32 in the tests above.
+        rel_f = float((a.float().cpu() - r).norm() / r.norm())
+        rel_u = float((u.float().cpu() - r).norm() / r.norm())
+        assert rel_f <= 0.15 and rel_f <= 1.1 * rel_u + 5e-3, (i, rel_f, rel_u)
+    # x is a ReLU output here: the fused input gradient is zero wherever x is (the mask of the producing layer)
+    assert bool((g_f[0][x.to(DEV).contiguous(memory_format=torch.channels_last) <= 0] == 0).all())
+    torch.cuda.synchronize()
+    assert bool((guard == 5.0).all())
+
+
 # --------------------------------------------------------------------------- weight-gradient GEMM (gemm_tn_kernel)
 @pytest.mark.parametrize("M,N,K", [(1024, 128, 128), (5000 + 37, 256, 384), (88892, 256, 256), (20011, 1024, 256),
                                    (16800, 256, 1024), (4200, 512, 2048)])
