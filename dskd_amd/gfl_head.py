@@ -192,19 +192,26 @@ class ATSSAssigner:
 
 
 def nms(boxes, scores, iou_threshold):
-    """Greedy NMS on [n, 4] xyxy boxes (ext-mmcv ``nms`` op): indices kept, by descending score."""
+    """Greedy NMS on [n, 4] xyxy boxes (ext-mmcv ``nms`` op): indices kept, by descending score.
+
+    Greedy suppression is the unique solution of keep[i] = not any_{j < i}(keep[j] and iou[j, i] > thr) in score order
+    (row i only looks at rows above it).  Iterating that map from all-ones fixes the first t entries after t rounds, so it
+    reaches the greedy answer after as many rounds as the longest suppression chain (a handful) -- each round one
+    [1, n] x [n, n] product on the device instead of a host loop over the n candidates."""
     if boxes.numel() == 0:
         return boxes.new_zeros((0,), dtype=torch.long)
     order = scores.argsort(descending=True)
-    iou = bbox_overlaps(boxes[order], boxes[order])
-    n = iou.shape[0]
-    keep = torch.ones(n, dtype=torch.bool, device=boxes.device)
-    iou_h = iou.cpu()                      # one transfer: the suppression chain is sequential (n <= nms_pre * levels)
-    keep_h = keep.cpu()
-    for i in range(n):
-        if keep_h[i]:
-            keep_h[i + 1:] &= ~(iou_h[i, i + 1:] > iou_threshold)
-    return order[keep_h.to(boxes.device)]
+    sup = (bbox_overlaps(boxes[order], boxes[order]) > iou_threshold).triu(1).float()      # sup[j, i]: j suppresses i
+    n = sup.shape[0]
+    keep = torch.ones(n, dtype=torch.float32, device=boxes.device)
+    for it in range(n):
+        new = ((keep[None] @ sup)[0] == 0).float()
+        # entries [0, it] are final after round it; compare (one host sync) every fourth round only
+        if it % 4 == 3 or it == n - 1:
+            if torch.equal(new, keep):
+                break
+        keep = new
+    return order[keep.bool()]
 
 
 def batched_nms(boxes, scores, idxs, iou_threshold):

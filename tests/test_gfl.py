@@ -156,3 +156,36 @@ def test_gfl_distillation_step_cpu(cpu_ops):
     m.eval()
     res = m.simple_test(img, metas)
     assert len(res) == B and len(res[0]) == 80 and res[0][0].shape[1] == 5
+
+
+def test_nms_fixed_point_equals_greedy_suppression():
+    """``gfl_head.nms`` (device-side fixed-point rounds) against the sequential definition of greedy NMS (ext-mmcv ``nms``,
+    called from mmdet/core/post_processing/bbox_nms.py:multiclass_nms): random clusters, two thresholds, and a chain
+    box_k -> box_k+1 whose answer needs as many rounds as the chain is long."""
+    from dskd_amd.gfl_head import nms, batched_nms, bbox_overlaps
+
+    def greedy(boxes, scores, thr):
+        order = scores.argsort(descending=True)
+        iou = bbox_overlaps(boxes[order], boxes[order])
+        keep = torch.ones(len(order), dtype=torch.bool)
+        for i in range(len(order)):
+            if keep[i]:
+                keep[i + 1:] &= ~(iou[i, i + 1:] > thr)
+        return order[keep]
+
+    g = torch.Generator().manual_seed(0)
+    for n in (1, 2, 7, 50, 300):
+        for spread in (20.0, 200.0):
+            xy = torch.rand(n, 2, generator=g) * spread
+            b = torch.cat([xy, xy + torch.rand(n, 2, generator=g) * 30 + 5], 1)
+            s = torch.rand(n, generator=g)
+            for thr in (0.3, 0.6):
+                assert torch.equal(nms(b, s, thr), greedy(b, s, thr))
+    chain = torch.stack([torch.tensor([k * 6.0, 0.0, k * 6.0 + 10.0, 10.0]) for k in range(40)])
+    s = torch.linspace(1.0, 0.1, 40)
+    kept = nms(chain, s, 0.2)
+    assert torch.equal(kept, greedy(chain, s, 0.2)) and len(kept) == 20
+    assert nms(chain[:0], s[:0], 0.5).numel() == 0
+    # class-aware: identical boxes of different classes never suppress each other
+    same = chain[:1].repeat(3, 1)
+    assert len(batched_nms(same, torch.tensor([0.9, 0.8, 0.7]), torch.tensor([0, 1, 0]), 0.5)) == 2
