@@ -114,6 +114,8 @@ class _TallLinearFn(torch.autograd.Function):
         if native.lin256_ok(x, weight.shape[0], weight.shape[1]) and weight.dtype == x.dtype and weight.is_contiguous():
             # 256 inputs, tall: the hand-written MFMA kernel (memory-bound; hipBLASLt takes ~1.7x as long)
             y = native.lin256(x, native.lin256_pack(weight), weight.shape[0], bias, relu)
+        elif native.gemm_nt_2d_ok(x, weight, bias):
+            y = native.gemm_nt_2d(x, weight, bias, relu)        # short inputs (decoder, head branches): own MFMA GEMM
         elif relu and bias is not None and x.is_cuda:
             y = torch._addmm_activation(bias, x, weight.t())     # bias + ReLU in the GEMM epilogue
         else:
@@ -443,6 +445,8 @@ def tall_linear(x, weight, bias, relu=False):
                 except Exception:
                     pass
             return native.lin256(x2, hit[1], weight.shape[0], bias, relu).view(*x.shape[:-1], weight.shape[0])
+        if x2 is not None and x2.dtype == weight.dtype and x2.is_contiguous() and native.gemm_nt_2d_ok(x2, weight, bias):
+            return native.gemm_nt_2d(x2, weight, bias, relu).view(*x.shape[:-1], weight.shape[0])
     y = F.linear(x, weight, bias)
     return torch.relu_(y) if relu else y
 
@@ -760,7 +764,11 @@ class FFN(nn.Module):
                 and first[0].bias is not None and first[0].frozen_lp(x.device.type) is not None:
             # frozen teacher under autocast: cached low-precision weights + fused bias/ReLU epilogue
             w, b = first[0].frozen_lp(x.device.type)
-            out = torch._addmm_activation(b, x.reshape(-1, x.shape[-1]).to(w.dtype), w.t()).view(*x.shape[:-1], -1)
+            x2 = x.reshape(-1, x.shape[-1]).to(w.dtype)
+            if x2.is_contiguous() and native.gemm_nt_2d_ok(x2, w, b):
+                out = native.gemm_nt_2d(x2, w, b, True).view(*x.shape[:-1], -1)
+            else:
+                out = torch._addmm_activation(b, x2, w.t()).view(*x.shape[:-1], -1)
             out = first[2](out)
             for m in rest:
                 out = m(out)
