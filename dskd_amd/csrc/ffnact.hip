@@ -145,6 +145,37 @@ __global__ __launch_bounds__(256) void colsum_kernel(const __bf16* __restrict__ 
   }
 }
 
+// Column sums of a SHORT [rows, C] bf16 matrix (the decoder's 1 200 query rows, the head branches' 7 200) written as bf16 in
+// ONE launch: a workgroup owns 64 columns (8 lanes x 16 bytes) and all rows, 128 row lanes with independent 16-byte loads,
+// one LDS tree.  No atomics, no zero fill, no cast pass (the tall form above needs all three); the ones-row GEMM it
+// replaces costs 10-19 us through the library at these sizes.
+__global__ __launch_bounds__(1024) void colsum_short_kernel(const __bf16* __restrict__ x, __bf16* __restrict__ out,
+                                                            int rows, int C) {
+  __shared__ float s_part[128][65];
+  const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int c0 = blockIdx.x * 64 + cg * 8;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c0 < C) {
+    for (int r = rl; r < rows; r += 128) {
+      float v[8];
+      unpack8(*reinterpret_cast<const u32x4*>(x + (size_t)r * C + c0), v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += v[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s_part[rl][cg * 8 + k] = acc[k];
+  __syncthreads();
+  for (int step = 64; step >= 1; step >>= 1) {
+    for (int i = threadIdx.x; i < step * 64; i += 1024) {
+      const int r = i >> 6, c = i & 63;
+      s_part[r][c] += s_part[r + step][c];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < C) out[blockIdx.x * 64 + threadIdx.x] = (__bf16)s_part[0][threadIdx.x];
+}
+
 }  // namespace
 }  // namespace dskd
 
@@ -174,6 +205,15 @@ extern "C" int dskd_colsum(const void* x, float* colsum, int copies, int64_t row
   }
 #undef DSKD_LAUNCH_COLSUM
   return check_launch("dskd_colsum");
+}
+
+extern "C" int dskd_colsum_short(const void* x, void* out, int64_t rows, int C, int dtype, void* stream) {
+  if (dtype != DSKD_DTYPE_BF16) return fail(DSKD_ERR_INVALID_ARG, "dskd_colsum_short: bf16 only");
+  if (!x || !out || rows < 0 || rows > 65536 || C <= 0 || (C & 7) || (reinterpret_cast<uintptr_t>(x) & 15))
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_colsum_short: null / unaligned pointer, rows outside [0, 65536] or C %% 8 != 0");
+  hipLaunchKernelGGL(colsum_short_kernel, dim3((unsigned)((C + 63) / 64)), dim3(1024), 0, (hipStream_t)stream,
+                     (const __bf16*)x, (__bf16*)out, (int)rows, C);
+  return check_launch("dskd_colsum_short");
 }
 
 extern "C" int dskd_dropout_fwd(void* y, int64_t n, float p, uint64_t seed, uint64_t offset,

@@ -52,6 +52,7 @@ _SIGNATURES = {
     "dskd_lin256_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_gemm_nt": (C.c_int, [_vp] * 5 + [_i64] + [C.c_int] * 9 + [_vp]),
     "dskd_conv3x3": (C.c_int, [_vp] * 5 + [C.c_int] * 8 + [_vp]),
+    "dskd_colsum_short": (C.c_int, [_vp, _vp, _i64, C.c_int, C.c_int, _vp]),
     "dskd_gemm_nt_dx": (C.c_int, [_vp] * 5 + [_i64] + [C.c_int] * 3 + [_vp]),
     "dskd_conv3x3_dx": (C.c_int, [_vp] * 4 + [C.c_int] * 6 + [_vp]),
     "dskd_gemm_tn": (C.c_int, [_vp] * 3 + [_i64] + [C.c_int] * 5 + [_vp]),
@@ -688,6 +689,20 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
     rc = load().dskd_colsum(x.data_ptr(), out.data_ptr(), copies, rows, Cc, DTYPE_BF16, _stream(x))
     _check(rc, "dskd_colsum")
     return out.sum(0) if copies > 1 else out[0]
+
+
+def colsum_short_ok(x: torch.Tensor) -> bool:
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and x.is_contiguous() and 0 < x.shape[0] < 16384
+            and x.shape[1] % 8 == 0 and x.data_ptr() % 16 == 0)
+
+
+def colsum_short(x: torch.Tensor) -> torch.Tensor:
+    """bf16 column sums (f32 accumulation) of a SHORT contiguous [rows, C] bf16 GPU matrix in one launch (dskd_colsum_short)."""
+    _need_gpu(x)
+    out = torch.empty((x.shape[1],), dtype=x.dtype, device=x.device)
+    _check(load().dskd_colsum_short(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], DTYPE_BF16, _stream(x)),
+           "dskd_colsum_short")
+    return out
 
 
 # --------------------------------------------------------------------------- tall Linear with 256 inputs (MFMA kernel)

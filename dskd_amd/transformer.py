@@ -73,6 +73,8 @@ def bias_grad(g2):
         return g2.sum(0, dtype=torch.float32).to(g2.dtype)
     if g2.dtype == torch.bfloat16 and g2.shape[-1] in native.COLSUM_WIDTHS and g2.is_contiguous() and g2.shape[0] >= 4096:
         return native.colsum(g2).to(g2.dtype)
+    if native.colsum_short_ok(g2):
+        return native.colsum_short(g2)          # the decoder's / head branches' short inputs: one launch, no library GEMM
     return rowsum(g2.contiguous())
 
 

@@ -350,6 +350,9 @@ int dskd_relu_dropout_bwd(const void* g, const void* y_dropped, void* out, float
  * dskd_add_ln_bwd; same for dskd_relu_dropout_bwd). */
 int dskd_colsum(const void* x, float* colsum, int copies, int64_t rows, int C, int dtype,
                 void* stream);
+/* out[c] = sum over rows of x[:, c] as bf16, ONE launch without atomics / zero fill -- the same bias gradient for SHORT
+ * inputs (the 1 200 query rows of the decoder's nn.Linear layers, 7 200 of the head branches); rows <= 65 536, C % 8 == 0. */
+int dskd_colsum_short(const void* x, void* out, int64_t rows, int C, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
  * The encoder FFN as one MFMA kernel per direction (bf16; d_model 256, hidden 1024 -- other sizes are refused and the

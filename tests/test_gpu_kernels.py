@@ -941,6 +941,32 @@ def test_ffn_fused_vs_float_reference(T):
     assert bool((guard == 7.0).all())
 
 
+@pytest.mark.parametrize("rows,C", [(1200, 256), (7200, 384), (1, 1024), (300, 80), (16383, 2048), (129, 72)])
+def test_colsum_short_vs_float_reference(rows, C):
+    """dskd_colsum_short (the bias gradient ``grad.sum(0)`` of the decoder's / head branches' nn.Linear layers, one launch)
+    against the f32 CPU sum of the same bf16 values; the short GEMM path of the same layers (dskd_gemm_nt on [rows, K] x
+    [N, K]^T + bias, optional ReLU) against the f32 product.  Row counts below, at and off the 128-row-lane stride."""
+    g = torch.Generator().manual_seed(rows + C)
+    x = torch.randn(rows, C, generator=g).bfloat16()
+    xd = x.to(DEV)
+    assert native.colsum_short_ok(xd)
+    guard = torch.full((4096,), 3.0, dtype=torch.bfloat16, device=DEV)
+    out = native.colsum_short(xd)
+    ref = x.float().sum(0)
+    assert out.dtype == torch.bfloat16 and out.shape == (C,)
+    assert float((out.float().cpu() - ref).abs().max()) <= 6e-3 * float(ref.abs().max()) + 1e-3
+    if C % 64 == 0:
+        w = (torch.randn(128, C, generator=g) / C ** 0.5).bfloat16()
+        b = torch.randn(128, generator=g).bfloat16()
+        assert native.gemm_nt_2d_ok(xd, w.to(DEV), b.to(DEV))
+        for relu in (False, True):
+            y = native.gemm_nt_2d(xd, w.to(DEV), b.to(DEV), relu)
+            yr = x.float() @ w.float().t() + b.float()
+            assert _close(y, torch.relu(yr) if relu else yr, 8e-3)
+    torch.cuda.synchronize()
+    assert bool((guard == 3.0).all())
+
+
 def test_ffn_fused_dropout_is_the_mask_of_dskd_dropout_fwd():
     """Training forward: the dropped hidden activation equals the GEMM chain's (addmm + ReLU, then dskd_dropout_fwd
     under the same key) -- identical zero pattern, values to bf16 rounding (the chain rounds twice) -- the rate is p,
