@@ -176,6 +176,24 @@ __global__ __launch_bounds__(1024) void colsum_short_kernel(const __bf16* __rest
   if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < C) out[blockIdx.x * 64 + threadIdx.x] = (__bf16)s_part[0][threadIdx.x];
 }
 
+// out[p][c] = sum over the copies of acc[p][k][c]; acc = 0.  The column-sum accumulators of dskd_colsum / dskd_add_ln_bwd /
+// dskd_ffn_bwd / dskd_relu_dropout_bwd are PERSISTENT buffers kept zeroed by this hand-over (as dskd_cvt_clear does for the
+// weight gradients): one launch where a zero fill before, a reduction over the copies and a cast after made three.
+template <typename TO>
+__global__ __launch_bounds__(256) void sum_clear_kernel(float* __restrict__ acc, int planes, int copies, int C,
+                                                        TO* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= planes * C) return;
+  const int p = i / C, c = i - p * C;
+  float* a = acc + (size_t)p * copies * C + c;
+  float s = 0.f;
+  for (int k = 0; k < copies; ++k) {
+    s += a[(size_t)k * C];
+    a[(size_t)k * C] = 0.f;
+  }
+  out[i] = (TO)s;
+}
+
 }  // namespace
 }  // namespace dskd
 
@@ -205,6 +223,21 @@ extern "C" int dskd_colsum(const void* x, float* colsum, int copies, int64_t row
   }
 #undef DSKD_LAUNCH_COLSUM
   return check_launch("dskd_colsum");
+}
+
+extern "C" int dskd_sum_clear(float* acc, int planes, int copies, int C, void* out, int out_dtype, void* stream) {
+  if (!acc || !out || planes < 1 || copies < 1 || C < 1)
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_sum_clear: null pointer or planes / copies / C < 1");
+  const unsigned blocks = (unsigned)(((long long)planes * C + 255) / 256);
+  if (out_dtype == DSKD_DTYPE_BF16)
+    hipLaunchKernelGGL(sum_clear_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, acc, planes, copies, C,
+                       (__bf16*)out);
+  else if (out_dtype == DSKD_DTYPE_F32)
+    hipLaunchKernelGGL(sum_clear_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, acc, planes, copies, C,
+                       (float*)out);
+  else
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_sum_clear: out_dtype must be f32 or bf16");
+  return check_launch("dskd_sum_clear");
 }
 
 extern "C" int dskd_colsum_short(const void* x, void* out, int64_t rows, int C, int dtype, void* stream) {

@@ -52,6 +52,7 @@ _SIGNATURES = {
     "dskd_lin256_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_gemm_nt": (C.c_int, [_vp] * 5 + [_i64] + [C.c_int] * 9 + [_vp]),
     "dskd_conv3x3": (C.c_int, [_vp] * 5 + [C.c_int] * 8 + [_vp]),
+    "dskd_sum_clear": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp]),
     "dskd_colsum_short": (C.c_int, [_vp, _vp, _i64, C.c_int, C.c_int, _vp]),
     "dskd_gemm_nt_dx": (C.c_int, [_vp] * 5 + [_i64] + [C.c_int] * 3 + [_vp]),
     "dskd_conv3x3_dx": (C.c_int, [_vp] * 4 + [C.c_int] * 6 + [_vp]),
@@ -118,6 +119,33 @@ def zeros(shape, dtype, device) -> torch.Tensor:
         return t.zero_()
     _check(load().dskd_zero_fill(t.data_ptr(), nbytes, _stream(t)), "dskd_zero_fill")
     return t
+
+
+_acc_cache = {}
+
+
+def _persistent_acc(shape, device) -> torch.Tensor:
+    """A zeroed f32 accumulator of ``shape`` that STAYS zeroed between uses: the kernels add their column sums into it and
+    :func:`sum_clear` hands the result over and clears it again -- no zero-fill launch per call.  One per shape and device,
+    used on one stream at a time (the backward's); it must exist before a hipGraph capture (run one eager step first)."""
+    device = torch.device(device)
+    if device.index is None and device.type == "cuda":
+        device = torch.device("cuda", torch.cuda.current_device())
+    key = (tuple(shape), device)
+    t = _acc_cache.get(key)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise NativeError("a column-sum accumulator must exist before a hipGraph capture (run one eager step)")
+        t = _acc_cache[key] = torch.zeros(shape, dtype=torch.float32, device=device)
+    return t
+
+
+def sum_clear(acc: torch.Tensor, planes: int, copies: int, Cc: int, out_dtype=torch.float32) -> torch.Tensor:
+    """``acc.view(planes, copies, Cc).sum(1)`` in ``out_dtype`` (f32 | bf16), leaving ``acc`` zeroed (dskd_sum_clear)."""
+    out = torch.empty((planes, Cc), dtype=out_dtype, device=acc.device)
+    dt = {torch.float32: DTYPE_F32, torch.bfloat16: DTYPE_BF16}[out_dtype]
+    _check(load().dskd_sum_clear(acc.data_ptr(), planes, copies, Cc, out.data_ptr(), dt, _stream(acc)), "dskd_sum_clear")
+    return out
 
 
 def _check(rc: int, what: str) -> None:
@@ -299,7 +327,7 @@ def graph_pins(device):
     if device.index is None and device.type == "cuda":
         device = torch.device("cuda", torch.cuda.current_device())
     return [t for t in (_msda_ws_cache.get(device), _drop_epochs.get(device)) if t is not None] + \
-        [t for k, t in _tn_acc.items() if k[2] == device]
+        [t for k, t in _tn_acc.items() if k[2] == device] + [t for k, t in _acc_cache.items() if k[1] == device]
 
 
 class _MSDAFunction(torch.autograd.Function):
@@ -487,13 +515,13 @@ class _AddLNFunction(torch.autograd.Function):
         dres = torch.empty_like(z)
         dh = torch.empty_like(z) if p > 0 else None
         copies = _colsum_copies(rows)
-        dgb = zeros((2, copies, D), torch.float32, z.device)
+        dgb = _persistent_acc((2, copies, D), z.device)
         rc = load().dskd_add_ln_bwd(dy.data_ptr(), None if dq is None else dq.data_ptr(), z.data_ptr(), stats.data_ptr(),
                                     gamma_f.data_ptr(), dres.data_ptr(), None if dh is None else dh.data_ptr(),
                                     dgb[0].data_ptr(), dgb[1].data_ptr(), copies, rows, D, p, seed, offset,
                                     dropout_epoch(z.device).data_ptr() if p > 0 else None, dt, _stream(z))
         _check(rc, "dskd_add_ln_bwd")
-        dgb = dgb.sum(1) if copies > 1 else dgb[:, 0]
+        dgb = sum_clear(dgb, 2, copies, D)
         dpos = None
         if pos_shape is not None and ctx.needs_input_grad[4] and dq is not None:
             # q = y + pos[r % pos_rows]: d(pos) = sum of dq over the repeats (the images of a batch)
@@ -581,13 +609,13 @@ def relu_dropout_bwd(g: torch.Tensor, y_dropped: torch.Tensor, p: float, want_co
     rows = g.numel() // Cc
     out = torch.empty_like(g)
     copies = _colsum_copies(rows)
-    colsum = zeros((copies, Cc), torch.float32, g.device) if want_colsum else None
+    colsum = _persistent_acc((copies, Cc), g.device) if want_colsum else None
     rc = load().dskd_relu_dropout_bwd(g.data_ptr(), y_dropped.data_ptr(), out.data_ptr(),
                                       None if colsum is None else colsum.data_ptr(), copies, rows, Cc, p, DTYPE_BF16,
                                       _stream(g))
     _check(rc, "dskd_relu_dropout_bwd")
     if colsum is not None:
-        colsum = colsum.sum(0) if copies > 1 else colsum[0]
+        colsum = sum_clear(colsum, 1, copies, Cc)[0]
     return out, colsum
 
 
@@ -654,7 +682,7 @@ def ffn_bwd_raw(grad_y: torch.Tensor, h: torch.Tensor, packed_bwd: torch.Tensor,
     gh = torch.empty_like(h)
     gx = torch.empty_like(grad_y)
     copies = _colsum_copies(tokens)
-    cs = zeros((copies, h.shape[1]), torch.float32, h.device) if want_colsum else None
+    cs = _persistent_acc((copies, h.shape[1]), h.device) if want_colsum else None
     if add_to_gx is not None and (add_to_gx.dtype != grad_y.dtype or add_to_gx.shape != grad_y.shape or
                                   not add_to_gx.is_contiguous()):
         raise NativeError("ffn_bwd_raw: add_to_gx must be a contiguous bf16 [tokens, d] tensor")
@@ -666,7 +694,7 @@ def ffn_bwd_raw(grad_y: torch.Tensor, h: torch.Tensor, packed_bwd: torch.Tensor,
     global _ffn_flops
     _ffn_flops += 4 * tokens * d * h.shape[1]
     if want_colsum:
-        return gh, gx, (cs.sum(0) if copies > 1 else cs[0])
+        return gh, gx, sum_clear(cs, 1, copies, h.shape[1])[0]
     return gh, gx
 
 
@@ -679,16 +707,17 @@ def _colsum_copies(rows: int) -> int:
     return 32 if rows >= 8192 else 1
 
 
-def colsum(x: torch.Tensor) -> torch.Tensor:
-    """fp32 column sums of a contiguous [rows, C] bf16 GPU matrix (bias gradient of a Linear)."""
+def colsum(x: torch.Tensor, out_dtype=torch.float32) -> torch.Tensor:
+    """Column sums (f32 accumulation; result f32 or bf16) of a contiguous [rows, C] bf16 GPU matrix: the bias gradient of a
+    Linear.  Two launches: partial sums into a persistent accumulator, hand-over + clear."""
     _need_gpu(x)
     Cc = x.shape[-1]
     rows = x.numel() // Cc
     copies = _colsum_copies(rows)
-    out = zeros((copies, Cc), torch.float32, x.device)
-    rc = load().dskd_colsum(x.data_ptr(), out.data_ptr(), copies, rows, Cc, DTYPE_BF16, _stream(x))
+    acc = _persistent_acc((copies, Cc), x.device)
+    rc = load().dskd_colsum(x.data_ptr(), acc.data_ptr(), copies, rows, Cc, DTYPE_BF16, _stream(x))
     _check(rc, "dskd_colsum")
-    return out.sum(0) if copies > 1 else out[0]
+    return sum_clear(acc, 1, copies, Cc, out_dtype)[0]
 
 
 def colsum_short_ok(x: torch.Tensor) -> bool:

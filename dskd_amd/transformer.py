@@ -72,7 +72,7 @@ def bias_grad(g2):
     if not g2.is_cuda:
         return g2.sum(0, dtype=torch.float32).to(g2.dtype)
     if g2.dtype == torch.bfloat16 and g2.shape[-1] in native.COLSUM_WIDTHS and g2.is_contiguous() and g2.shape[0] >= 4096:
-        return native.colsum(g2).to(g2.dtype)
+        return native.colsum(g2, out_dtype=g2.dtype)
     if native.colsum_short_ok(g2):
         return native.colsum_short(g2)          # the decoder's / head branches' short inputs: one launch, no library GEMM
     return rowsum(g2.contiguous())
@@ -205,7 +205,7 @@ class _FusedFFNFn(torch.autograd.Function):
         if ctx.needs_input_grad[3]:
             gw2 = _weight_grad(gy, h, ctx.chunk, ctx.dt)
         if ctx.needs_input_grad[4]:
-            gb2 = native.colsum(gy).to(ctx.dt)
+            gb2 = native.colsum(gy, out_dtype=ctx.dt) if ctx.dt in (torch.float32, torch.bfloat16) else native.colsum(gy).to(ctx.dt)
         return (gx if ctx.needs_input_grad[0] else None), gw1, gb1, gw2, gb2, None, None
 
 

@@ -353,6 +353,11 @@ int dskd_colsum(const void* x, float* colsum, int copies, int64_t rows, int C, i
 /* out[c] = sum over rows of x[:, c] as bf16, ONE launch without atomics / zero fill -- the same bias gradient for SHORT
  * inputs (the 1 200 query rows of the decoder's nn.Linear layers, 7 200 of the head branches); rows <= 65 536, C % 8 == 0. */
 int dskd_colsum_short(const void* x, void* out, int64_t rows, int C, int dtype, void* stream);
+/* out[p][c] = sum_k acc[p][k][c] (f32 or bf16), then acc = 0: hands the [planes][copies][C] f32 accumulators of dskd_colsum,
+ * dskd_add_ln_bwd (planes = 2: d gamma, d beta), dskd_ffn_bwd and dskd_relu_dropout_bwd over in the parameter's dtype and
+ * leaves them zeroed for their next use -- the caller keeps them as persistent buffers instead of zero-filling a fresh
+ * one per call (same idea as dskd_cvt_clear for the weight gradients). */
+int dskd_sum_clear(float* acc, int planes, int copies, int C, void* out, int out_dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
  * The encoder FFN as one MFMA kernel per direction (bf16; d_model 256, hidden 1024 -- other sizes are refused and the
