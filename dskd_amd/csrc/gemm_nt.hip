@@ -347,6 +347,7 @@ __device__ __forceinline__ bf16x8 tr_pair(unsigned a0, unsigned a1) {      // to
   return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
+template <bool ATOMIC>
 __global__ __launch_bounds__(256, 1) void gemm_tn_kernel(const TnArgs a) {
   constexpr int ROWB = 256;                  // bytes of one token's 128 channels
   constexpr int TOK = DSKD_TN_TOK;           // tokens per stage
@@ -475,9 +476,16 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_kernel(const TnArgs a) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      float* cp = a.c + (long long)(tn * 128 + wn * 64 + i * 32 + 4 * h) * a.K + tk * 128 + wk * 64 + j * 32 + r;
+      // ATOMIC: every split adds into the one [N, K] result.  Otherwise split sp owns plane sp of a [splits, N, K] scratch
+      // and writes it with plain stores (the chip's float-atomic rate is ~1.3 TB/s: the 16 MB flush of a launch was 12 us
+      // of its 26-90); reduce_cvt_kernel sums the planes and hands the result over in the parameter's dtype.
+      float* cp = a.c + (ATOMIC ? 0ll : (long long)sp * a.N * a.K) +
+                  (long long)(tn * 128 + wn * 64 + i * 32 + 4 * h) * a.K + tk * 128 + wk * 64 + j * 32 + r;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) atomicAdd(cp + (long long)((e & 3) + 8 * (e >> 2)) * a.K, acc[i][j][e]);
+      for (int e = 0; e < 16; ++e) {
+        if constexpr (ATOMIC) atomicAdd(cp + (long long)((e & 3) + 8 * (e >> 2)) * a.K, acc[i][j][e]);
+        else cp[(long long)((e & 3) + 8 * (e >> 2)) * a.K] = acc[i][j][e];
+      }
     }
 }
 
@@ -490,6 +498,24 @@ __global__ __launch_bounds__(256) void cvt_clear_kernel(float* __restrict__ src,
     reinterpret_cast<bf16x4v*>(dst)[i] = bf16x4v{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
     reinterpret_cast<f32x4*>(src)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+}
+
+// dst[i] (bf16) = sum over the planes of part[p][i]: the split-K partial products of gemm_tn_kernel<false> summed in a fixed
+// order (deterministic, unlike the atomic form) and handed over in the parameter's dtype.
+__global__ __launch_bounds__(256) void reduce_cvt_kernel(const float* __restrict__ part, int planes, long long n,
+                                                         __bf16* __restrict__ dst) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int p = 0;
+  for (; p + 3 < planes; p += 4) {
+    s0 += part[(long long)p * n + i];
+    s1 += part[(long long)(p + 1) * n + i];
+    s2 += part[(long long)(p + 2) * n + i];
+    s3 += part[(long long)(p + 3) * n + i];
+  }
+  for (; p < planes; ++p) s0 += part[(long long)p * n + i];
+  dst[i] = (__bf16)((s0 + s1) + (s2 + s3));
 }
 
 }  // namespace
@@ -570,8 +596,8 @@ extern "C" int dskd_conv3x3_dx(const void* g, const void* wt, const void* gate, 
   return conv3x3_impl(g, wt, nullptr, nullptr, gate, y, B, Hi, Wi, C, N, 1, 0, dtype, stream);
 }
 
-extern "C" int dskd_gemm_tn(const void* g, const void* x, float* c, int64_t M, int N, int K, int ldg, int ldx, int dtype,
-                            void* stream) {
+static int gemm_tn_plan(const void* g, const void* x, const void* c, int64_t M, int N, int K, int ldg, int ldx, int dtype,
+                        TnArgs* a, long long* tiles_out) {
   if (dtype != DSKD_DTYPE_BF16) return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_tn: bf16 only");
   if (!g || !x || !c || M < 0) return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_tn: null pointer or negative row count");
   if (N <= 0 || K <= 0 || (N & 127) || (K & 127) || ldg < N || ldx < K || (ldg & 7) || (ldx & 7))
@@ -579,32 +605,70 @@ extern "C" int dskd_gemm_tn(const void* g, const void* x, float* c, int64_t M, i
                 "ldg=%d ldx=%d)", N, K, ldg, ldx);
   if ((reinterpret_cast<uintptr_t>(g) & 15) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(c) & 15))
     return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_tn: pointers must be 16-byte aligned");
-  if (M == 0) return DSKD_OK;
-  TnArgs a;
-  a.g = (const __bf16*)g; a.x = (const __bf16*)x; a.c = c; a.M = M; a.N = N; a.K = K; a.ldg = ldg; a.ldx = ldx;
+  a->g = (const __bf16*)g; a->x = (const __bf16*)x; a->c = (float*)c; a->M = M; a->N = N; a->K = K; a->ldg = ldg; a->ldx = ldx;
   const long long tiles = (long long)(N >> 7) * (K >> 7);
-  // splits: one workgroup per CU (256 in all: each adds its 64 KB tile with atomics, 16 MB at ~1.3 TB/s), two per CU
-  // where that still leaves the atomic volume small and >= 1 024 tokens per workgroup; never fewer than 256 tokens each
+  // splits: one workgroup per CU (256 in all: each flushes its 64 KB tile, 16 MB per launch), two per CU
+  // where that still leaves the flush volume small and >= 1 024 tokens per workgroup; never fewer than 256 tokens each
   long long sp = 256 / tiles;
   if (sp < 1) sp = 1;
   if (tiles * sp * 2 * 65536 <= (long long)(DSKD_TN_ATOMIC_MB * 1.0e6) && M / (2 * sp) >= 1024) sp *= 2;
   const long long by_work = (M + 255) / 256;
   if (sp > by_work) sp = by_work;
   if (sp < 1) sp = 1;
-  a.chunk = (((M + sp - 1) / sp) + DSKD_TN_TOK - 1) / DSKD_TN_TOK * DSKD_TN_TOK;
-  sp = (M + a.chunk - 1) / a.chunk;
-  a.splits = (int)sp;
+  a->chunk = (((M + sp - 1) / sp) + DSKD_TN_TOK - 1) / DSKD_TN_TOK * DSKD_TN_TOK;
+  sp = M > 0 ? (M + a->chunk - 1) / a->chunk : 1;       // every split has tokens
+  a->splits = (int)sp;
+  *tiles_out = tiles;
+  return DSKD_OK;
+}
+
+template <bool ATOMIC>
+static int gemm_tn_launch(const TnArgs& a, long long tiles, hipStream_t st) {
   constexpr int lds = DSKD_TN_NS * 2 * DSKD_TN_TOK * 256;
   static bool done[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   if (!done[dev]) {
-    if (hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm_tn_kernel<ATOMIC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return fail(DSKD_ERR_LAUNCH, "dskd_gemm_tn: cannot reserve %d bytes of LDS", lds);
     done[dev] = true;
   }
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(tiles * sp)), dim3(256), lds, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(gemm_tn_kernel<ATOMIC>, dim3((unsigned)(tiles * a.splits)), dim3(256), lds, st, a);
   return check_launch("dskd_gemm_tn");
+}
+
+extern "C" int dskd_gemm_tn(const void* g, const void* x, float* c, int64_t M, int N, int K, int ldg, int ldx, int dtype,
+                            void* stream) {
+  TnArgs a;
+  long long tiles = 0;
+  if (int rc = gemm_tn_plan(g, x, c, M, N, K, ldg, ldx, dtype, &a, &tiles)) return rc;
+  if (M == 0) return DSKD_OK;
+  return gemm_tn_launch<true>(a, tiles, (hipStream_t)stream);
+}
+
+extern "C" int64_t dskd_gemm_tn_scratch_bytes(int64_t M, int N, int K) {
+  TnArgs a;
+  long long tiles = 0;
+  static const char dummy[16] __attribute__((aligned(16))) = {};
+  if (gemm_tn_plan(dummy, dummy, dummy, M, N, K, N, K, DSKD_DTYPE_BF16, &a, &tiles)) return -1;
+  return (int64_t)a.splits * N * K * (int64_t)sizeof(float);
+}
+
+extern "C" int dskd_gemm_tn_bf16(const void* g, const void* x, void* out, void* scratch, int64_t scratch_bytes, int64_t M,
+                                 int N, int K, int ldg, int ldx, int dtype, void* stream) {
+  TnArgs a;
+  long long tiles = 0;
+  if (!out || (reinterpret_cast<uintptr_t>(out) & 1)) return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_tn_bf16: null output");
+  if (int rc = gemm_tn_plan(g, x, scratch, M, N, K, ldg, ldx, dtype, &a, &tiles)) return rc;
+  if (M == 0) return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_tn_bf16: M must be positive");
+  if (scratch_bytes < (int64_t)a.splits * N * K * (int64_t)sizeof(float))
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_tn_bf16: scratch of %lld bytes, %lld needed", (long long)scratch_bytes,
+                (long long)a.splits * N * K * (long long)sizeof(float));
+  if (int rc = gemm_tn_launch<false>(a, tiles, (hipStream_t)stream)) return rc;
+  const long long n = (long long)N * K;
+  hipLaunchKernelGGL(reduce_cvt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)scratch, a.splits, n, (__bf16*)out);
+  return check_launch("dskd_gemm_tn_bf16/reduce");
 }
 
 extern "C" int dskd_cvt_clear(float* src, void* dst, int64_t n, int dtype, void* stream) {

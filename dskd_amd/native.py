@@ -58,6 +58,8 @@ _SIGNATURES = {
     "dskd_conv3x3_dx": (C.c_int, [_vp] * 4 + [C.c_int] * 6 + [_vp]),
     "dskd_gemm_tn": (C.c_int, [_vp] * 3 + [_i64] + [C.c_int] * 5 + [_vp]),
     "dskd_cvt_clear": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp]),
+    "dskd_gemm_tn_scratch_bytes": (_i64, [_i64, C.c_int, C.c_int]),
+    "dskd_gemm_tn_bf16": (C.c_int, [_vp] * 4 + [_i64, _i64] + [C.c_int] * 5 + [_vp]),
     "dskd_winattn_fwd": (C.c_int, [_vp] * 4 + [C.c_int] * 5 + [_f32, C.c_int, _vp]),
     "dskd_winattn_bwd": (C.c_int, [_vp] * 6 + [C.c_int] * 5 + [_f32, C.c_int, _vp]),
     "dskd_clip_adamw_chunk": (C.c_int, []),
@@ -327,7 +329,8 @@ def graph_pins(device):
     if device.index is None and device.type == "cuda":
         device = torch.device("cuda", torch.cuda.current_device())
     return [t for t in (_msda_ws_cache.get(device), _drop_epochs.get(device)) if t is not None] + \
-        [t for k, t in _tn_acc.items() if k[2] == device] + [t for k, t in _acc_cache.items() if k[1] == device]
+        [t for k, t in _tn_acc.items() if k[2] == device] + [t for k, t in _acc_cache.items() if k[1] == device] + \
+        [t for d, t in _tn_scratch.items() if d == device]
 
 
 class _MSDAFunction(torch.autograd.Function):
@@ -898,14 +901,13 @@ def gemm_tn(g2: torch.Tensor, x2: torch.Tensor, out: Optional[torch.Tensor] = No
     return out
 
 
-_tn_acc = {}
+_tn_acc = {}          # (N, K, device) -> f32 accumulators of gemm_tn_bf16_atomic (kept for A/B runs and tests)
+_tn_scratch = {}      # device -> the split-K scratch of gemm_tn_bf16
 
 
-def gemm_tn_bf16(g2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
-    """``(g2^T @ x2).to(bf16)`` -- a weight gradient in the low-precision parameter's dtype -- in two launches: the split-K
-    kernel adds into a PERSISTENT f32 accumulator of that shape (kept zeroed between uses), ``dskd_cvt_clear`` hands the
-    result over as bf16 and zeroes the accumulator again.  (A fresh accumulator per call costs a zero fill before and a
-    cast after: 2 x 109 small launches per step.)  Calls on one stream only: the accumulator is shared per shape."""
+def gemm_tn_bf16_atomic(g2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
+    """The round-3 form of :func:`gemm_tn_bf16`: the split-K kernel adds into a PERSISTENT f32 accumulator of that shape
+    with float atomics, ``dskd_cvt_clear`` hands the result over as bf16 and zeroes the accumulator again."""
     N, K = g2.shape[1], x2.shape[1]
     key = (N, K, g2.device)
     acc = _tn_acc.get(key)
@@ -916,6 +918,33 @@ def gemm_tn_bf16(g2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     gemm_tn(g2, x2, out=acc)
     out = torch.empty((N, K), dtype=torch.bfloat16, device=g2.device)
     _check(load().dskd_cvt_clear(acc.data_ptr(), out.data_ptr(), N * K, DTYPE_BF16, _stream(g2)), "dskd_cvt_clear")
+    return out
+
+
+def gemm_tn_bf16(g2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
+    """``(g2^T @ x2).to(bf16)`` -- a weight gradient in the low-precision parameter's dtype -- in two launches without
+    atomics: the split-K kernel writes every split's partial product into a persistent scratch ([splits, N, K] f32, plain
+    stores), a second launch sums the planes in a fixed order and casts (dskd_gemm_tn_bf16).  The float-atomic flush of the
+    earlier form ran at the chip's ~1.3 TB/s atomic rate: 12 us of every launch.  Calls on one stream only (one scratch per
+    device); the scratch must exist before a hipGraph capture."""
+    _need_gpu(g2, x2)
+    M, N = g2.shape
+    K = x2.shape[1]
+    need = int(load().dskd_gemm_tn_scratch_bytes(M, N, K))
+    if need < 0:
+        raise NativeError("gemm_tn_bf16: " + load().dskd_last_error().decode())
+    dev = g2.device
+    ws = _tn_scratch.get(dev)
+    if ws is None or ws.numel() < need:
+        if torch.cuda.is_current_stream_capturing():
+            raise NativeError("gemm_tn_bf16: the scratch must exist before a hipGraph capture (run one eager step)")
+        ws = _tn_scratch[dev] = torch.empty(max(need, 32 << 20), dtype=torch.uint8, device=dev)
+    out = torch.empty((N, K), dtype=torch.bfloat16, device=dev)
+    rc = load().dskd_gemm_tn_bf16(g2.data_ptr(), x2.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), M, N, K,
+                                  g2.stride(0), x2.stride(0), DTYPE_BF16, _stream(g2))
+    _check(rc, "dskd_gemm_tn_bf16")
+    global _ffn_flops
+    _ffn_flops += 2 * M * N * K
     return out
 
 

@@ -452,6 +452,13 @@ int dskd_conv3x3_dx(const void* g, const void* wt, const void* gate, void* y, in
  * c must be zero-filled (or hold a value to accumulate onto).  ldg / ldx: row strides of g / x in elements.
  * ------------------------------------------------------------------------- */
 int dskd_gemm_tn(const void* g, const void* x, float* c, int64_t M, int N, int K, int ldg, int ldx, int dtype, void* stream);
+/* out[N, K] (bf16) = g[M, N]^T x[M, K]: the same product with the split-K partial products written as plain stores into
+ * `scratch` ([splits, N, K] f32, dskd_gemm_tn_scratch_bytes(M, N, K) bytes) and summed + cast by a second launch in a fixed
+ * order -- no float atomics (their rate, ~1.3 TB/s chip-wide, made the 16 MB flush 12 us of every launch), no accumulator
+ * to keep zeroed, deterministic.  out is overwritten.  M > 0. */
+int64_t dskd_gemm_tn_scratch_bytes(int64_t M, int N, int K);
+int dskd_gemm_tn_bf16(const void* g, const void* x, void* out, void* scratch, int64_t scratch_bytes, int64_t M, int N, int K,
+                      int ldg, int ldx, int dtype, void* stream);
 /* dst (bf16, n elements) = src (f32); src = 0 -- the accumulator of dskd_gemm_tn handed over in the parameter's dtype and
  * left zeroed for its next use (n a multiple of 4). */
 int dskd_cvt_clear(float* src, void* dst, int64_t n, int dtype, void* stream);

@@ -16,12 +16,14 @@ for name, M, N, K in shapes:
     g = torch.randn(M, N, device=dev).bfloat16(); x = torch.randn(M, K, device=dev).bfloat16()
     if not native.gemm_tn_ok(g, x):
         print(f"{name:12s} M={M:6d} N={N:4d} K={K:4d}: not taken"); continue
-    out = torch.zeros(N, K, device=dev)
-    for _ in range(3): native.gemm_tn(g, x, out=out)
-    torch.cuda.synchronize()
-    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(20): native.gemm_tn(g, x, out=out)
-    e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) / 20 * 1e3
-    print(f"{name:12s} M={M:6d} N={N:4d} K={K:4d}: {us:7.1f} us  {2.0 * M * N * K / us / 1e6:6.0f} TF/s  {(M * (N + K) * 2) / us / 1e3:6.0f} GB/s")
+    res = []
+    for fn in (native.gemm_tn_bf16, native.gemm_tn_bf16_atomic):
+        for _ in range(3): fn(g, x)
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20): fn(g, x)
+        e1.record(); torch.cuda.synchronize()
+        res.append(e0.elapsed_time(e1) / 20 * 1e3)
+    us = res[0]
+    print(f"{name:12s} M={M:6d} N={N:4d} K={K:4d}: planes+reduce {us:7.1f} us ({2.0 * M * N * K / us / 1e6:5.0f} TF/s)   atomics+cvt_clear {res[1]:7.1f} us")

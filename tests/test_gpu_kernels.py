@@ -1455,8 +1455,15 @@ def test_gemm_tn_vs_float_reference(M, N, K):
     assert _close(out, ref, 2e-3), float((out.cpu() - ref).abs().max()) / float(ref.abs().max())
     out2 = native.gemm_tn(gd, xd, out=out.clone())                      # accumulates
     assert _close(out2, 2 * ref, 2e-3)
-    # the bf16 hand-over through the persistent accumulator (dskd_cvt_clear): same values, and the accumulator is zero again
+    # the bf16 forms.  dskd_gemm_tn_bf16: split-K planes in a scratch + a fixed-order reduction: deterministic (two calls
+    # bit-equal) and independent of what the scratch held before
+    native._tn_scratch.pop(gd.device, None)
     b1 = native.gemm_tn_bf16(gd, xd)
+    native._tn_scratch[gd.device].fill_(0x7F)                           # NaN-ish garbage in every plane
     b2 = native.gemm_tn_bf16(gd, xd)
-    assert b1.dtype == torch.bfloat16 and _close(b1, ref, 6e-3) and _close(b2, ref, 6e-3)
+    assert b1.dtype == torch.bfloat16 and _close(b1, ref, 6e-3) and torch.equal(b1, b2)
+    # the atomic form (persistent accumulator + dskd_cvt_clear): same values, and the accumulator is zero again
+    a1 = native.gemm_tn_bf16_atomic(gd, xd)
+    a2 = native.gemm_tn_bf16_atomic(gd, xd)
+    assert _close(a1, ref, 6e-3) and _close(a2, ref, 6e-3)
     assert float(native._tn_acc[(N, K, gd.device)].abs().max()) == 0.0
