@@ -791,14 +791,13 @@ def conv1x1_ok(x: torch.Tensor, w: torch.Tensor, conv) -> bool:
             and w.data_ptr() % 16 == 0 and (w.stride(1) == 1 or w.is_contiguous()) and w.stride(0) == w.shape[1])
 
 
-def gemm_nt_2d_ok(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], strided_w: bool = False) -> bool:
+def gemm_nt_2d_ok(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> bool:
     """Can dskd_gemm_nt form ``x [M, K] @ w [N, K]^T (+ bias)`` for a SHORT bf16 CUDA input (the decoder's 1 200 query rows,
     the head branches' 7 200): 6.6-9 us per launch against 10-19 us for the library GEMM at these sizes
-    (profiles/r03_lin_vs_gemm_microbench.txt).  Tall inputs keep lin256 / the fused FFN / the library (faster there).
-    ``strided_w``: only ask whether the SHAPES fit (the caller makes ``w`` contiguous itself)."""
+    (profiles/r03_lin_vs_gemm_microbench.txt).  Tall inputs keep lin256 / the fused FFN / the library (faster there)."""
     return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and w.dim() == 2 and w.dtype == torch.bfloat16
             and 0 < x.shape[0] < 16384 and x.shape[1] == w.shape[1] and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0
-            and x.is_contiguous() and (strided_w or w.is_contiguous()) and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0
+            and x.is_contiguous() and w.is_contiguous() and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0
             and (bias is None or (bias.dtype == torch.bfloat16 and bias.is_contiguous() and bias.data_ptr() % 16 == 0
                                   and bias.numel() == w.shape[0])))
 

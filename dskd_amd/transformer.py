@@ -139,10 +139,6 @@ class _TallLinearFn(torch.autograd.Function):
             if weight.shape[0] == 256 and native.lin256_ok(g2, weight.shape[1], weight.shape[0]) and \
                     weight.dtype == g2.dtype and weight.is_contiguous():
                 gx = native.lin256(g2, native.lin256_pack(weight, transposed=True), weight.shape[1]).view(x.shape)
-            elif not os.environ.get('DSKD_SHORT_DX_LIB') and g2.is_contiguous() and weight.shape[1] % 64 == 0 and native.gemm_nt_2d_ok(g2, weight.t(), None, strided_w=True):
-                # short inputs: dX = g W on the own GEMM too (the transposed weight is one small copy; the library's
-                # NN GEMM takes ~14 us per launch at these sizes, copy + own kernel ~10)
-                gx = native.gemm_nt_2d(g2, weight.t().contiguous(), None).view(x.shape)
             else:
                 gx = (g2 @ weight).view(x.shape)
         if ctx.needs_input_grad[1]:
