@@ -89,3 +89,33 @@ def test_gemm_nt_argument_validation():
     assert lib.dskd_gemm_nt(ok_ptr, ok_ptr, None, None, ok_ptr, 100, 64, 64, 0, 2, 5, 5, 9, 8, 1, None) == -1      # 2 * 4 >= Wi
     assert b"row map" in lib.dskd_last_error()
     assert lib.dskd_gemm_nt(ok_ptr, ok_ptr, None, None, ok_ptr, 0, 64, 64, 0, 0, 0, 0, 0, 0, 1, None) == 0         # nothing to do
+
+
+def test_round3_late_entry_points_validate_their_arguments():
+    """dskd_gemm_nt_dx / dskd_conv3x3_dx / dskd_gemm_tn_bf16 / dskd_colsum_short / dskd_sum_clear / dskd_fgkd_fwd refuse
+    bad shapes, null and misaligned pointers and short scratch buffers BEFORE any launch (no GPU needed): a kernel that
+    runs on operands it was not built for can fault the whole node."""
+    lib = native.load()
+    p = 4096
+    bf16, f32 = native.DTYPE_BF16, native.DTYPE_F32
+    assert lib.dskd_gemm_nt_dx(p, p, None, None, p, 128, 96, 64, bf16, None) == -1 and b"multiples of 64" in lib.dskd_last_error()
+    assert lib.dskd_gemm_nt_dx(p, p, None, p + 8, p, 128, 64, 64, bf16, None) == -1 and b"aligned" in lib.dskd_last_error()
+    assert lib.dskd_gemm_nt_dx(p, p, None, None, p, 128, 64, 64, f32, None) == -1
+    assert lib.dskd_gemm_nt_dx(p, p, None, None, p, 0, 64, 64, bf16, None) == 0
+    assert lib.dskd_conv3x3_dx(p, p, None, p, 1, 8, 8, 96, 64, bf16, None) == -1 and b"64 * 2^k" in lib.dskd_last_error()
+    assert lib.dskd_conv3x3_dx(p, p, p + 2, p, 1, 8, 8, 64, 64, bf16, None) == -1 and b"aligned" in lib.dskd_last_error()
+    assert lib.dskd_conv3x3_dx(p, p, None, p, 0, 8, 8, 64, 64, bf16, None) == 0
+    # split-K scratch: the planner's answer, and a buffer one byte short of it
+    need = lib.dskd_gemm_tn_scratch_bytes(88892, 256, 256)
+    assert need > 0 and need % (256 * 256 * 4) == 0 and need <= 64 << 20
+    assert lib.dskd_gemm_tn_scratch_bytes(1000, 100, 256) == -1
+    assert lib.dskd_gemm_tn_bf16(p, p, p, p, need - 1, 88892, 256, 256, 256, 256, bf16, None) == -1
+    assert b"scratch" in lib.dskd_last_error()
+    assert lib.dskd_gemm_tn_bf16(p, p, None, p, need, 88892, 256, 256, 256, 256, bf16, None) == -1
+    assert lib.dskd_gemm_tn_bf16(p, p, p, p, need, 88892, 256, 256, 128, 256, bf16, None) == -1          # ldg < N
+    assert lib.dskd_colsum_short(p, p, 70000, 256, bf16, None) == -1 and b"rows" in lib.dskd_last_error()
+    assert lib.dskd_colsum_short(p, p, 100, 250, bf16, None) == -1
+    assert lib.dskd_colsum_short(p + 2, p, 100, 256, bf16, None) == -1
+    assert lib.dskd_sum_clear(None, 1, 1, 256, p, f32, None) == -1
+    assert lib.dskd_sum_clear(p, 1, 0, 256, p, f32, None) == -1
+    assert lib.dskd_sum_clear(p, 1, 1, 256, p, 7, None) == -1 and b"out_dtype" in lib.dskd_last_error()
