@@ -643,7 +643,7 @@ class MultiheadAttention(nn.Module):
         self.proj_drop = nn.Dropout(proj_drop)
         self.dropout_layer = nn.Dropout(dropout_layer["drop_prob"]) if dropout_layer else nn.Identity()
 
-    def _attend(self, query, key, value):
+    def _attend(self, query, key, value, batch_first=False):
         """``nn.MultiheadAttention`` without masks on the GPU, same arithmetic with fewer launches:
         q and k projected by ONE GEMM when they are the same tensor (DETR self-attention: q = k =
         query + query_pos, v = query), fused ``scaled_dot_product_attention``, the step's
@@ -652,17 +652,26 @@ class MultiheadAttention(nn.Module):
         live = self.__dict__.get("_live_lp")
         w, b, wo, bo = live if live is not None else (self.attn.in_proj_weight, self.attn.in_proj_bias,
                                                       self.attn.out_proj.weight, self.attn.out_proj.bias)
-        L, B, _ = query.shape
-        S = key.shape[0]
         if query is key:
             q, k = tall_linear(query, w[:2 * E], b[:2 * E]).split(E, dim=-1)
         else:
             q, k = tall_linear(query, w[:E], b[:E]), tall_linear(key, w[E:2 * E], b[E:2 * E])
         v = tall_linear(value, w[2 * E:], b[2 * E:])
+        p_drop = self.attn.dropout if self.training else 0.0
+        if batch_first:         # [B, L, E] tokens: the head split is a view either way, nothing is permuted + copied on the way in
+            B, L, _ = query.shape
+            S = key.shape[1]
+            q = q.reshape(B, L, H, E // H).permute(0, 2, 1, 3)
+            k = k.reshape(B, S, H, E // H).permute(0, 2, 1, 3)
+            v = v.reshape(B, S, H, E // H).permute(0, 2, 1, 3)
+            out = F.scaled_dot_product_attention(q, k, v, dropout_p=p_drop)
+            return tall_linear(out.permute(0, 2, 1, 3).reshape(B, L, E), wo, bo)
+        L, B, _ = query.shape
+        S = key.shape[0]
         q = q.reshape(L, B, H, E // H).permute(1, 2, 0, 3)
         k = k.reshape(S, B, H, E // H).permute(1, 2, 0, 3)
         v = v.reshape(S, B, H, E // H).permute(1, 2, 0, 3)
-        out = F.scaled_dot_product_attention(q, k, v, dropout_p=self.attn.dropout if self.training else 0.0)
+        out = F.scaled_dot_product_attention(q, k, v, dropout_p=p_drop)
         return tall_linear(out.permute(2, 0, 1, 3).reshape(L, B, E), wo, bo)
 
     def tail_dropout_p(self):
@@ -690,16 +699,18 @@ class MultiheadAttention(nn.Module):
             key = query
         elif key_pos is not None:
             key = key + key_pos
-        if self.batch_first:
-            query, key, value = query.transpose(0, 1), key.transpose(0, 1), value.transpose(0, 1)
+        tbf = kwargs.get("tokens_batch_first")
+        bf = self.batch_first if tbf is None else bool(tbf)     # set by the decoder's batch-first GPU path: [B, L, E] tokens
         if attn_mask is None and key_padding_mask is None and query.is_cuda and self.attn.in_proj_weight is not None \
                 and self.attn.in_proj_bias is not None and self.attn._qkv_same_embed_dim:
-            out = self._attend(query, key, value)
+            out = self._attend(query, key, value, batch_first=bf)
         else:
+            if bf:
+                query, key, value = query.transpose(0, 1), key.transpose(0, 1), value.transpose(0, 1)
             out = self.attn(query=query, key=key, value=value, attn_mask=attn_mask, key_padding_mask=key_padding_mask,
                             need_weights=False)[0]
-        if self.batch_first:
-            out = out.transpose(0, 1)
+            if bf:
+                out = out.transpose(0, 1)
         if fuse_tail:
             return out
         return identity + self.dropout_layer(self.proj_drop(out))
@@ -1024,8 +1035,22 @@ class DeformableDetrTransformerDecoder(TransformerLayerSequence):
         super().__init__(*args, **kwargs)
         self.return_intermediate = return_intermediate
 
+    def batch_first_ok(self):
+        """Can the layers run on [B, L, E] tokens: every attention module is one of ours that takes ``tokens_batch_first``
+        (MultiheadAttention for the self-attention, MultiScaleDeformableAttention for the cross-attention)?"""
+        ok = self.__dict__.get("_bf_ok")
+        if ok is None:
+            ok = all(isinstance(a, (MultiheadAttention, MultiScaleDeformableAttention))
+                     for layer in self.layers for a in layer.attentions)
+            self.__dict__["_bf_ok"] = ok
+        return ok
+
     def forward(self, query, *args, reference_points=None, valid_ratios=None, reg_branches=None, **kwargs):
         output = query
+        # ``tokens_batch_first`` (set by DeformableDetrTransformer on the GPU): query / query_pos come as [B, L, E] and every
+        # layer keeps that layout -- the deformable cross-attention and the regression branches are batch-first anyway, and
+        # the reference's [L, B, E] costs a permute + copy of the query tensor around each of them (transformer.py:983-995)
+        bf = bool(kwargs.get("tokens_batch_first"))
         qp = kwargs.get("query_pos")
         if qp is not None and qp.is_cuda and torch.is_autocast_enabled(qp.device.type):
             # every layer's fused path wants the positional queries in the compute dtype: cast once, not six times
@@ -1041,7 +1066,8 @@ class DeformableDetrTransformerDecoder(TransformerLayerSequence):
                 assert reference_points.shape[-1] == 2
                 reference_points_input = reference_points[:, :, None] * valid_ratios[:, None]
             output = layer(output, *args, reference_points=reference_points_input, **kwargs)
-            output = output.permute(1, 0, 2)
+            if not bf:
+                output = output.permute(1, 0, 2)
             if reg_branches is not None:
                 tmp = reg_branches[lid](output)
                 if reference_points.shape[-1] == 4:
@@ -1051,13 +1077,16 @@ class DeformableDetrTransformerDecoder(TransformerLayerSequence):
                     new_reference_points[..., :2] = tmp[..., :2] + inverse_sigmoid(reference_points)
                     new_reference_points = new_reference_points.sigmoid()
                 reference_points = new_reference_points.detach()
-            output = output.permute(1, 0, 2)
+            if not bf:
+                output = output.permute(1, 0, 2)
             if self.return_intermediate:
                 intermediate.append(output)
                 intermediate_reference_points.append(reference_points)
         if self.return_intermediate:
-            return torch.stack(intermediate), torch.stack(intermediate_reference_points)
-        return output, reference_points
+            states = torch.stack(intermediate)
+            # batch-first run: [layers, B, L, E] in memory, handed out in the reference layout [layers, L, B, E] as a view
+            return (states.permute(0, 2, 1, 3) if bf else states), torch.stack(intermediate_reference_points)
+        return (output.permute(1, 0, 2) if bf else output), reference_points
 
 
 @TRANSFORMER.register_module()
@@ -1161,12 +1190,15 @@ class DeformableDetrTransformer(nn.Module):
         reference_points = self.reference_points(query_pos).sigmoid()
         init_reference_out = reference_points
 
-        query = query.permute(1, 0, 2)
-        query_pos = query_pos.permute(1, 0, 2)
+        dec_bf = memory.is_cuda and self.decoder.batch_first_ok()
+        if not dec_bf:
+            query = query.permute(1, 0, 2)
+            query_pos = query_pos.permute(1, 0, 2)
         inter_states, inter_references = self.decoder(
             query=query, key=None, value=memory, query_pos=query_pos, key_padding_mask=mask_flatten,
             reference_points=reference_points, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
-            valid_ratios=valid_ratios, reg_branches=reg_branches, value_batch_first=True, **kwargs)
+            valid_ratios=valid_ratios, reg_branches=reg_branches, value_batch_first=True,
+            **(dict(kwargs, tokens_batch_first=True) if dec_bf else kwargs))
         spatial_shapes_t = device_const(spatial_shapes, torch.long, device)
         info_all = (memory.permute(1, 0, 2), spatial_shapes_t)      # reference layout (sum HW, bs, C), a view
         return inter_states, init_reference_out, inter_references, info_all, None, None
