@@ -872,20 +872,39 @@ class BaseTransformerLayer(nn.Module):
             query_pos = query_pos.to(dtype)
         if key_pos is not None and key_pos.dtype != dtype:
             key_pos = key_pos.to(dtype)
+        # ``x + query_pos`` for the NEXT attention sub-layer comes out of the LayerNorm launch in front of it (want_q: one more
+        # 16-byte store per lane instead of an add launch, and in the backward the two gradients are summed inside
+        # add_ln_bwd) -- within the layer, and across layers through a tag on the layer's output (the decoder hands each
+        # layer's output straight to the next).  Only when pos has the shape of the tokens (elementwise: any layout).
+        can_q = query_pos is not None and query_pos.shape == x.shape and query_pos.dtype == dtype and x.is_cuda
+        tag = getattr(query, "_dskd_q", None)
+        q_next = tag[0] if (can_q and tag is not None and tag[1] is query_pos and tag[0].shape == x.shape) else None
         ai = 0
-        for op, mod, norm in plan:
+        for k, (op, mod, norm) in enumerate(plan):
             p = mod.tail_dropout_p()
             if op == "ffn":
                 h = mod.core(x, final_dropout=False)
             elif op == "self_attn":
-                h = mod(x, x, x, None, query_pos=query_pos, key_pos=query_pos, attn_mask=attn_masks[ai],
-                        key_padding_mask=query_key_padding_mask, fuse_tail=True, **kwargs)
+                if q_next is not None:        # q = k = x + pos already formed; v = x
+                    h = mod(q_next, q_next, x, None, query_pos=None, key_pos=None, attn_mask=attn_masks[ai],
+                            key_padding_mask=query_key_padding_mask, fuse_tail=True, **kwargs)
+                else:
+                    h = mod(x, x, x, None, query_pos=query_pos, key_pos=query_pos, attn_mask=attn_masks[ai],
+                            key_padding_mask=query_key_padding_mask, fuse_tail=True, **kwargs)
                 ai += 1
             else:
-                h = mod(x, key, value, None, query_pos=query_pos, key_pos=key_pos, attn_mask=attn_masks[ai],
-                        key_padding_mask=key_padding_mask, fuse_tail=True, **kwargs)
+                if q_next is not None:
+                    h = mod(q_next, key, value, None, query_pos=None, key_pos=key_pos, attn_mask=attn_masks[ai],
+                            key_padding_mask=key_padding_mask, fuse_tail=True, **kwargs)
+                else:
+                    h = mod(x, key, value, None, query_pos=query_pos, key_pos=key_pos, attn_mask=attn_masks[ai],
+                            key_padding_mask=key_padding_mask, fuse_tail=True, **kwargs)
                 ai += 1
-            x, _ = native.add_layer_norm(h.to(dtype), x, norm, p=p)
+            nxt = plan[(k + 1) % len(plan)][0]          # the sub-layer that reads this LayerNorm's output (next layer: same plan)
+            want_q = can_q and nxt != "ffn" and (nxt == "self_attn" or key_pos is None)
+            x, q_next = native.add_layer_norm(h.to(dtype), x, norm, p=p, pos=query_pos if want_q else None, want_q=want_q)
+        if q_next is not None:
+            x._dskd_q = (q_next, query_pos)
         return x
 
     def forward(self, query, key=None, value=None, query_pos=None, key_pos=None, attn_masks=None,
@@ -1057,6 +1076,8 @@ class DeformableDetrTransformerDecoder(TransformerLayerSequence):
             dt = torch.get_autocast_dtype(qp.device.type)
             if qp.dtype != dt and dt in (torch.bfloat16, torch.float16):
                 kwargs["query_pos"] = qp.to(dt)
+                if bf:      # the LayerNorm launches that also form x + query_pos read the f32 values (native._pos_f32)
+                    kwargs["query_pos"]._dskd_f32 = qp.detach().float().contiguous()
         intermediate, intermediate_reference_points = [], []
         for lid, layer in enumerate(self.layers):
             if reference_points.shape[-1] == 4:
