@@ -86,10 +86,38 @@ int fill(const int64_t* spatial_shapes, int levels, int points, PrepGeom* g) {
   return DSKD_OK;
 }
 
+// d(reference points)[q, l, :] = sum over heads and points of d(loc)[q, h, l, p, :]: loc = ref[q, l] + offset / (W, H).
+// One thread per (query, level, x|y), heads * points strided loads.  (ATen's reduction over the [nq, H, L, P, 2] view takes
+// 14 us for the decoder's 1 200 queries; this sits on the decoder's launch chain six times per backward.)
+__global__ __launch_bounds__(256) void grad_ref_kernel(const float* __restrict__ gl, float* __restrict__ out, long long n,
+                                                       int heads, int levels, int points) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;      // (q, l, xy)
+  if (i >= n) return;
+  const int xy = (int)(i & 1);
+  const int l = (int)((i >> 1) % levels);
+  const long long q = (i >> 1) / levels;
+  const float* base = gl + (q * heads * levels + l) * (long long)points * 2 + xy;
+  float s = 0.f;
+  for (int h = 0; h < heads; ++h)
+    for (int p = 0; p < points; ++p) s += base[((long long)h * levels * points + p) * 2];
+  out[i] = s;
+}
+
 }  // namespace
 }  // namespace dskd
 
 using namespace dskd;
+
+extern "C" int dskd_msda_grad_ref(const float* grad_loc, float* grad_ref, int64_t n_query, int heads, int levels, int points,
+                                  void* stream) {
+  if (n_query < 0 || heads < 1 || levels < 1 || points < 1) return fail(DSKD_ERR_INVALID_ARG, "dskd_msda_grad_ref: bad sizes");
+  if (n_query == 0) return DSKD_OK;
+  if (!grad_loc || !grad_ref) return fail(DSKD_ERR_INVALID_ARG, "dskd_msda_grad_ref: null pointer");
+  const long long n = (long long)n_query * levels * 2;
+  hipLaunchKernelGGL(grad_ref_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, grad_loc, grad_ref,
+                     n, heads, levels, points);
+  return check_launch("dskd_msda_grad_ref");
+}
 
 extern "C" int dskd_msda_prep_fwd(const void* both, const float* ref, const int64_t* spatial_shapes,
                                   float* loc, float* attn, int64_t n_query, int heads, int levels,

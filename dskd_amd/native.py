@@ -35,6 +35,7 @@ _SIGNATURES = {
     "dskd_msda_bwd_ws": (C.c_int, [_vp] * 9 + [C.c_int] * 8 + [_vp, _i64, _vp]),
     "dskd_msda_prep_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_msda_prep_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "dskd_msda_grad_ref": (C.c_int, [_vp, _vp, _i64, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_add_ln_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, _f32, _f32,
                                    C.c_uint64, C.c_uint64, _vp, C.c_int, _vp]),
     "dskd_add_ln_bwd": (C.c_int, [_vp] * 9 + [C.c_int, _i64, C.c_int, _f32, C.c_uint64, C.c_uint64, _vp, C.c_int, _vp]),
@@ -414,7 +415,10 @@ class _MSDAPrepFunction(torch.autograd.Function):
         grad_ref = None
         if ctx.needs_input_grad[1]:
             # loc = ref[..., None, :, None, :] + off / (W, H): d(ref) = sum of d(loc) over heads and points
-            grad_ref = gl.reshape(nq, heads, levels, points, 2).sum((1, 3)).view(ref_shape).to(ref_dtype)
+            gr = torch.empty((nq, levels, 2), dtype=torch.float32, device=gl.device)
+            _check(load().dskd_msda_grad_ref(gl.data_ptr(), gr.data_ptr(), nq, heads, levels, points, _stream(gl)),
+                   "dskd_msda_grad_ref")
+            grad_ref = gr.view(ref_shape).to(ref_dtype)
         return grad_both, grad_ref, None, None, None, None
 
 

@@ -317,6 +317,33 @@ class _AddLevelEmbed(torch.autograd.Function):
         return (g if ctx.needs_input_grad[0] else None), ge
 
 
+class _JoinRows(torch.autograd.Function):
+    """``torch.cat([a, b], 0)`` for two tensors that already lie behind each other in ONE buffer (lowp_params allocates the
+    low-precision copies of sampling_offsets / attention_weights that way): the result is a view, the backward two views."""
+
+    @staticmethod
+    def adjacent(a, b):
+        return (a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype and a.shape[1:] == b.shape[1:]
+                and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+                and a.storage_offset() + a.numel() == b.storage_offset())
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.n = a.shape[0]
+        return a.as_strided((a.shape[0] + b.shape[0],) + tuple(a.shape[1:]), a.stride())
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:ctx.n], g[ctx.n:]
+
+
+def join_rows(a, b):
+    """cat([a, b], 0) -- as a view when the two already are neighbours in memory (see :class:`_JoinRows`)."""
+    if _JoinRows.adjacent(a, b):
+        return _JoinRows.apply(a, b)
+    return torch.cat([a, b], 0)
+
+
 class lowp_params:
     """``with lowp_params(root, dtype):`` -- every trainable :class:`Linear` below ``root`` uses
     a ``dtype`` copy of its parameters made by ONE :class:`_CastParams` call (autograd routes
@@ -349,7 +376,22 @@ class lowp_params:
             key = tuple((p.data_ptr(), tuple(p.shape)) for p in params) + (self.dtype,)
             static = self.root.__dict__.get("_lp_static")
             if static is None or static[0] != key:
-                static = (key, [torch.empty_like(p, dtype=self.dtype) for p in params])
+                bufs = [None] * len(params)
+                # sampling_offsets | attention_weights of one MultiScaleDeformableAttention are used as ONE GEMM on the
+                # concatenated weights: their copies lie behind each other, so that the concatenation is a view (join_rows)
+                index = {id(p): i for i, p in enumerate(params)}
+                for m in self.root.modules():
+                    if isinstance(m, MultiScaleDeformableAttention):
+                        for pa, pb in ((m.sampling_offsets.weight, m.attention_weights.weight),
+                                       (m.sampling_offsets.bias, m.attention_weights.bias)):
+                            ia, ib = index.get(id(pa)), index.get(id(pb))
+                            if ia is None or ib is None or bufs[ia] is not None or bufs[ib] is not None \
+                                    or not (pa.is_contiguous() and pb.is_contiguous()) or pa.shape[1:] != pb.shape[1:]:
+                                continue
+                            joint = torch.empty((pa.shape[0] + pb.shape[0],) + tuple(pa.shape[1:]), dtype=self.dtype,
+                                                device=pa.device)
+                            bufs[ia], bufs[ib] = joint[:pa.shape[0]], joint[pa.shape[0]:]
+                static = (key, [b if b is not None else torch.empty_like(p, dtype=self.dtype) for b, p in zip(bufs, params)])
                 self.root.__dict__["_lp_static"] = static
             self.outs = list(_CastParams.apply(self.dtype, static[1], *params))
             outs = iter(self.outs)
@@ -589,8 +631,8 @@ class MultiScaleDeformableAttention(nn.Module):
             w_cat, b_cat = self._cat
         else:
             (sw, sb), (ww, wb) = so.lp(), aw.lp()
-            w_cat = torch.cat([sw, ww], 0)
-            b_cat = torch.cat([sb, wb], 0)
+            w_cat = join_rows(sw, ww)
+            b_cat = join_rows(sb, wb)
         both = tall_linear(query, w_cat, b_cat)
         if value.is_cuda and reference_points.shape[-1] == 2 and self.num_levels * self.num_points == 16 \
                 and self.num_levels <= 4 and both.dtype == value.dtype and not (

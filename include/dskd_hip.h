@@ -157,6 +157,10 @@ int dskd_msda_prep_fwd(const void* both, const float* ref, const int64_t* spatia
 int dskd_msda_prep_bwd(const float* grad_loc, const float* grad_attn, const float* attn,
                        const int64_t* spatial_shapes, void* grad_both, int64_t n_query,
                        int heads, int levels, int points, int dtype, void* stream);
+/* grad_ref[q, l, 0:2] (f32) = sum over heads and points of grad_loc[q, h, l, p, 0:2]: the gradient of the reference points
+ * (the decoder's come from a trainable Linear on the query embedding: mmdet/models/utils/transformer.py:1016-1017). */
+int dskd_msda_grad_ref(const float* grad_loc, float* grad_ref, int64_t n_query, int heads, int levels, int points,
+                       void* stream);
 
 /* ---------------------------------------------------------------------------
  * Rectangular linear sum assignment, bit-exact with scipy 1.15.3
