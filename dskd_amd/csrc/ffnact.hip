@@ -166,14 +166,21 @@ __global__ __launch_bounds__(1024) void colsum_short_kernel(const __bf16* __rest
 #pragma unroll
   for (int k = 0; k < 8; ++k) s_part[rl][cg * 8 + k] = acc[k];
   __syncthreads();
-  for (int step = 64; step >= 1; step >>= 1) {
-    for (int i = threadIdx.x; i < step * 64; i += 1024) {
-      const int r = i >> 6, c = i & 63;
-      s_part[r][c] += s_part[r + step][c];
-    }
-    __syncthreads();
+  __shared__ float s_half[8][65];
+  if (threadIdx.x < 512) {                       // two steps instead of a seven-barrier tree: 16 rows per thread, then 8
+    const int g = threadIdx.x >> 6, c = threadIdx.x & 63;
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += s_part[g * 16 + r][c];
+    s_half[g][c] = t;
   }
-  if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < C) out[blockIdx.x * 64 + threadIdx.x] = (__bf16)s_part[0][threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t += s_half[g][threadIdx.x];
+    out[blockIdx.x * 64 + threadIdx.x] = (__bf16)t;
+  }
 }
 
 // out[p][c] = sum over the copies of acc[p][k][c]; acc = 0.  The column-sum accumulators of dskd_colsum / dskd_add_ln_bwd /
@@ -182,16 +189,27 @@ __global__ __launch_bounds__(1024) void colsum_short_kernel(const __bf16* __rest
 template <typename TO>
 __global__ __launch_bounds__(256) void sum_clear_kernel(float* __restrict__ acc, int planes, int copies, int C,
                                                         TO* __restrict__ out) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= planes * C) return;
-  const int p = i / C, c = i - p * C;
-  float* a = acc + (size_t)p * copies * C + c;
+  // 32 outputs per workgroup, 8 lanes of copies each (copy k, k + 8, ..: independent loads), one LDS step over the 8
+  __shared__ float s_part[8][33];
+  const int cl = threadIdx.x & 31, kg = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + cl;
   float s = 0.f;
-  for (int k = 0; k < copies; ++k) {
-    s += a[(size_t)k * C];
-    a[(size_t)k * C] = 0.f;
+  if (i < planes * C) {
+    const int p = i / C, c = i - p * C;
+    float* a = acc + (size_t)p * copies * C + c;
+    for (int k = kg; k < copies; k += 8) {
+      s += a[(size_t)k * C];
+      a[(size_t)k * C] = 0.f;
+    }
   }
-  out[i] = (TO)s;
+  s_part[kg][cl] = s;
+  __syncthreads();
+  if (kg == 0 && i < planes * C) {
+    float t = s_part[0][cl];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += s_part[k][cl];
+    out[i] = (TO)t;
+  }
 }
 
 }  // namespace
@@ -228,7 +246,7 @@ extern "C" int dskd_colsum(const void* x, float* colsum, int copies, int64_t row
 extern "C" int dskd_sum_clear(float* acc, int planes, int copies, int C, void* out, int out_dtype, void* stream) {
   if (!acc || !out || planes < 1 || copies < 1 || C < 1)
     return fail(DSKD_ERR_INVALID_ARG, "dskd_sum_clear: null pointer or planes / copies / C < 1");
-  const unsigned blocks = (unsigned)(((long long)planes * C + 255) / 256);
+  const unsigned blocks = (unsigned)(((long long)planes * C + 31) / 32);
   if (out_dtype == DSKD_DTYPE_BF16)
     hipLaunchKernelGGL(sum_clear_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, acc, planes, copies, C,
                        (__bf16*)out);
