@@ -518,6 +518,32 @@ __global__ __launch_bounds__(256) void reduce_cvt_kernel(const float* __restrict
   dst[i] = (__bf16)((s0 + s1) + (s2 + s3));
 }
 
+// The same sum for MANY planes of a small result (64 planes of 256 x 256: the thin layers): 32 outputs per workgroup, 8 lanes
+// of planes each (independent loads), one LDS step -- a thread of the form above walks its 64 planes alone.
+__global__ __launch_bounds__(256) void reduce_cvt_wide_kernel(const float* __restrict__ part, int planes, long long n,
+                                                              __bf16* __restrict__ dst) {
+  __shared__ float s_part[8][33];
+  const int cl = threadIdx.x & 31, kg = threadIdx.x >> 5;
+  const long long i = (long long)blockIdx.x * 32 + cl;
+  float s0 = 0.f, s1 = 0.f;
+  if (i < n) {
+    int p = kg;
+    for (; p + 8 < planes; p += 16) {
+      s0 += part[(long long)p * n + i];
+      s1 += part[(long long)(p + 8) * n + i];
+    }
+    if (p < planes) s0 += part[(long long)p * n + i];
+  }
+  s_part[kg][cl] = s0 + s1;
+  __syncthreads();
+  if (kg == 0 && i < n) {
+    float t = s_part[0][cl];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += s_part[k][cl];
+    dst[i] = (__bf16)t;
+  }
+}
+
 }  // namespace
 }  // namespace dskd
 
@@ -666,8 +692,12 @@ extern "C" int dskd_gemm_tn_bf16(const void* g, const void* x, void* out, void* 
                 (long long)a.splits * N * K * (long long)sizeof(float));
   if (int rc = gemm_tn_launch<false>(a, tiles, (hipStream_t)stream)) return rc;
   const long long n = (long long)N * K;
-  hipLaunchKernelGGL(reduce_cvt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const float*)scratch, a.splits, n, (__bf16*)out);
+  if (a.splits >= 16 && n <= (1 << 20))
+    hipLaunchKernelGGL(reduce_cvt_wide_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)scratch, a.splits, n, (__bf16*)out);
+  else
+    hipLaunchKernelGGL(reduce_cvt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)scratch, a.splits, n, (__bf16*)out);
   return check_launch("dskd_gemm_tn_bf16/reduce");
 }
 

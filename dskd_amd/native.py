@@ -607,7 +607,8 @@ def dropout_(y: torch.Tensor, p: float) -> torch.Tensor:
     return y
 
 
-def relu_dropout_bwd(g: torch.Tensor, y_dropped: torch.Tensor, p: float, want_colsum: bool = True):
+def relu_dropout_bwd(g: torch.Tensor, y_dropped: torch.Tensor, p: float, want_colsum: bool = True,
+                     colsum_dtype=torch.float32):
     """Backward of ``dropout_p(relu(.))`` given its OUTPUT: ``g * (y_dropped != 0) / (1 - p)`` and
     the column sums of that (the bias gradient of the Linear in front).  [rows, C] bf16."""
     _need_gpu(g, y_dropped)
@@ -622,7 +623,7 @@ def relu_dropout_bwd(g: torch.Tensor, y_dropped: torch.Tensor, p: float, want_co
                                       _stream(g))
     _check(rc, "dskd_relu_dropout_bwd")
     if colsum is not None:
-        colsum = sum_clear(colsum, 1, copies, Cc)[0]
+        colsum = sum_clear(colsum, 1, copies, Cc, colsum_dtype)[0]
     return out, colsum
 
 
@@ -680,7 +681,7 @@ def ffn_fwd_raw(x: torch.Tensor, packed_fwd: torch.Tensor, b1: torch.Tensor, b2:
 
 
 def ffn_bwd_raw(grad_y: torch.Tensor, h: torch.Tensor, packed_bwd: torch.Tensor, p: float, want_colsum: bool = False,
-                add_to_gx: Optional[torch.Tensor] = None):
+                add_to_gx: Optional[torch.Tensor] = None, colsum_dtype=torch.float32):
     """(grad_h, grad_x[, column sums of grad_h in f32 = grad of b1]) of :func:`ffn_fwd_raw` given grad_y [tokens, d]
     and the stored H: one MFMA launch.  ``add_to_gx`` [tokens, d] bf16 is added to grad_x in the kernel's epilogue."""
     _need_gpu(grad_y, h, packed_bwd)
@@ -701,7 +702,7 @@ def ffn_bwd_raw(grad_y: torch.Tensor, h: torch.Tensor, packed_bwd: torch.Tensor,
     global _ffn_flops
     _ffn_flops += 4 * tokens * d * h.shape[1]
     if want_colsum:
-        return gh, gx, sum_clear(cs, 1, copies, h.shape[1])[0]
+        return gh, gx, sum_clear(cs, 1, copies, h.shape[1], colsum_dtype)[0]
     return gh, gx
 
 

@@ -165,7 +165,8 @@ class _FFNInnerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, weight, y = ctx.saved_tensors
-        g1, colsum = native.relu_dropout_bwd(g, y, ctx.p, want_colsum=ctx.needs_input_grad[2])
+        cdt = weight.dtype if weight.dtype in (torch.float32, torch.bfloat16) else torch.float32
+        g1, colsum = native.relu_dropout_bwd(g, y, ctx.p, want_colsum=ctx.needs_input_grad[2], colsum_dtype=cdt)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = g1 @ weight
@@ -196,7 +197,8 @@ class _FusedFFNFn(torch.autograd.Function):
     def backward(ctx, gy):
         x, h, pb = ctx.saved_tensors
         gy = gy.contiguous()
-        gh, gx, cs = native.ffn_bwd_raw(gy, h, pb, ctx.p, want_colsum=True)
+        cdt = ctx.dt if ctx.dt in (torch.float32, torch.bfloat16) else torch.float32
+        gh, gx, cs = native.ffn_bwd_raw(gy, h, pb, ctx.p, want_colsum=True, colsum_dtype=cdt)
         gw1 = gb1 = gw2 = gb2 = None
         if ctx.needs_input_grad[1]:
             gw1 = _weight_grad(gh, x, ctx.chunk, ctx.dt)
