@@ -527,6 +527,30 @@ __global__ __launch_bounds__(256) void lin256_pack_kernel(const __bf16* __restri
   *reinterpret_cast<bf16x8*>(packed + (size_t)f * 8) = v;
 }
 
+// Many weights in ONE launch: table row e = {source, destination, N, transposed} (device int64 [n, 4]); blockIdx.y = row.
+// The student's ~40 tall 256-input Linear weights change once per optimiser step: one launch right after the step's
+// low-precision copies are made instead of one pack launch in front of every lin256 call (42 per step, ~4.6 us each,
+// most of them on the forward / backward launch chains).
+__global__ __launch_bounds__(256) void lin256_pack_many_kernel(const long long* __restrict__ table) {
+  const long long* e = table + (size_t)blockIdx.y * 4;
+  const __bf16* W = reinterpret_cast<const __bf16*>(e[0]);
+  __bf16* packed = reinterpret_cast<__bf16*>(e[1]);
+  const int N = (int)e[2], transposed = (int)e[3];
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= (N / 32) * 1024) return;
+  const int ot = f >> 10, q = f & 1023, lane = q & 63, s = q >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int row = 32 * ot + pi_row(r), k0 = 128 * h + 8 * s;
+  bf16x8 v;
+  if (!transposed) {
+    v = *reinterpret_cast<const bf16x8*>(W + (size_t)row * kD + k0);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = W[(size_t)(k0 + j) * N + row];
+  }
+  *reinterpret_cast<bf16x8*>(packed + (size_t)f * 8) = v;
+}
+
 struct LinArgs {
   const __bf16* x;       // [T, 256]
   const __bf16* wp;      // packed weight tiles [N / 32][16 KB]
@@ -727,6 +751,17 @@ extern "C" int dskd_lin256_pack(const void* w, void* packed, int N, int K, int t
   hipLaunchKernelGGL(lin256_pack_kernel, dim3((frags + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const __bf16*)w,
                      (__bf16*)packed, N, transposed);
   return check_launch("dskd_lin256_pack");
+}
+
+extern "C" int dskd_lin256_pack_many(const int64_t* table, int n, int dtype, void* stream) {
+  if (dtype != DSKD_DTYPE_BF16) return fail(DSKD_ERR_INVALID_ARG, "dskd_lin256_pack_many: bf16 only");
+  if (n < 0 || (n > 0 && !table)) return fail(DSKD_ERR_INVALID_ARG, "dskd_lin256_pack_many: null table");
+  if (n == 0) return DSKD_OK;
+  if (n > 65535) return fail(DSKD_ERR_INVALID_ARG, "dskd_lin256_pack_many: more than 65535 entries");
+  // 64 blocks of 256 fragments cover the largest image (N = 512); smaller ones leave their upper blocks idle
+  hipLaunchKernelGGL(lin256_pack_many_kernel, dim3(64, (unsigned)n), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const long long*>(table));
+  return check_launch("dskd_lin256_pack_many");
 }
 
 extern "C" int dskd_lin256_fwd(const void* x, const void* packed, const void* bias, void* y, int64_t tokens, int N, int K,

@@ -50,6 +50,7 @@ _SIGNATURES = {
     "dskd_ffn_bwd": (C.c_int, [_vp] * 7 + [C.c_int, _i64, C.c_int, C.c_int, _f32, C.c_int, _vp]),
     "dskd_lin256_packed_bytes": (_i64, [C.c_int]),
     "dskd_lin256_pack": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "dskd_lin256_pack_many": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "dskd_lin256_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_gemm_nt": (C.c_int, [_vp] * 5 + [_i64] + [C.c_int] * 9 + [_vp]),
     "dskd_conv3x3": (C.c_int, [_vp] * 5 + [C.c_int] * 8 + [_vp]),
@@ -331,7 +332,8 @@ def graph_pins(device):
         device = torch.device("cuda", torch.cuda.current_device())
     return [t for t in (_msda_ws_cache.get(device), _drop_epochs.get(device)) if t is not None] + \
         [t for k, t in _tn_acc.items() if k[2] == device] + [t for k, t in _acc_cache.items() if k[1] == device] + \
-        [t for d, t in _tn_scratch.items() if d == device]
+        [t for d, t in _tn_scratch.items() if d == device] + \
+        [t for pre in set(_prepacked.values()) for t in pre.pins() if t.device == device]
 
 
 class _MSDAFunction(torch.autograd.Function):
@@ -754,12 +756,66 @@ def lin256_ok(x: torch.Tensor, n_out: int, k_in: int) -> bool:
             and x.data_ptr() % 16 == 0 and LIN256_ENABLED)
 
 
+class Lin256Prepack:
+    """Fragment-order images of a fixed set of weights (persistent bf16 buffers whose CONTENTS change once per step: the
+    low-precision parameter copies of transformer.lowp_params), refreshed by ONE launch (:meth:`refresh`) instead of one
+    ``lin256_pack`` launch in front of every use.  :func:`lin256_pack` returns an image from here when it was refreshed
+    after the last write to its source (``stamp == epoch[0]``; the owner bumps ``epoch[0]`` whenever it rewrites the
+    sources) -- anything else packs on the spot as before.  The object keeps sources and images alive, so a data pointer
+    cannot come back as another tensor while its entry exists."""
+
+    def __init__(self, weights, epoch):
+        self.epoch, self.stamp = epoch, -1
+        self.sources, self.images, rows = [], {}, []
+        for w in weights:
+            if not (w.is_cuda and w.dtype == torch.bfloat16 and w.dim() == 2 and w.is_contiguous() and w.data_ptr() % 16 == 0):
+                continue
+            forms = []
+            if w.shape[1] == 256 and w.shape[0] % 32 == 0 and 32 <= w.shape[0] <= 512:
+                forms.append((False, w.shape[0]))
+            if w.shape[0] == 256 and w.shape[1] % 32 == 0 and 32 <= w.shape[1] <= 512:
+                forms.append((True, w.shape[1]))
+            for transposed, n in forms:
+                key = (w.data_ptr(), tuple(w.shape), transposed)
+                if key in self.images:
+                    continue
+                img = torch.empty(int(load().dskd_lin256_packed_bytes(n)) // 2, dtype=torch.bfloat16, device=w.device)
+                self.images[key] = img
+                rows.append([w.data_ptr(), img.data_ptr(), n, 1 if transposed else 0])
+            if forms:
+                self.sources.append(w)
+        self.n = len(rows)
+        self.table = torch.tensor(rows, dtype=torch.int64, device=weights[0].device) if rows else None
+
+    def refresh(self):
+        if self.n:
+            _check(load().dskd_lin256_pack_many(self.table.data_ptr(), self.n, DTYPE_BF16, _stream(self.table)),
+                   "dskd_lin256_pack_many")
+        self.stamp = self.epoch[0]
+        for key in self.images:
+            _prepacked[key] = self
+
+    def drop(self):
+        for key in self.images:
+            if _prepacked.get(key) is self:
+                del _prepacked[key]
+
+    def pins(self):
+        return ([self.table] if self.table is not None else []) + list(self.images.values())
+
+
+_prepacked = {}      # (data_ptr, shape, transposed) -> the Lin256Prepack that holds this weight's image
+
+
 def lin256_pack(w: torch.Tensor, transposed: bool = False) -> torch.Tensor:
     """Fragment-order image of a bf16 weight: ``w`` [N, 256] (nn.Linear layout), or with ``transposed`` ``w`` [256, N]
     whose TRANSPOSE is the layer (the input-gradient GEMM ``g @ w`` of a [256, 256] Linear)."""
     _need_gpu(w)
     if w.dtype != torch.bfloat16 or not w.is_contiguous() or w.dim() != 2:
         raise NativeError("lin256_pack: contiguous 2-D bf16 weight expected")
+    pre = _prepacked.get((w.data_ptr(), tuple(w.shape), bool(transposed)))
+    if pre is not None and pre.stamp == pre.epoch[0]:
+        return pre.images[(w.data_ptr(), tuple(w.shape), bool(transposed))]
     n, k = (w.shape[1], w.shape[0]) if transposed else (w.shape[0], w.shape[1])
     nbytes = load().dskd_lin256_packed_bytes(n)
     if nbytes < 0 or k != 256:

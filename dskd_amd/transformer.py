@@ -395,7 +395,27 @@ class lowp_params:
                             bufs[ia], bufs[ib] = joint[:pa.shape[0]], joint[pa.shape[0]:]
                 static = (key, [b if b is not None else torch.empty_like(p, dtype=self.dtype) for b, p in zip(bufs, params)])
                 self.root.__dict__["_lp_static"] = static
+                # fragment-order images of the tall 256-input weights (and of the joint so | aw buffers), refreshed by one
+                # launch per step right after the cast below (native.Lin256Prepack)
+                old = self.root.__dict__.pop("_lp_prepack", None)
+                if old is not None:
+                    old.drop()
+                if self.dtype == torch.bfloat16 and params[0].is_cuda and not torch.cuda.is_current_stream_capturing():
+                    joints, seen = [], set()
+                    for b in bufs:
+                        if b is not None and b.dim() == 2 and b.untyped_storage().data_ptr() not in seen:
+                            seen.add(b.untyped_storage().data_ptr())
+                            base = b._base if b._base is not None else b
+                            joints.append(base)
+                    epoch = self.root.__dict__.setdefault("_lp_epoch", [0])
+                    self.root.__dict__["_lp_prepack"] = native.Lin256Prepack(
+                        [t for t in static[1] if t.dim() == 2 and t._base is None] + joints, epoch)
+            epoch = self.root.__dict__.setdefault("_lp_epoch", [0])
+            epoch[0] += 1                       # the copies are about to be rewritten: images made before are stale
             self.outs = list(_CastParams.apply(self.dtype, static[1], *params))
+            pre = self.root.__dict__.get("_lp_prepack")
+            if pre is not None:
+                pre.refresh()
             outs = iter(self.outs)
             for m in self.live:
                 m.__dict__["_live_lp"] = (next(outs), next(outs) if m.bias is not None else None)

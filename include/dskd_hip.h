@@ -406,6 +406,9 @@ int dskd_ffn_bwd(const void* grad_y, const void* h, const void* packed_bwd, void
  * ------------------------------------------------------------------------- */
 int64_t dskd_lin256_packed_bytes(int N);
 int dskd_lin256_pack(const void* w, void* packed, int N, int K, int transposed, int dtype, void* stream);
+/* The same for many weights in one launch: table = device int64 [n, 4] rows {w pointer, packed pointer, N, transposed}, every
+ * row as dskd_lin256_pack would take it (the caller validates: N a multiple of 32 in [32, 512], K = 256, 16-byte alignment). */
+int dskd_lin256_pack_many(const int64_t* table, int n, int dtype, void* stream);
 int dskd_lin256_fwd(const void* x, const void* packed, const void* bias, void* y, int64_t tokens, int N, int K, int relu,
                     int dtype, void* stream);
 

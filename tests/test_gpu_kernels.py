@@ -967,6 +967,43 @@ def test_colsum_short_vs_float_reference(rows, C):
     assert bool((guard == 3.0).all())
 
 
+def test_lin256_prepack_serves_fresh_images_only():
+    """native.Lin256Prepack (one dskd_lin256_pack_many launch for all weights of a step) hands lin256_pack the same bytes as
+    a pack on the spot -- forward and transposed form, a [256, 256] weight and a [384, 256] joint buffer -- and ONLY while
+    its stamp matches the owner's epoch: after the sources were rewritten without a refresh the stale image is not used."""
+    g = torch.Generator().manual_seed(9)
+    w = torch.randn(256, 256, generator=g).bfloat16().to(DEV)
+    j = torch.randn(384, 256, generator=g).bfloat16().to(DEV)
+
+    def on_the_spot(t, transposed):
+        native._prepacked.clear()
+        return native.lin256_pack(t, transposed)
+
+    want = {(id(w), False): on_the_spot(w, False), (id(w), True): on_the_spot(w, True), (id(j), False): on_the_spot(j, False)}
+    epoch = [0]
+    pre = native.Lin256Prepack([w, j], epoch)
+    assert pre.n == 3
+    epoch[0] += 1
+    pre.refresh()
+    for (t, tr) in ((w, False), (w, True), (j, False)):
+        got = native.lin256_pack(t, tr)
+        assert got.data_ptr() == pre.images[(t.data_ptr(), tuple(t.shape), tr)].data_ptr()       # the persistent image
+        assert torch.equal(got, want[(id(t), tr)])
+    # the owner rewrites the sources (next step's cast) and has not refreshed yet: no stale image
+    w.mul_(2.0)
+    epoch[0] += 1
+    fresh = native.lin256_pack(w, False)
+    assert fresh.data_ptr() != pre.images[(w.data_ptr(), (256, 256), False)].data_ptr()
+    assert torch.equal(fresh.float(), want[(id(w), False)].float() * 2)
+    pre.refresh()
+    assert torch.equal(native.lin256_pack(w, False).float(), want[(id(w), False)].float() * 2)
+    x = torch.randn(17000, 256, generator=g).bfloat16().to(DEV)
+    y = native.lin256(x, native.lin256_pack(j, False), 384)
+    assert _close(y, x.float().cpu() @ j.float().cpu().t(), 8e-3)
+    pre.drop()
+    assert not native._prepacked
+
+
 def test_ffn_fused_dropout_is_the_mask_of_dskd_dropout_fwd():
     """Training forward: the dropped hidden activation equals the GEMM chain's (addmm + ReLU, then dskd_dropout_fwd
     under the same key) -- identical zero pattern, values to bf16 rounding (the chain rounds twice) -- the rate is p,
