@@ -308,14 +308,24 @@ class _AddLevelEmbed(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pos, emb):
+        dev = pos.device.type
+        # under bf16 autocast the table reaches the encoder in bf16 (DetrTransformerEncoder._forward_fused), so the gradient
+        # that comes back here in f32 holds bf16 values: the column sums may read them as bf16 (half the bytes, own kernel)
+        ctx.lowp = pos.is_cuda and torch.is_autocast_enabled(dev) and torch.get_autocast_dtype(dev) == torch.bfloat16
         return pos + emb.view(1, 1, -1)
 
     @staticmethod
     def backward(ctx, g):
         ge = None
         if ctx.needs_input_grad[1]:
-            g2 = g.reshape(-1, g.shape[-1])
-            ge = rowsum(g2.contiguous()) if g2.is_cuda else g2.sum(0)
+            if g.is_cuda and ctx.lowp and g.dtype == torch.float32 and g.shape[-1] in native.COLSUM_WIDTHS:
+                # one strided read into a contiguous bf16 copy + the streaming column sum: ~40 us for the finest level where
+                # contiguous() + an f32 ones-row GEMM through the library took ~170 (132 us for the GEMM alone)
+                gb = g.to(torch.bfloat16).reshape(-1, g.shape[-1])
+                ge = native.colsum(gb if gb.is_contiguous() else gb.contiguous(), out_dtype=torch.float32)
+            else:
+                g2 = g.reshape(-1, g.shape[-1])
+                ge = rowsum(g2.contiguous()) if g2.is_cuda else g2.sum(0)
         return (g if ctx.needs_input_grad[0] else None), ge
 
 
