@@ -57,6 +57,30 @@ struct GemmArgs {
 
 __device__ __attribute__((aligned(256))) char g_zero_page[256];
 
+#ifdef DSKD_GEMM_PROFILE
+// timing-only diagnostic build (scratch/r04_gemm_prof.py): wave 0 of every workgroup stamps its phases into a buffer of its
+// own (8 words per workgroup) that nothing else reads
+__device__ long long* g_gemm_prof;
+__device__ __forceinline__ void prof_stamp(int slot) {
+  if (g_gemm_prof && threadIdx.x == 0) {
+    long long* p = g_gemm_prof + (long long)blockIdx.x * 8;
+    p[slot] = (long long)__builtin_amdgcn_s_memtime();
+    if (slot == 0) {
+      p[6] = (long long)__builtin_amdgcn_s_memrealtime();
+      unsigned id;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id));
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      p[5] = ((long long)xcc << 32) | id;
+    }
+    if (slot == 4) p[7] = (long long)__builtin_amdgcn_s_memrealtime();
+  }
+}
+#define PROF(slot) prof_stamp(slot)
+#else
+#define PROF(slot)
+#endif
+
 __device__ __forceinline__ unsigned lds_offset(const void* p) {
   return (unsigned)(unsigned long)((const __attribute__((address_space(3))) char*)p);
 }
@@ -99,12 +123,35 @@ __device__ __forceinline__ void mfma_stage(f32x16 (&acc)[MT][2], Frags<MT>& f) {
       if (ks == 2) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(f.w[2][0]), "+v"(f.w[2][1]), "+v"(f.x[2][0]));
       if (ks == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.w[3][0]), "+v"(f.w[3][1]), "+v"(f.x[3][0]));
     }
+    // r4: without this fence hipcc moves the later waits up in front of the first MFMA (the asm statements only keep their
+    // order among themselves): lgkmcnt(12), (8), (4) back to back, i.e. every fragment read of the stage has to land before
+    // any MFMA issues (seen in the ISA of the r3 build)
+    if constexpr (COUNTED) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w[ks][nt], f.x[ks][mt], acc[mt][nt], 0, 0, 0);
+    if constexpr (COUNTED) __builtin_amdgcn_sched_barrier(0);
   }
+}
+struct FragK {
+  bf16x8 w[2], x[2];
+};
+// One k-step (16) of a 64 x 64 wave tile: the MFMAs only (the caller has waited for / waits for the fragments);
+// KS < 3: behind a counted wait that assumes the stage's 16 fragment reads are the wave's youngest LDS operations.
+template <int KS>
+__device__ __forceinline__ void mfma_ks(f32x16 (&acc)[2][2], Frags<2>& f) {
+  if constexpr (KS == 0) asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(f.w[0][0]), "+v"(f.w[0][1]), "+v"(f.x[0][0]), "+v"(f.x[0][1]));
+  if constexpr (KS == 1) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(f.w[1][0]), "+v"(f.w[1][1]), "+v"(f.x[1][0]), "+v"(f.x[1][1]));
+  if constexpr (KS == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f.w[2][0]), "+v"(f.w[2][1]), "+v"(f.x[2][0]), "+v"(f.x[2][1]));
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+      acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w[KS][nt], f.x[KS][mt], acc[mt][nt], 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
 }
 // Epilogue: lane = one token (m_first + 32 mt), 16 consecutive outputs (n_first + 32 nt ..) per accumulator tile.
 template <int MT>
@@ -275,6 +322,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs a) {
       for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
 
   {
+    PROF(0);
     issue(0);
     Frags<MT> f;
     for (int kt = 0; kt < nk; ++kt) {
@@ -285,12 +333,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_s_barrier();                                       // ... and everybody's
+      if (kt == 0) PROF(1);
       read_stage<MT, PX, PW>(f, xa, wa, (kt % NS) * STAGE);
       mfma_stage<MT, true>(acc, f);
       __builtin_amdgcn_s_barrier();       // every wave has read this stage before the next DMA overwrites it
     }
   }
+  PROF(2);
   store_tile<MT>(a, acc, m0 + wm * MT * 32 + r, n0 + wn * 64 + 16 * h);
+#ifdef DSKD_GEMM_PROFILE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PROF(4);
+#endif
 }
 
 template <int BN, int MT, bool CONV3>
@@ -310,6 +364,553 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
   if (tiles > 0x7FFFFFFFll) return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_nt: too many tiles");
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), LDS, st, a);
   return check_launch("dskd_gemm_nt");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// r4: the same tile loop as a PERSISTENT workgroup.  Phase stamps of gemm_nt_kernel (profiles/r04_gemm_phases.txt): a
+// workgroup lives 7 - 16 us of which the K loop is 35 - 70 %; the rest is the first stage's HBM round trip (2 900 - 3 900
+// cycles) and the epilogue (3 600 - 6 400 cycles with a residual) -- paid by every one of the 500 - 4 000 tiles of a launch,
+// and three resident workgroups per CU only partly cover each other.  Here 3 x 256 workgroups each walk a contiguous
+// range of tiles and the LDS-DMA pipeline never drains: the first stage of tile t + 1 is requested while the last stage of
+// tile t is multiplied, the residual / gate rows of a tile are requested when its loop starts, and the stores of tile t
+// drain under the loop of tile t + 1.
+template <int BN, int MT, bool CONV3>
+__global__ __launch_bounds__(256, 2) void gemm_nt_persist_kernel(const GemmArgs a, long long tiles) {
+  constexpr int NS = 2;
+  constexpr int WN = BN / 64;
+  constexpr int WM = 4 / WN;
+  constexpr int BM = WM * MT * 32;
+  constexpr int XRB = BM / 64;
+  constexpr int PX = BM * 64, PW = BN * 64;
+  constexpr int STAGE = 2 * (PX + PW);
+  constexpr int WRB = BN / 64;
+  constexpr int LOADS = 2 * (XRB + WRB);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int wn = wave % WN, wm = wave / WN;
+  const int tiles_n = a.N / BN;
+  const int nk = a.K >> 6;
+
+  // this workgroup's tiles [t_first, t_last): ranges of workgroups that share an XCD are adjacent
+  const int rg = xcd_remap(blockIdx.x, gridDim.x);
+  long long t_issue = tiles * rg / gridDim.x;
+  const long long t_last = tiles * (rg + 1) / gridDim.x;
+  if (t_issue >= t_last) return;
+  const long long n_items = (t_last - t_issue) * nk;
+
+  // ---- issue side: the tile whose stages are being requested
+  const int lr = lane >> 2;
+  const int csw = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;
+  const char* xp[XRB];
+  const char* wp[WRB];
+  unsigned vmask[XRB];
+  long long i_m0 = 0;
+  int i_n0 = 0, i_kt = 0;
+  const char* const zp = g_zero_page + csw;
+  auto setup_tile = [&](long long t) {
+    const int tn = (int)(t % tiles_n);
+    i_m0 = (t / tiles_n) * BM;
+    i_n0 = tn * BN;
+#pragma unroll
+    for (int j = 0; j < XRB; ++j) {
+      long long m = i_m0 + (wave * XRB + j) * 16 + lr;
+      if (m >= a.M) m = a.M - 1;
+      long long row = m;
+      vmask[j] = 0x1FFu;
+      if (a.s) {
+        const long long img = m / a.HoWo;
+        const int rem = (int)(m - img * a.HoWo);
+        const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+        const int hi = a.s * ho, wi = a.s * wo;
+        row = (img * a.Hi + hi) * a.Wi + wi;
+        if constexpr (CONV3) {
+          const unsigned rowm = (hi > 0 ? 1u : 0u) | 2u | (hi + 1 < a.Hi ? 4u : 0u);
+          const unsigned colm = (wi > 0 ? 1u : 0u) | 2u | (wi + 1 < a.Wi ? 4u : 0u);
+          vmask[j] = ((rowm & 1u) ? colm : 0u) | ((rowm & 2u) ? colm << 3 : 0u) | ((rowm & 4u) ? colm << 6 : 0u);
+        }
+      }
+      xp[j] = reinterpret_cast<const char*>(a.x) + row * (CONV3 ? a.C : a.K) * 2 + csw;
+    }
+#pragma unroll
+    for (int j = 0; j < WRB; ++j)
+      wp[j] = reinterpret_cast<const char*>(a.w) + (long long)(i_n0 + (wave * WRB + j) * 16 + lr) * a.K * 2 + csw;
+  };
+  auto issue = [&](int kt, int buf) {
+    char* sx = smem + buf * STAGE;
+    char* sw = sx + 2 * PX;
+    const int kb = kt * 128;
+    int tap = 0, xoff = kb;
+    if constexpr (CONV3) {
+      tap = kt >> a.cshift;
+      const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+      xoff = ((ky - 1) * a.Wi + (kx - 1)) * a.C * 2 + (kt - (tap << a.cshift)) * 128;
+    }
+#pragma unroll
+    for (int j = 0; j < XRB; ++j) {
+      const char* src = xp[j] + xoff;
+      if constexpr (CONV3) src = ((vmask[j] >> tap) & 1u) ? src : zp;
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + q * 64),
+                                         (__attribute__((address_space(3))) void*)(sx + q * PX + (wave * XRB + j) * 1024),
+                                         16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < WRB; ++j)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp[j] + kb + q * 64),
+                                         (__attribute__((address_space(3))) void*)(sw + q * PW + (wave * WRB + j) * 1024),
+                                         16, 0, 0);
+  };
+
+  const unsigned base = lds_offset(smem);
+  unsigned xa[MT][2], wa[2][2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int c = 2 * e + h;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = (wm * MT + mt) * 32 + r;
+      xa[mt][e] = base + row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int row = (wn * 2 + nt) * 32 + pi_row(r);
+      wa[nt][e] = base + 2 * PX + row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
+    }
+  }
+  f32x16 acc[MT][2];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+
+  setup_tile(t_issue);
+  long long c_m0 = i_m0;             // compute side: the tile being multiplied
+  int c_n0 = i_n0, c_kt = 0;
+  issue(0, 0);
+  i_kt = 1;
+  Frags<MT> f;
+  for (long long item = 0; item < n_items; ++item) {
+    const int buf = (int)(item & 1);
+    long long n_m0 = c_m0;           // the tile of item + 1 (compute side takes it over after an epilogue)
+    int n_n0 = c_n0;
+    if (item + 1 < n_items) {
+      if (i_kt == nk) {              // next item opens the next tile
+        ++t_issue;
+        setup_tile(t_issue);
+        i_kt = 0;
+      }
+      n_m0 = i_m0; n_n0 = i_n0;
+      issue(i_kt, buf ^ 1);
+      ++i_kt;
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");      // my part of this item has landed; item + 1 in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    read_stage<MT, PX, PW>(f, xa, wa, buf * STAGE);
+    mfma_stage<MT, true>(acc, f);
+    __builtin_amdgcn_s_barrier();       // every wave has read this buffer before the DMA after next overwrites it
+    if (++c_kt == nk) {
+      store_tile<MT>(a, acc, c_m0 + wm * MT * 32 + r, c_n0 + wn * 64 + 16 * h);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+      c_kt = 0;
+      c_m0 = n_m0; c_n0 = n_n0;
+    }
+  }
+}
+
+template <int BN, int MT, bool CONV3>
+int launch_persist(const GemmArgs& a, hipStream_t st) {
+  constexpr int BM = (4 / (BN / 64)) * MT * 32;
+  constexpr int LDS = 2 * 2 * (BM * 64 + BN * 64);
+  static bool done[64] = {};
+  if (!reserve_lds((const void*)gemm_nt_persist_kernel<BN, MT, CONV3>, LDS, done))
+    return fail(DSKD_ERR_LAUNCH, "dskd_gemm_nt: cannot reserve %d bytes of LDS", LDS);
+  const long long tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
+  const long long grid = tiles < 768 ? tiles : 768;       // 3 resident workgroups (48 KB of LDS each) on each of 256 CUs
+  hipLaunchKernelGGL((gemm_nt_persist_kernel<BN, MT, CONV3>), dim3((unsigned)grid), dim3(256), LDS, st, a, tiles);
+  return check_launch("dskd_gemm_nt/persistent");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The MFMA-bound shapes (K >= 256: ResNet stages 3-4, the ChannelMapper, every 3x3 convolution): big tiles.
+//
+// What bounds gemm_nt_kernel there (profiles/r03_conv1x1_microbench.txt, r04_gemm_big_microbench.txt): a 64 x 128 tile
+// pulls (64 + 128) rows x 128 B = 24 KB through LDS-DMA per K stage for 1.05 MFLOP; at 510-580 TFLOP/s that is 12-15 TB/s of
+// L2 -> LDS fill, i.e. the chip's gather-into-LDS rate (MI355X_MICROARCH.md "Indexed rows": 16.8-18.8 TB/s), not the
+// matrix pipe (busy 24 %).  Fill bytes per FLOP fall with the tile: 256 x 128 needs 11.7 KB / MFLOP, 256 x 256 7.8.
+//   * workgroup = WM x WN waves, every wave 64 tokens x 64 outputs (2 x 2 accumulator tiles, 1 KB of fragment reads per
+//     MFMA), tile 64 WM x 64 WN; NS LDS stages of K = 64 with the LDS-DMA NS - 1 stages ahead and ONE barrier per stage
+//     (the barrier that publishes stage k also retires the reads of stage k - 1, whose buffer the next DMA overwrites);
+//   * a big tile means few tiles (132 .. 1 056 for 256 CUs): the last, partial round of the grid would idle most of the
+//     chip.  The host cuts the tile list at a multiple of the resident workgroups: the first `full` tiles are whole
+//     workgroups, each remaining tile is split along K over `splits` workgroups that store f32 partial tiles into the
+//     caller's scratch; gemm_fixup_kernel sums them and applies the epilogue (no inter-workgroup hand-off inside a
+//     launch, no atomics: deterministic);
+//   * epilogue through LDS: the accumulators (lane = token, 16 channels) are turned in a per-wave f32 scratch so that
+//     8 lanes cover the 128 contiguous bytes of one token's 64 outputs -- residual / gate are read and the result is
+//     stored as whole 128-B lines (gemm_nt_kernel's lanes touch 32 rows x 16 B per instruction).
+struct BigPlan {
+  int full;          // work items [0, full): whole tiles (a multiple of 8, or all)
+  int splits;        // each tile >= full is cut into `splits` K ranges (1: stored directly)
+  float* planes;     // [tiles - full][splits][BM * BN] f32 partial tiles (splits > 1)
+};
+
+__device__ __forceinline__ void lds_write4(unsigned addr, const f32x16& v, int q) {
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}) : "memory");
+}
+
+// rows [row0, row0 + 32) x 64 outputs of one wave: acc[nt][i] = token (lane & 31), output 32 nt + 16 (lane >> 5) + i.
+// `scr`: this wave's 32 x 272-byte LDS scratch.  PARTIAL: f32 to `dst_f32` (row stride ldp floats), no epilogue.
+template <bool PARTIAL>
+__device__ __forceinline__ void store_rows32(const GemmArgs& a, const f32x16 (&acc)[2], unsigned scr, long long m_first,
+                                             int n_first, float* dst_f32, int ldp, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) lds_write4(scr + r * 272 + (nt * 32 + 16 * h + 4 * q) * 4, acc[nt], q);
+  const int row = lane >> 3, ch = lane & 7;
+  const int n = n_first + ch * 8;
+  float bias[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) bias[i] = 0.f;
+  if (!PARTIAL && a.bias) {
+    const bf16x8 b = *reinterpret_cast<const bf16x8*>(a.bias + n);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bias[i] = (float)b[i];
+  }
+  f32x4 v0[4], v1[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const unsigned ad = scr + (it * 8 + row) * 272 + ch * 32;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v0[it]) : "v"(ad) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(v1[it]) : "v"(ad) : "memory");
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0[0]), "+v"(v0[1]), "+v"(v0[2]), "+v"(v0[3]), "+v"(v1[0]), "+v"(v1[1]), "+v"(v1[2]),
+               "+v"(v1[3])::"memory");
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const long long m = m_first + it * 8 + row;
+    if (m >= a.M) continue;
+    float v[8] = {v0[it].x, v0[it].y, v0[it].z, v0[it].w, v1[it].x, v1[it].y, v1[it].z, v1[it].w};
+    if constexpr (PARTIAL) {
+      float* dp = dst_f32 + (long long)(it * 8 + row) * ldp + ch * 8;
+      *reinterpret_cast<f32x4*>(dp) = v0[it];
+      *reinterpret_cast<f32x4*>(dp + 4) = v1[it];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += bias[i];
+      if (a.res) {
+        const bf16x8 rr = *reinterpret_cast<const bf16x8*>(a.res + m * a.N + n);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += (float)rr[i];
+      }
+      if (a.gate) {
+        const bf16x8 gg = *reinterpret_cast<const bf16x8*>(a.gate + m * a.N + n);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)gg[i] > 0.f ? v[i] : 0.f;
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = (__bf16)(a.relu ? fmaxf(v[i], 0.f) : v[i]);
+      *reinterpret_cast<bf16x8*>(a.y + m * a.N + n) = o;
+    }
+  }
+}
+
+template <int WM, int WN, int NS, bool CONV3>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_big_kernel(const GemmArgs a, const BigPlan p) {
+  constexpr int WAVES = WM * WN, BM = 64 * WM, BN = 64 * WN;
+  constexpr int XRB = 4 / WN, WRB = 4 / WM;          // 16-row blocks per wave and operand
+  static_assert(XRB * WN == 4 && WRB * WM == 4, "WM, WN in {1, 2, 4}");
+  constexpr int PX = BM * 64, PW = BN * 64;          // bytes of one 32-k panel
+  constexpr int STAGE = 2 * (PX + PW);
+  constexpr int LOADS = 2 * (XRB + WRB);             // LDS-DMA instructions per wave and stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int wn = wave % WN, wm = wave / WN;
+  const int tiles_n = a.N / BN;
+  const int nk = a.K >> 6;
+
+  int tile, ks0 = 0, ks1 = nk, sp = 0;
+  const int b = blockIdx.x;
+  const bool partial = p.splits > 1 && b >= p.full;
+  if (b < p.full) {
+    tile = xcd_remap(b, p.full);
+  } else {
+    const int rb = b - p.full;
+    tile = p.full + rb / p.splits;
+    sp = rb - (rb / p.splits) * p.splits;
+    ks0 = (int)((long long)sp * nk / p.splits);
+    ks1 = (int)((long long)(sp + 1) * nk / p.splits);
+  }
+  const int tn = tile % tiles_n;
+  const long long tm = tile / tiles_n;
+  const long long m0 = tm * BM;
+  const int n0 = tn * BN;
+
+  // ---- per-lane source pointers of the LDS-DMA: lane i of an instruction fills row (i >> 2), chunk position (i & 3)
+  const int lr = lane >> 2;
+  const int csw = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;
+  const char* xp[XRB];
+  const char* wp[WRB];
+  unsigned vmask[XRB];
+#pragma unroll
+  for (int j = 0; j < XRB; ++j) {
+    long long m = m0 + (wave * XRB + j) * 16 + lr;
+    if (m >= a.M) m = a.M - 1;
+    long long row = m;
+    vmask[j] = 0x1FFu;
+    if (a.s) {
+      const long long img = m / a.HoWo;
+      const int rem = (int)(m - img * a.HoWo);
+      const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+      const int hi = a.s * ho, wi = a.s * wo;
+      row = (img * a.Hi + hi) * a.Wi + wi;
+      if constexpr (CONV3) {
+        const unsigned rowm = (hi > 0 ? 1u : 0u) | 2u | (hi + 1 < a.Hi ? 4u : 0u);
+        const unsigned colm = (wi > 0 ? 1u : 0u) | 2u | (wi + 1 < a.Wi ? 4u : 0u);
+        vmask[j] = ((rowm & 1u) ? colm : 0u) | ((rowm & 2u) ? colm << 3 : 0u) | ((rowm & 4u) ? colm << 6 : 0u);
+      }
+    }
+    xp[j] = reinterpret_cast<const char*>(a.x) + row * (CONV3 ? a.C : a.K) * 2 + csw;
+  }
+  const char* const zp = g_zero_page + csw;
+#pragma unroll
+  for (int j = 0; j < WRB; ++j)
+    wp[j] = reinterpret_cast<const char*>(a.w) + (long long)(n0 + (wave * WRB + j) * 16 + lr) * a.K * 2 + csw;
+
+  // LDS-DMA instructions [lo, hi) of the LOADS that bring in K stage kt (the bounds are constants after inlining)
+  auto issue = [&](int kt, int lo, int hi) {
+    char* sx = smem + ((kt - ks0) % NS) * STAGE;
+    char* sw = sx + 2 * PX;
+    const int kb = kt * 128;
+    int tap = 0, xoff = kb;
+    if constexpr (CONV3) {
+      tap = kt >> a.cshift;
+      const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+      xoff = ((ky - 1) * a.Wi + (kx - 1)) * a.C * 2 + (kt - (tap << a.cshift)) * 128;
+    }
+#pragma unroll
+    for (int j = 0; j < XRB; ++j) {
+      const char* src = xp[j] + xoff;
+      if constexpr (CONV3) src = ((vmask[j] >> tap) & 1u) ? src : zp;
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        if (2 * j + q >= lo && 2 * j + q < hi)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + q * 64),
+                                           (__attribute__((address_space(3))) void*)(sx + q * PX + (wave * XRB + j) * 1024),
+                                           16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < WRB; ++j)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        if (2 * XRB + 2 * j + q >= lo && 2 * XRB + 2 * j + q < hi)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp[j] + kb + q * 64),
+                                           (__attribute__((address_space(3))) void*)(sw + q * PW + (wave * WRB + j) * 1024),
+                                           16, 0, 0);
+  };
+  // all but my `n` youngest K stages have landed
+  auto wait_stages = [&](int n) {
+    if (n >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LOADS < 63 ? 3 * LOADS : 63) : "memory");
+    else if (n == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
+    else if (n == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+
+  const unsigned base = lds_offset(smem);
+  unsigned xa[2][2], wa[2][2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int c = 2 * e + h;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int row = (wm * 2 + mt) * 32 + r;
+      xa[mt][e] = base + row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int row = (wn * 2 + nt) * 32 + pi_row(r);
+      wa[nt][e] = base + 2 * PX + row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
+    }
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+
+  // ---- K loop.  The fragments of stage k + 1 are requested (second register set) BEFORE the last MFMA group of stage k,
+  // right behind the one barrier of the stage, and the LDS-DMA instructions of stage k + NS go out in three parts between
+  // the MFMA groups: first cut had barrier -> 6 DMA issues -> 16 fragment reads -> MFMAs in a row with both waves of a SIMD
+  // in the same phase, 2 200 - 2 400 cycles per stage for 1 024 cycles of MFMA (profiles/r04_gemm_big_phases.txt).
+  constexpr int P1 = LOADS / 3, P2 = 2 * LOADS / 3;
+  PROF(0);
+#pragma unroll
+  for (int i = 0; i < NS; ++i)
+    if (ks0 + i < ks1) issue(ks0 + i, 0, LOADS);
+  // fragment registers: k-steps 0 .. 2 of the stage in f (re-used by the next stage: its reads are requested when those
+  // MFMAs have been issued), k-step 3 alternates between t0 / t1 (still needed while the next stage's reads land)
+  Frags<2> f;
+  FragK t0, t1;
+  auto read_next = [&](FragK& t, unsigned so) {
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) f.w[ks][nt] = frag_read(wa[nt][ks & 1] + so + (ks >> 1) * PW);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) f.x[ks][mt] = frag_read(xa[mt][ks & 1] + so + (ks >> 1) * PX);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) t.w[nt] = frag_read(wa[nt][1] + so + PW);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) t.x[mt] = frag_read(xa[mt][1] + so + PX);
+  };
+  if (ks0 < ks1) {
+    wait_stages(min(NS - 1, ks1 - 1 - ks0));
+    __builtin_amdgcn_s_barrier();
+    PROF(1);
+    read_next(t0, 0);
+  }
+  auto body = [&](FragK& cur, FragK& nxt, int kt) {
+    const bool tail_dma = kt > ks0 && kt - 1 + NS < ks1;      // stage kt - 1 + NS: first part issued in the previous body
+    mfma_ks<0>(acc, f);
+    if (tail_dma) issue(kt - 1 + NS, P1, P2);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_ks<1>(acc, f);
+    if (tail_dma) issue(kt - 1 + NS, P2, LOADS);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_ks<2>(acc, f);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur.w[0]), "+v"(cur.w[1]), "+v"(cur.x[0]), "+v"(cur.x[1])::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < ks1) {
+      wait_stages(min(NS - 2, ks1 - 2 - kt));          // my part of stage kt + 1 has landed
+      __builtin_amdgcn_s_barrier();                    // everybody's has; everybody has read stage kt
+      read_next(nxt, ((kt + 1 - ks0) % NS) * STAGE);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.w[nt], cur.x[mt], acc[mt][nt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + NS < ks1) issue(kt + NS, 0, P1);          // ... into the buffer of stage kt (every wave is past the barrier)
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int kt = ks0; kt < ks1; kt += 2) {
+    body(t0, t1, kt);
+    if (kt + 1 < ks1) body(t1, t0, kt + 1);
+  }
+  PROF(2);
+  __builtin_amdgcn_s_barrier();           // the stage buffers become the epilogue's scratch
+  PROF(3);
+  const unsigned scr = base + wave * (32 * 272);
+  const long long m_w = m0 + wm * 64;
+  const int n_w = n0 + wn * 64;
+  if (partial) {
+    float* pl = p.planes + ((long long)(tile - p.full) * p.splits + sp) * (BM * BN) + (long long)(wm * 64) * BN + wn * 64;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) store_rows32<true>(a, acc[mt], scr, m_w + mt * 32, n_w, pl + (long long)mt * 32 * BN, BN, lane);
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) store_rows32<false>(a, acc[mt], scr, m_w + mt * 32, n_w, nullptr, 0, lane);
+  }
+#ifdef DSKD_GEMM_PROFILE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PROF(4);
+#endif
+}
+
+// Sum of the `splits` partial tiles of every split tile + the epilogue; one thread = 8 consecutive outputs of one token.
+__global__ __launch_bounds__(256) void gemm_fixup_kernel(const GemmArgs a, const BigPlan p, int BM, int BN) {
+  const int per_row = BN >> 3;
+  const int e = blockIdx.y * 256 + threadIdx.x;
+  if (e >= BM * per_row) return;
+  const int row = e / per_row, c8 = e - row * per_row;
+  const int tile = p.full + blockIdx.x;
+  const int tiles_n = a.N / BN;
+  const int tn = tile % tiles_n;
+  const long long m = (long long)(tile / tiles_n) * BM + row;
+  if (m >= a.M) return;
+  const int n = tn * BN + c8 * 8;
+  const float* pl = p.planes + (long long)blockIdx.x * p.splits * (BM * BN) + (long long)row * BN + c8 * 8;
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < p.splits; ++s) {
+    const f32x4 u0 = *reinterpret_cast<const f32x4*>(pl + (long long)s * BM * BN);
+    const f32x4 u1 = *reinterpret_cast<const f32x4*>(pl + (long long)s * BM * BN + 4);
+    v[0] += u0.x; v[1] += u0.y; v[2] += u0.z; v[3] += u0.w;
+    v[4] += u1.x; v[5] += u1.y; v[6] += u1.z; v[7] += u1.w;
+  }
+  if (a.bias) {
+    const bf16x8 bb = *reinterpret_cast<const bf16x8*>(a.bias + n);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += (float)bb[i];
+  }
+  if (a.res) {
+    const bf16x8 rr = *reinterpret_cast<const bf16x8*>(a.res + m * a.N + n);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += (float)rr[i];
+  }
+  if (a.gate) {
+    const bf16x8 gg = *reinterpret_cast<const bf16x8*>(a.gate + m * a.N + n);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)gg[i] > 0.f ? v[i] : 0.f;
+  }
+  bf16x8 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (__bf16)(a.relu ? fmaxf(v[i], 0.f) : v[i]);
+  *reinterpret_cast<bf16x8*>(a.y + m * a.N + n) = o;
+}
+
+// Tile configurations of gemm_big_kernel the host may pick (index = the `cfg` of dskd_gemm_debug_config).
+struct BigCfg {
+  int wm, wn, ns, occ;      // waves along tokens / outputs, LDS stages, resident workgroups per CU
+};
+constexpr int kBigCfgs = 6;
+__host__ inline const BigCfg& big_cfg(int i) {
+  static const BigCfg t[kBigCfgs] = {
+      {2, 2, 2, 2},      // 1: 128 x 128, 4 waves, 64 KB
+      {4, 2, 3, 1},      // 2: 256 x 128, 8 waves, 144 KB
+      {2, 4, 3, 1},      // 3: 128 x 256, 8 waves, 144 KB
+      {4, 1, 2, 2},      // 4: 256 x 64, 4 waves, 80 KB
+      {2, 2, 3, 1},      // 5: 128 x 128, 4 waves, 96 KB
+      {4, 2, 2, 1},      // 6: 256 x 128, 8 waves, 96 KB
+  };
+  return t[i];
+}
+
+template <int WM, int WN, int NS, bool CONV3>
+int launch_big(const GemmArgs& a, const BigPlan& p, long long items, hipStream_t st) {
+  constexpr int BM = 64 * WM, BN = 64 * WN, WAVES = WM * WN;
+  constexpr int stage = 2 * (BM * 64 + BN * 64);
+  constexpr int lds_pipe = NS * stage, lds_epi = WAVES * 32 * 272;
+  constexpr int LDS = lds_pipe > lds_epi ? lds_pipe : lds_epi;
+  static bool done[64] = {};
+  if (!reserve_lds((const void*)gemm_big_kernel<WM, WN, NS, CONV3>, LDS, done))
+    return fail(DSKD_ERR_LAUNCH, "dskd_gemm_nt: cannot reserve %d bytes of LDS", LDS);
+  hipLaunchKernelGGL((gemm_big_kernel<WM, WN, NS, CONV3>), dim3((unsigned)items), dim3(WAVES * 64), LDS, st, a, p);
+  return check_launch("dskd_gemm_nt/big");
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -549,46 +1150,161 @@ __global__ __launch_bounds__(256) void reduce_cvt_wide_kernel(const float* __res
 
 using namespace dskd;
 
+// ---- tile choice ---------------------------------------------------------------------------------------------------
+// cfg 0 = gemm_nt_kernel (64 x 128 / 128 x 64 tiles, 3 workgroups per CU), 1 .. kBigCfgs = big_cfg(cfg - 1).
+// dskd_gemm_nt_tune: a tuning hook for microbenchmarks and tests (scratch/r04_gemm_big.py) -- cfg < 0: automatic
+// (default); splits: 0 automatic, 1 never split, > 1 forced (clamped to the K stages and the scratch).
+static int g_tune_cfg = -1, g_tune_splits = 0;
+extern "C" int dskd_gemm_nt_tune(int cfg, int splits) {
+  if (cfg > kBigCfgs + 1) return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_nt_tune: cfg %d > %d", cfg, kBigCfgs + 1);
+  g_tune_cfg = cfg;
+  g_tune_splits = splits;
+  return DSKD_OK;
+}
+extern "C" int64_t dskd_gemm_nt_scratch_bytes(void) { return (int64_t)32 << 20; }
+#ifdef DSKD_GEMM_PROFILE
+extern "C" int dskd_gemm_nt_profile(void* buf) {      // 8 x int64 per workgroup of the next launches (NULL: off)
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_prof), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
+
+struct BigChoice {
+  int cfg;           // 0: gemm_nt_kernel
+  BigPlan plan;
+  long long items;   // workgroups of the main launch
+  int rem;           // split tiles (fixup grid), 0: no fixup launch
+  double t;          // modelled time, us
+};
+
+// Model of one launch (us).  Constants fitted to profiles/r04_gemm_big_microbench.txt: a CU sustains ~5.2 MFLOP/us of bf16
+// MFMA in these loops and ~62 KB/us of L2 -> LDS fill, whichever is slower paces a K stage; every tile pays a pipeline
+// fill (~1.6 us: the first stage's HBM round trip) and its epilogue at the CU's share of HBM bandwidth (~22 KB/us).
+static BigChoice model_cfg(int cfg, long long M, int N, int K, int epi_ops, bool conv3, int64_t scratch_bytes) {
+  BigChoice c{};
+  c.cfg = cfg;
+  c.t = 1e30;
+  int BM, BN, occ;
+  if (cfg == 0 || cfg == kBigCfgs + 1) {
+    BN = (N % 128) ? 64 : 128; BM = (N % 128) ? 128 : 64; occ = 3;
+  } else {
+    const BigCfg& g = big_cfg(cfg - 1);
+    BM = 64 * g.wm; BN = 64 * g.wn; occ = g.occ;
+  }
+  if (N % BN) return c;
+  const long long tiles = ((M + BM - 1) / BM) * (N / BN);
+  if (tiles > 0x3FFFFFFFll) return c;
+  const int nk = K >> 6;
+  const long long slots = 256ll * occ;
+  const double t_stage = occ * fmax(BM * (double)BN * 128.0 / 5.2e6, (BM + BN) * 128.0 / 62.0e3);
+  const double t_epi = occ * (BM * (double)BN * 2.0 * (1 + epi_ops)) / 22.0e3;
+  const double t_tile = 1.6 + nk * t_stage + t_epi;
+  const long long rounds = tiles / slots, R = tiles - rounds * slots;
+  c.plan.full = (int)tiles; c.plan.splits = 1; c.plan.planes = nullptr; c.items = tiles; c.rem = 0;
+  if (R == 0) { c.t = rounds * t_tile; return c; }
+  // last, partial round: R tiles on `slots` slots
+  const double alone = R <= 256 ? t_tile / occ * 1.15 : t_tile;      // fewer workgroups than CUs: each has a CU to itself
+  c.t = rounds * t_tile + alone;
+  if (cfg == 0 || cfg == kBigCfgs + 1 || g_tune_splits == 1) return c;
+  long long S = g_tune_splits > 1 ? g_tune_splits : slots / R;
+  if (S > nk) S = nk;
+  if (S > 32) S = 32;
+  while (S > 1 && R * S * BM * BN * 4ll > scratch_bytes) --S;
+  if (S <= 1) return c;
+  const double t_split = 1.6 + (double)((nk + S - 1) / S) * t_stage * (R * S <= 256 ? 1.0 / occ * 1.15 : 1.0) +
+                         occ * BM * (double)BN * 4.0 / 22.0e3 + 3.0;      // f32 partial tile out + the fixup launch
+  if (g_tune_splits > 1 || rounds * t_tile + t_split < c.t) {
+    c.t = rounds * t_tile + t_split;
+    c.plan.full = (int)(rounds * slots); c.plan.splits = (int)S; c.items = rounds * slots + R * S; c.rem = (int)R;
+  }
+  return c;
+}
+
+static BigChoice choose_cfg(long long M, int N, int K, int epi_ops, bool conv3, int64_t scratch_bytes) {
+  if (g_tune_cfg >= 0) return model_cfg(g_tune_cfg, M, N, K, epi_ops, conv3, scratch_bytes);
+  BigChoice best = model_cfg(0, M, N, K, epi_ops, conv3, scratch_bytes);
+  if (K < 256 || M < 2048) return best;       // thin K: one or two stages, the small tile's three workgroups per CU stream best
+  for (int cfg = 1; cfg <= kBigCfgs; ++cfg) {
+    const BigChoice c = model_cfg(cfg, M, N, K, epi_ops, conv3, scratch_bytes);
+    if (c.t < best.t) best = c;
+  }
+  return best;
+}
+
+template <bool CONV3>
+static int launch_choice(const GemmArgs& a, BigChoice c, void* scratch, hipStream_t st) {
+  if (c.cfg == kBigCfgs + 1) {
+    if (a.N % 128) return launch_persist<64, 1, CONV3>(a, st);
+    return launch_persist<128, 1, CONV3>(a, st);
+  }
+  if (c.cfg == 0) {
+    if (a.N % 128) return launch_gemm<64, 1, CONV3>(a, st);
+    // 64 tokens x 128 outputs per workgroup (each wave 32 x 64): measured faster than 128 x 128 of the same kernel on every
+    // layer shape of the trunk (scratch/r03_conv1x1.py) -- three workgroups per CU instead of two
+    return launch_gemm<128, 1, CONV3>(a, st);
+  }
+  c.plan.planes = (float*)scratch;
+  int rc;
+  switch (c.cfg) {
+    case 1: rc = launch_big<2, 2, 2, CONV3>(a, c.plan, c.items, st); break;
+    case 2: rc = launch_big<4, 2, 3, CONV3>(a, c.plan, c.items, st); break;
+    case 3: rc = launch_big<2, 4, 3, CONV3>(a, c.plan, c.items, st); break;
+    case 4: rc = launch_big<4, 1, 2, CONV3>(a, c.plan, c.items, st); break;
+    case 5: rc = launch_big<2, 2, 3, CONV3>(a, c.plan, c.items, st); break;
+    default: rc = launch_big<4, 2, 2, CONV3>(a, c.plan, c.items, st); break;
+  }
+  if (rc || c.rem == 0) return rc;
+  const BigCfg& g = big_cfg(c.cfg - 1);
+  const int BM = 64 * g.wm, BN = 64 * g.wn;
+  hipLaunchKernelGGL(gemm_fixup_kernel, dim3((unsigned)c.rem, (unsigned)((BM * (BN >> 3) + 255) / 256)), dim3(256), 0, st, a,
+                     c.plan, BM, BN);
+  return check_launch("dskd_gemm_nt/fixup");
+}
+
 static int gemm_nt_impl(const void* x, const void* w, const void* bias, const void* res, const void* gate, void* y,
                         int64_t M, int N, int K, int relu, int stride, int Ho, int Wo, int Hi, int Wi, int dtype,
-                        void* stream) {
+                        void* scratch, int64_t scratch_bytes, void* stream) {
   if (dtype != DSKD_DTYPE_BF16) return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_nt: bf16 only");
   if (!x || !w || !y || M < 0) return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_nt: null pointer or negative row count");
   if (N <= 0 || K <= 0 || (N & 63) || (K & 63))
     return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_nt: N and K must be positive multiples of 64 (got N=%d K=%d)", N, K);
   auto mis = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
-  if (mis(x) || mis(w) || mis(y) || (bias && mis(bias)) || (res && mis(res)) || (gate && mis(gate)))
+  if (mis(x) || mis(w) || mis(y) || (bias && mis(bias)) || (res && mis(res)) || (gate && mis(gate)) || (scratch && mis(scratch)))
     return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_nt: pointers must be 16-byte aligned");
   if (stride < 0 || (stride > 0 && (Ho <= 0 || Wo <= 0 || Hi <= 0 || Wi <= 0 || M % ((int64_t)Ho * Wo) != 0 ||
                                     (int64_t)stride * (Ho - 1) >= Hi || (int64_t)stride * (Wo - 1) >= Wi)))
     return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_nt: bad row map (stride=%d Ho=%d Wo=%d Hi=%d Wi=%d)", stride, Ho, Wo, Hi, Wi);
+  if (scratch_bytes < 0) return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_nt: negative scratch size");
   if (M == 0) return DSKD_OK;
   GemmArgs a;
   a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = (const __bf16*)bias; a.res = (const __bf16*)res;
   a.gate = (const __bf16*)gate;
   a.y = (__bf16*)y; a.M = M; a.N = N; a.K = K; a.relu = relu;
   a.s = stride; a.HoWo = stride ? Ho * Wo : 1; a.Wo = stride ? Wo : 1; a.Hi = Hi; a.Wi = Wi;
-  hipStream_t st = (hipStream_t)stream;
   a.C = K; a.cshift = 0;
-  if (N % 128) return launch_gemm<64, 1, false>(a, st);
-  // 64 tokens x 128 outputs per workgroup (each wave 32 x 64): measured faster than 128 x 128 on every layer shape of the
-  // trunk (one model forward 1.20 against 1.32 ms, scratch/r03_conv1x1.py) -- three workgroups per CU instead of two, and
-  // the deep layers (4 200 .. 16 800 tokens: 132 .. 1 056 tiles of 128 x 128 for 256 CUs) load the CUs more evenly.
-  return launch_gemm<128, 1, false>(a, st);
+  const BigChoice c = choose_cfg(M, N, K, (res ? 1 : 0) + (gate ? 1 : 0), false, scratch ? scratch_bytes : 0);
+  if (c.t >= 1e30) return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_nt: tile configuration %d cannot take N=%d", c.cfg, N);
+  return launch_choice<false>(a, c, scratch, (hipStream_t)stream);
 }
 
 extern "C" int dskd_gemm_nt(const void* x, const void* w, const void* bias, const void* res, void* y, int64_t M, int N, int K,
                             int relu, int stride, int Ho, int Wo, int Hi, int Wi, int dtype, void* stream) {
-  return gemm_nt_impl(x, w, bias, res, nullptr, y, M, N, K, relu, stride, Ho, Wo, Hi, Wi, dtype, stream);
+  return gemm_nt_impl(x, w, bias, res, nullptr, y, M, N, K, relu, stride, Ho, Wo, Hi, Wi, dtype, nullptr, 0, stream);
 }
 
 extern "C" int dskd_gemm_nt_dx(const void* g, const void* wt, const void* res, const void* gate, void* y, int64_t M, int N,
                                int K, int dtype, void* stream) {
-  return gemm_nt_impl(g, wt, nullptr, res, gate, y, M, N, K, 0, 0, 0, 0, 0, 0, dtype, stream);
+  return gemm_nt_impl(g, wt, nullptr, res, gate, y, M, N, K, 0, 0, 0, 0, 0, 0, dtype, nullptr, 0, stream);
+}
+
+extern "C" int dskd_gemm_nt_ws(const void* x, const void* w, const void* bias, const void* res, const void* gate, void* y,
+                               int64_t M, int N, int K, int relu, int stride, int Ho, int Wo, int Hi, int Wi, int dtype,
+                               void* scratch, int64_t scratch_bytes, void* stream) {
+  return gemm_nt_impl(x, w, bias, res, gate, y, M, N, K, relu, stride, Ho, Wo, Hi, Wi, dtype, scratch, scratch_bytes, stream);
 }
 
 static int conv3x3_impl(const void* x, const void* w, const void* bias, const void* res, const void* gate, void* y, int B,
-                        int Hi, int Wi, int C, int N, int stride, int relu, int dtype, void* stream) {
+                        int Hi, int Wi, int C, int N, int stride, int relu, int dtype, void* scratch, int64_t scratch_bytes,
+                        void* stream) {
   if (dtype != DSKD_DTYPE_BF16) return fail(DSKD_ERR_INVALID_ARG, "dskd_conv3x3: bf16 only");
   if (!x || !w || !y || B < 0 || Hi <= 0 || Wi <= 0) return fail(DSKD_ERR_INVALID_ARG, "dskd_conv3x3: null pointer or bad size");
   int cshift = 0;
@@ -597,8 +1313,9 @@ static int conv3x3_impl(const void* x, const void* w, const void* bias, const vo
     return fail(DSKD_ERR_INVALID_ARG, "dskd_conv3x3: C must be 64 * 2^k (<= 1024) and N a multiple of 64 (got C=%d N=%d)", C, N);
   if (stride != 1 && stride != 2) return fail(DSKD_ERR_INVALID_ARG, "dskd_conv3x3: stride 1 or 2 (got %d)", stride);
   auto mis = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
-  if (mis(x) || mis(w) || mis(y) || (bias && mis(bias)) || (res && mis(res)) || (gate && mis(gate)))
+  if (mis(x) || mis(w) || mis(y) || (bias && mis(bias)) || (res && mis(res)) || (gate && mis(gate)) || (scratch && mis(scratch)))
     return fail(DSKD_ERR_INVALID_ARG, "dskd_conv3x3: pointers must be 16-byte aligned");
+  if (scratch_bytes < 0) return fail(DSKD_ERR_INVALID_ARG, "dskd_conv3x3: negative scratch size");
   const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;        // kernel 3, padding 1
   if ((long long)Hi * Wi * C * 2 >= 0x7FFFFFFFll) return fail(DSKD_ERR_INVALID_ARG, "dskd_conv3x3: image too large");
   if (B == 0) return DSKD_OK;
@@ -607,19 +1324,25 @@ static int conv3x3_impl(const void* x, const void* w, const void* bias, const vo
   a.gate = (const __bf16*)gate;
   a.y = (__bf16*)y; a.M = (long long)B * Ho * Wo; a.N = N; a.K = 9 * C; a.relu = relu;
   a.s = stride; a.HoWo = Ho * Wo; a.Wo = Wo; a.Hi = Hi; a.Wi = Wi; a.C = C; a.cshift = cshift;
-  hipStream_t st = (hipStream_t)stream;
-  if (N % 128) return launch_gemm<64, 1, true>(a, st);
-  return launch_gemm<128, 1, true>(a, st);
+  const BigChoice c = choose_cfg(a.M, N, a.K, (res ? 1 : 0) + (gate ? 1 : 0), true, scratch ? scratch_bytes : 0);
+  if (c.t >= 1e30) return fail(DSKD_ERR_INVALID_ARG, "dskd_conv3x3: tile configuration %d cannot take N=%d", c.cfg, N);
+  return launch_choice<true>(a, c, scratch, (hipStream_t)stream);
 }
 
 extern "C" int dskd_conv3x3(const void* x, const void* w, const void* bias, const void* res, void* y, int B, int Hi, int Wi,
                             int C, int N, int stride, int relu, int dtype, void* stream) {
-  return conv3x3_impl(x, w, bias, res, nullptr, y, B, Hi, Wi, C, N, stride, relu, dtype, stream);
+  return conv3x3_impl(x, w, bias, res, nullptr, y, B, Hi, Wi, C, N, stride, relu, dtype, nullptr, 0, stream);
 }
 
 extern "C" int dskd_conv3x3_dx(const void* g, const void* wt, const void* gate, void* y, int B, int Hi, int Wi, int C, int N,
                                int dtype, void* stream) {
-  return conv3x3_impl(g, wt, nullptr, nullptr, gate, y, B, Hi, Wi, C, N, 1, 0, dtype, stream);
+  return conv3x3_impl(g, wt, nullptr, nullptr, gate, y, B, Hi, Wi, C, N, 1, 0, dtype, nullptr, 0, stream);
+}
+
+extern "C" int dskd_conv3x3_ws(const void* x, const void* w, const void* bias, const void* res, const void* gate, void* y, int B,
+                               int Hi, int Wi, int C, int N, int stride, int relu, int dtype, void* scratch,
+                               int64_t scratch_bytes, void* stream) {
+  return conv3x3_impl(x, w, bias, res, gate, y, B, Hi, Wi, C, N, stride, relu, dtype, scratch, scratch_bytes, stream);
 }
 
 static int gemm_tn_plan(const void* g, const void* x, const void* c, int64_t M, int N, int K, int ldg, int ldx, int dtype,

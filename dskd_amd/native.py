@@ -58,6 +58,10 @@ _SIGNATURES = {
     "dskd_colsum_short": (C.c_int, [_vp, _vp, _i64, C.c_int, C.c_int, _vp]),
     "dskd_gemm_nt_dx": (C.c_int, [_vp] * 5 + [_i64] + [C.c_int] * 3 + [_vp]),
     "dskd_conv3x3_dx": (C.c_int, [_vp] * 4 + [C.c_int] * 6 + [_vp]),
+    "dskd_gemm_nt_scratch_bytes": (_i64, []),
+    "dskd_gemm_nt_ws": (C.c_int, [_vp] * 6 + [_i64] + [C.c_int] * 9 + [_vp, _i64, _vp]),
+    "dskd_conv3x3_ws": (C.c_int, [_vp] * 6 + [C.c_int] * 8 + [_vp, _i64, _vp]),
+    "dskd_gemm_nt_tune": (C.c_int, [C.c_int, C.c_int]),
     "dskd_gemm_tn": (C.c_int, [_vp] * 3 + [_i64] + [C.c_int] * 5 + [_vp]),
     "dskd_cvt_clear": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp]),
     "dskd_gemm_tn_scratch_bytes": (_i64, [_i64, C.c_int, C.c_int]),
@@ -333,6 +337,7 @@ def graph_pins(device):
     return [t for t in (_msda_ws_cache.get(device), _drop_epochs.get(device)) if t is not None] + \
         [t for k, t in _tn_acc.items() if k[2] == device] + [t for k, t in _acc_cache.items() if k[1] == device] + \
         [t for d, t in _tn_scratch.items() if d == device] + \
+        [t for (d, _), t in _gemm_ws_cache.items() if d == device.index] + \
         [t for pre in set(_prepacked.values()) for t in pre.pins() if t.device == device]
 
 
@@ -869,12 +874,32 @@ def gemm_nt_2d(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], r
     return gemm_nt_raw(x, w, bias, None, x.shape[0], w.shape[0], w.shape[1], relu, y)
 
 
-def gemm_nt_raw(x, w2d, bias, res, M, N, K, relu, out, stride=0, Ho=0, Wo=0, Hi=0, Wi=0):
-    """``out[M, N] = act(x[M, K] w2d[N, K]^T + bias (+ res))`` -- raw launch of dskd_gemm_nt (bf16, no autograd)."""
-    rc = load().dskd_gemm_nt(x.data_ptr(), w2d.data_ptr(), None if bias is None else bias.data_ptr(),
-                             None if res is None else res.data_ptr(), out.data_ptr(), M, N, K, 1 if relu else 0, stride,
-                             Ho, Wo, Hi, Wi, DTYPE_BF16, _stream(x))
-    _check(rc, "dskd_gemm_nt")
+_gemm_ws_cache = {}
+
+
+def _gemm_scratch(t: torch.Tensor):
+    """(pointer, bytes) of the split-K scratch of dskd_gemm_nt_ws / dskd_conv3x3_ws for the CURRENT stream of ``t``'s device:
+    one buffer per (device, stream) -- the teacher's stream and the training stream run convolutions side by side.  The
+    partial tiles live only between the two launches of one call.  A stream first seen during a hipGraph capture gets no
+    scratch (NULL: the library then never splits; same results, the last round of the grid is just emptier)."""
+    key = (t.device.index, torch.cuda.current_stream(t.device).cuda_stream)
+    ws = _gemm_ws_cache.get(key)
+    if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None, 0
+        ws = _gemm_ws_cache[key] = torch.empty(int(load().dskd_gemm_nt_scratch_bytes()), dtype=torch.uint8, device=t.device)
+    return ws.data_ptr(), ws.numel()
+
+
+def gemm_nt_raw(x, w2d, bias, res, M, N, K, relu, out, stride=0, Ho=0, Wo=0, Hi=0, Wi=0, gate=None):
+    """``out[M, N] = act(x[M, K] w2d[N, K]^T + bias (+ res))``, zeroed where ``gate <= 0`` -- raw launch of dskd_gemm_nt_ws
+    (bf16, no autograd)."""
+    ws, ws_bytes = _gemm_scratch(x)
+    rc = load().dskd_gemm_nt_ws(x.data_ptr(), w2d.data_ptr(), None if bias is None else bias.data_ptr(),
+                                None if res is None else res.data_ptr(), None if gate is None else gate.data_ptr(),
+                                out.data_ptr(), M, N, K, 1 if relu else 0, stride, Ho, Wo, Hi, Wi, DTYPE_BF16, ws, ws_bytes,
+                                _stream(x))
+    _check(rc, "dskd_gemm_nt_ws")
     global _ffn_flops
     _ffn_flops += 2 * M * N * K
     return out
@@ -1021,17 +1046,19 @@ def conv3x3_ok(x: torch.Tensor, w: torch.Tensor, conv) -> bool:
             and x.shape[2] * x.shape[3] * Cin * 2 < 2 ** 31 - 1)
 
 
-def conv3x3_raw(x, w, bias, res, relu, stride, out=None):
-    """Raw launch of dskd_conv3x3 (no autograd): x [B, C, H, W] channels_last, w [N, C, 3, 3] channels_last."""
+def conv3x3_raw(x, w, bias, res, relu, stride, out=None, gate=None):
+    """Raw launch of dskd_conv3x3_ws (no autograd): x [B, C, H, W] channels_last, w [N, C, 3, 3] channels_last."""
     B, Cin, H, W = x.shape
     N = w.shape[0]
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     if out is None:
         out = torch.empty((B, N, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-    rc = load().dskd_conv3x3(x.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(),
-                             None if res is None else res.data_ptr(), out.data_ptr(), B, H, W, Cin, N, stride,
-                             1 if relu else 0, DTYPE_BF16, _stream(x))
-    _check(rc, "dskd_conv3x3")
+    ws, ws_bytes = _gemm_scratch(x)
+    rc = load().dskd_conv3x3_ws(x.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(),
+                                None if res is None else res.data_ptr(), None if gate is None else gate.data_ptr(),
+                                out.data_ptr(), B, H, W, Cin, N, stride, 1 if relu else 0, DTYPE_BF16, ws, ws_bytes,
+                                _stream(x))
+    _check(rc, "dskd_conv3x3_ws")
     global _ffn_flops
     _ffn_flops += 2 * B * Ho * Wo * N * 9 * Cin
     return out
@@ -1084,27 +1111,14 @@ def conv3x3(x, w, bias=None, identity=None, relu=False, stride=1):
 
 # --------------------------------------------------------------------------- a whole Bottleneck, backward fused
 def gemm_nt_dx_raw(g, wt2d, res, gate, M, N, K, out):
-    """``out[M, N] = (gate > 0) ? g[M, K] wt2d[N, K]^T + res : 0`` -- raw launch of dskd_gemm_nt_dx (bf16, no autograd)."""
-    rc = load().dskd_gemm_nt_dx(g.data_ptr(), wt2d.data_ptr(), None if res is None else res.data_ptr(),
-                                None if gate is None else gate.data_ptr(), out.data_ptr(), M, N, K, DTYPE_BF16, _stream(g))
-    _check(rc, "dskd_gemm_nt_dx")
-    global _ffn_flops
-    _ffn_flops += 2 * M * N * K
-    return out
+    """``out[M, N] = (gate > 0) ? g[M, K] wt2d[N, K]^T + res : 0`` -- the input-gradient form of dskd_gemm_nt_ws."""
+    return gemm_nt_raw(g, wt2d, None, res, M, N, K, False, out, gate=gate)
 
 
 def conv3x3_dx_raw(g, wt, gate):
-    """``(gate > 0) ? conv3x3(g, wt, stride 1, padding 1) : 0`` -- raw launch of dskd_conv3x3_dx; wt [C_out_of_dx, C_in_of_dx,
-    3, 3] channels_last = the forward weight with the taps flipped and the channel roles swapped."""
-    B, Cin, H, W = g.shape
-    N = wt.shape[0]
-    out = torch.empty((B, N, H, W), dtype=g.dtype, device=g.device, memory_format=torch.channels_last)
-    rc = load().dskd_conv3x3_dx(g.data_ptr(), wt.data_ptr(), None if gate is None else gate.data_ptr(), out.data_ptr(),
-                                B, H, W, Cin, N, DTYPE_BF16, _stream(g))
-    _check(rc, "dskd_conv3x3_dx")
-    global _ffn_flops
-    _ffn_flops += 2 * B * H * W * N * 9 * Cin
-    return out
+    """``(gate > 0) ? conv3x3(g, wt, stride 1, padding 1) : 0`` -- the input-gradient form of dskd_conv3x3_ws; wt
+    [C_out_of_dx, C_in_of_dx, 3, 3] channels_last = the forward weight with the taps flipped and the channel roles swapped."""
+    return conv3x3_raw(g, wt, None, None, False, 1, gate=gate)
 
 
 def _rows(t):          # [B, C, H, W] channels_last -> its NHWC rows [B*H*W, C] (a view)
@@ -1128,8 +1142,10 @@ class _BottleneckFunction(torch.autograd.Function):
     backward written out so that what autograd would run as separate passes over the activations rides in the epilogue of
     the input-gradient GEMMs: the ReLU masks (``threshold_backward`` of y1, y2 and -- for a block fed by another block --
     of the block input) and the sum of the identity path's gradient with conv1's.  The returned input gradient is then
-    already masked by ``x > 0``; it is tagged with the pointer of ``x`` so that the producing block (whose output IS x)
-    skips its own mask -- masking twice is the same as once, so a lost tag costs a pass, never correctness."""
+    already masked by ``x > 0``; it is tagged with (pointer of ``x``, its own pointer, its version counter) so that the
+    producing block (whose output IS x) skips its own mask.  Masking twice is the same as once, so a lost tag costs a pass;
+    a tag that SURVIVES a sum would be wrong (autograd adds further consumers of x into the first-arrived gradient in
+    place, keeping the Python object): the version counter in the tag catches that, the sum is masked again."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, w3, b3, wd, bd, stride, dstride, x_is_relu):
@@ -1155,10 +1171,14 @@ class _BottleneckFunction(torch.autograd.Function):
     def backward(ctx, g):
         x, y1, y2, y, w1, w2, w3, wd = ctx.saved_tensors
         need = ctx.needs_input_grad
+        # the tag is honoured only on the very tensor it was put on, unmodified since: autograd sums several consumers of y
+        # IN PLACE into the first gradient that arrived (InputBuffer: old_var.add_(var) keeps the Python object and its
+        # attributes), which bumps the version counter -- a sum that contains an unmasked addend must be masked here
         tag = getattr(g, "_dskd_relu_masked", None)
+        masked = tag is not None and tag == (y.data_ptr(), g.data_ptr(), g._version)
         if not g.is_contiguous(memory_format=torch.channels_last):
             g = g.contiguous(memory_format=torch.channels_last)
-        g3 = g if tag == y.data_ptr() else torch.ops.aten.threshold_backward(g, y, 0)
+        g3 = g if masked else torch.ops.aten.threshold_backward(g, y, 0)
         B, Cin, H, W = x.shape
         P, N = w1.shape[0], w3.shape[0]
         Ho, Wo = y.shape[2], y.shape[3]
@@ -1208,7 +1228,7 @@ class _BottleneckFunction(torch.autograd.Function):
             gx = torch.empty_like(x)
             gemm_nt_dx_raw(g1, w1.reshape(P, Cin).t().contiguous(), gid, x if ctx.x_is_relu else None, B * H * W, Cin, P, gx)
             if ctx.x_is_relu:
-                gx._dskd_relu_masked = x.data_ptr()
+                gx._dskd_relu_masked = (x.data_ptr(), gx.data_ptr(), gx._version)
         return gx, gw1, gb1, gw2, gb2, gw3, gb3, gwd, gbd, None, None, None
 
 

@@ -452,6 +452,27 @@ int dskd_conv3x3_dx(const void* g, const void* wt, const void* gate, void* y, in
                     void* stream);
 
 /* ---------------------------------------------------------------------------
+ * The same four products with a caller-owned scratch buffer (r4): the general forms
+ *   dskd_gemm_nt_ws   y[M, N] = gate_relu(x[M, K] w[N, K]^T + bias + res)   (= dskd_gemm_nt / dskd_gemm_nt_dx)
+ *   dskd_conv3x3_ws   y       = gate_relu(conv3x3(x, w, stride) + bias + res)   (= dskd_conv3x3 / dskd_conv3x3_dx)
+ * with gate_relu(v) = relu ? max(v, 0) : v, zeroed where gate <= 0 (gate NULL: no mask).  For K >= 256 the library picks a
+ * big output tile (128 x 128 .. 256 x 128, csrc/gemm_nt.hip gemm_big_kernel) per layer shape; the tiles of the grid's
+ * last, partial round are then split along K over the idle CUs, which write f32 partial tiles into `scratch`
+ * (dskd_gemm_nt_scratch_bytes() bytes cover every shape; NULL / too small: no split) and a second launch sums them in a
+ * fixed order and applies the epilogue -- deterministic, nothing persistent inside the library.  One scratch per stream in
+ * flight.  Reference: the convolutions of mmdet/models/backbones/resnet.py:271-303 and necks/channel_mapper.py:90-100.
+ * dskd_gemm_nt_tune(cfg, splits): tuning hook of the microbenchmarks / tests (cfg < 0: automatic (default), 0: the small-tile
+ * kernel, 1..6: a fixed big tile; splits 0: automatic, 1: never, > 1: forced).
+ * ------------------------------------------------------------------------- */
+int64_t dskd_gemm_nt_scratch_bytes(void);
+int dskd_gemm_nt_ws(const void* x, const void* w, const void* bias, const void* res, const void* gate, void* y, int64_t M,
+                    int N, int K, int relu, int stride, int Ho, int Wo, int Hi, int Wi, int dtype, void* scratch,
+                    int64_t scratch_bytes, void* stream);
+int dskd_conv3x3_ws(const void* x, const void* w, const void* bias, const void* res, const void* gate, void* y, int B, int Hi,
+                    int Wi, int C, int N, int stride, int relu, int dtype, void* scratch, int64_t scratch_bytes, void* stream);
+int dskd_gemm_nt_tune(int cfg, int splits);
+
+/* ---------------------------------------------------------------------------
  * c[N, K] += g[M, N]^T x[M, K]  (bf16 in, f32 out; N, K multiples of 128): the weight gradient dW = dY^T X of an
  * nn.Linear / 1x1 convolution over M tokens -- what autograd's mm / convolution_backward compute for the transformer's
  * Linear layers (ext-mmcv FFN, MultiScaleDeformableAttention projections) and the Bottleneck's 1x1 convolutions

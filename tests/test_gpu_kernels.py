@@ -1474,6 +1474,64 @@ def test_fused_bottleneck_chain_vs_float_reference(Cin, P, H, W, stride, down):
     assert bool((guard == 5.0).all())
 
 
+@pytest.mark.parametrize("side_first", [True, False])
+def test_fused_bottleneck_output_with_a_second_consumer(side_first):
+    """A stage output y that feeds the next Bottleneck AND another consumer (the neck's lateral convolution, the feature
+    loss): autograd sums the two gradients of y, in place into whichever arrived first.  When the next block's tagged
+    ("already masked by y > 0") gradient arrives first the sum keeps the Python object and with it the tag: the
+    producer must mask again, because the other addend is not masked.  The side consumer is built before / after the
+    second block (both arrival orders) with a gradient that is large exactly where y == 0; compared with the unfused
+    chain on the same kernels (which always masks), input and weight gradients of the FIRST block."""
+    g = torch.Generator().manual_seed(11 + side_first)
+    B, Cin, P, H, W = 2, 256, 64, 19, 23
+    N = 4 * P
+
+    def mk(co, ci, k):
+        return (torch.randn(co, ci, k, k, generator=g) * (2.0 / (ci * k * k)) ** 0.5).bfloat16()
+
+    x = torch.randn(B, Cin, H, W, generator=g).relu().bfloat16()
+    blocks = [dict(w1=mk(P, Cin, 1), w2=mk(P, P, 3), w3=mk(N, P, 1)), dict(w1=mk(P, N, 1), w2=mk(P, P, 3), w3=mk(N, P, 1))]
+    for blk in blocks:
+        for k, co in (("b1", P), ("b2", P), ("b3", N)):
+            blk[k] = (torch.randn(co, generator=g) * 0.1 - (0.3 if k == "b3" else 0.0)).bfloat16()       # many zeros in y
+    up = torch.randn(B, N, H, W, generator=g).bfloat16()
+    side_w = (torch.randn(B, N, H, W, generator=g) * 4.0).bfloat16()
+
+    def run(fused):
+        cl = dict(memory_format=torch.channels_last)
+        xd = x.to(DEV).contiguous(**cl).requires_grad_(True)
+        leaves, hd, side, y_first = [xd], xd, None, None
+        for bi, blk in enumerate(blocks):
+            ws = {k: blk[k].to(DEV).contiguous(**cl).requires_grad_(True) for k in ("w1", "w2", "w3")}
+            bs = {k: blk[k].to(DEV) for k in ("b1", "b2", "b3")}
+            if bi == 0:
+                leaves += [ws["w1"], ws["w2"], ws["w3"]]
+            if bi == 1 and side_first:
+                side = (hd * side_w.to(DEV).contiguous(**cl)).float().sum()
+            if fused:
+                hd = native.bottleneck(hd, ws["w1"], bs["b1"], ws["w2"], bs["b2"], ws["w3"], bs["b3"], None, None, 1,
+                                       x_is_relu=True)
+            else:
+                o = native.conv1x1(hd, ws["w1"], bs["b1"], None, True, 1)
+                o = native.conv3x3(o, ws["w2"], bs["b2"], None, True, 1)
+                hd = native.conv1x1(o, ws["w3"], bs["b3"], hd, True, 1)
+            if bi == 0:
+                y_first = hd
+        if not side_first:
+            side = (y_first * side_w.to(DEV).contiguous(**cl)).float().sum()
+        total = (hd * up.to(DEV).contiguous(**cl)).float().sum() + side
+        return y_first.detach(), torch.autograd.grad(total, leaves)
+
+    y_f, g_f = run(True)
+    y_u, g_u = run(False)
+    assert torch.equal(y_f, y_u) and float((y_f == 0).float().mean()) > 0.2
+    xmask = (x.to(DEV) > 0)
+    for i, (a, u) in enumerate(zip(g_f, g_u)):
+        if i == 0:
+            u = u * xmask
+        assert _close(a, u.float().cpu(), 1.0e-2), (i, float((a.float() - u.float()).abs().max()), float(u.abs().max()))
+
+
 # --------------------------------------------------------------------------- weight-gradient GEMM (gemm_tn_kernel)
 @pytest.mark.parametrize("M,N,K", [(1024, 128, 128), (5000 + 37, 256, 384), (88892, 256, 256), (20011, 1024, 256),
                                    (16800, 256, 1024), (4200, 512, 2048)])
