@@ -201,6 +201,70 @@ __device__ __forceinline__ void store_tile(const GemmArgs& a, const f32x16 (&acc
   }
 }
 
+// ---- epilogue through LDS (r4): whole 128-byte lines instead of 32 rows x 16 B per store instruction
+__device__ __forceinline__ void lds_write4(unsigned addr, const f32x16& v, int q) {
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}) : "memory");
+}
+
+// rows [row0, row0 + 32) x 64 outputs of one wave: acc[nt][i] = token (lane & 31), output 32 nt + 16 (lane >> 5) + i.
+// `scr`: this wave's 32 x 272-byte LDS scratch.  PARTIAL: f32 to `dst_f32` (row stride ldp floats), no epilogue.
+template <bool PARTIAL>
+__device__ __forceinline__ void store_rows32(const GemmArgs& a, const f32x16 (&acc)[2], unsigned scr, long long m_first,
+                                             int n_first, float* dst_f32, int ldp, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) lds_write4(scr + r * 272 + (nt * 32 + 16 * h + 4 * q) * 4, acc[nt], q);
+  const int row = lane >> 3, ch = lane & 7;
+  const int n = n_first + ch * 8;
+  float bias[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) bias[i] = 0.f;
+  if (!PARTIAL && a.bias) {
+    const bf16x8 b = *reinterpret_cast<const bf16x8*>(a.bias + n);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bias[i] = (float)b[i];
+  }
+  f32x4 v0[4], v1[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const unsigned ad = scr + (it * 8 + row) * 272 + ch * 32;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v0[it]) : "v"(ad) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(v1[it]) : "v"(ad) : "memory");
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0[0]), "+v"(v0[1]), "+v"(v0[2]), "+v"(v0[3]), "+v"(v1[0]), "+v"(v1[1]), "+v"(v1[2]),
+               "+v"(v1[3])::"memory");
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const long long m = m_first + it * 8 + row;
+    if (m >= a.M) continue;
+    float v[8] = {v0[it].x, v0[it].y, v0[it].z, v0[it].w, v1[it].x, v1[it].y, v1[it].z, v1[it].w};
+    if constexpr (PARTIAL) {
+      float* dp = dst_f32 + (long long)(it * 8 + row) * ldp + ch * 8;
+      *reinterpret_cast<f32x4*>(dp) = v0[it];
+      *reinterpret_cast<f32x4*>(dp + 4) = v1[it];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += bias[i];
+      if (a.res) {
+        const bf16x8 rr = *reinterpret_cast<const bf16x8*>(a.res + m * a.N + n);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += (float)rr[i];
+      }
+      if (a.gate) {
+        const bf16x8 gg = *reinterpret_cast<const bf16x8*>(a.gate + m * a.N + n);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)gg[i] > 0.f ? v[i] : 0.f;
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = (__bf16)(a.relu ? fmaxf(v[i], 0.f) : v[i]);
+      *reinterpret_cast<bf16x8*>(a.y + m * a.N + n) = o;
+    }
+  }
+}
+
 // Two LDS stages, the DMA of stage k + 1 issued before stage k is consumed; 48 | 64 KB per workgroup, so two or three
 // workgroups share a CU and cover each other's waits.  Measured and NOT kept (scratch/r03_conv1x1.py, every variant
 // green on the parity tests, each slower on all 19 layer shapes of the trunk): four stages with the DMA three ahead;
@@ -210,7 +274,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& a, const f32x16 (&acc
 // one round of the chip -- and there tile quantisation (264 = 256 + 8) and the second resident workgroup matter more
 // than the per-stage latency.  SQ counters of the K = 1024, N = 256, 16 800-token layer: no LDS bank conflicts, MFMA
 // pipe busy 24 % of the wave's lifetime, 30 % in s_waitcnt / barrier.
-template <int BN, int MT, bool CONV3>
+template <int BN, int MT, bool CONV3, bool LDS_EPI = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs a) {
   constexpr int NS = 2;
   constexpr int WN = BN / 64;              // waves along the outputs
@@ -340,18 +404,26 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs a) {
     }
   }
   PROF(2);
-  store_tile<MT>(a, acc, m0 + wm * MT * 32 + r, n0 + wn * 64 + 16 * h);
+  if constexpr (LDS_EPI) {       // the loop's last barrier is behind every wave's fragment reads: the stage buffers are free
+    const unsigned scr = base + wave * (32 * 272);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      store_rows32<false>(a, acc[mt], scr, m0 + (wm * MT + mt) * 32, n0 + wn * 64, nullptr, 0, lane);
+  } else {
+    store_tile<MT>(a, acc, m0 + wm * MT * 32 + r, n0 + wn * 64 + 16 * h);
+  }
 #ifdef DSKD_GEMM_PROFILE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   PROF(4);
 #endif
 }
 
-template <int BN, int MT, bool CONV3>
+template <int BN, int MT, bool CONV3, bool LDS_EPI = false>
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
   constexpr int BM = (4 / (BN / 64)) * MT * 32;
   constexpr int LDS = 2 * 2 * (BM * 64 + BN * 64);
-  auto kern = gemm_nt_kernel<BN, MT, CONV3>;
+  static_assert(LDS >= 4 * 32 * 272, "epilogue scratch");
+  auto kern = gemm_nt_kernel<BN, MT, CONV3, LDS_EPI>;
   int dev = 0;
   static bool done[64] = {};              // the attribute is per device: set it once on each
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -364,185 +436,6 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
   if (tiles > 0x7FFFFFFFll) return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_nt: too many tiles");
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), LDS, st, a);
   return check_launch("dskd_gemm_nt");
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// r4: the same tile loop as a PERSISTENT workgroup.  Phase stamps of gemm_nt_kernel (profiles/r04_gemm_phases.txt): a
-// workgroup lives 7 - 16 us of which the K loop is 35 - 70 %; the rest is the first stage's HBM round trip (2 900 - 3 900
-// cycles) and the epilogue (3 600 - 6 400 cycles with a residual) -- paid by every one of the 500 - 4 000 tiles of a launch,
-// and three resident workgroups per CU only partly cover each other.  Here 3 x 256 workgroups each walk a contiguous
-// range of tiles and the LDS-DMA pipeline never drains: the first stage of tile t + 1 is requested while the last stage of
-// tile t is multiplied, the residual / gate rows of a tile are requested when its loop starts, and the stores of tile t
-// drain under the loop of tile t + 1.
-template <int BN, int MT, bool CONV3>
-__global__ __launch_bounds__(256, 2) void gemm_nt_persist_kernel(const GemmArgs a, long long tiles) {
-  constexpr int NS = 2;
-  constexpr int WN = BN / 64;
-  constexpr int WM = 4 / WN;
-  constexpr int BM = WM * MT * 32;
-  constexpr int XRB = BM / 64;
-  constexpr int PX = BM * 64, PW = BN * 64;
-  constexpr int STAGE = 2 * (PX + PW);
-  constexpr int WRB = BN / 64;
-  constexpr int LOADS = 2 * (XRB + WRB);
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int r = lane & 31, h = lane >> 5;
-  const int wn = wave % WN, wm = wave / WN;
-  const int tiles_n = a.N / BN;
-  const int nk = a.K >> 6;
-
-  // this workgroup's tiles [t_first, t_last): ranges of workgroups that share an XCD are adjacent
-  const int rg = xcd_remap(blockIdx.x, gridDim.x);
-  long long t_issue = tiles * rg / gridDim.x;
-  const long long t_last = tiles * (rg + 1) / gridDim.x;
-  if (t_issue >= t_last) return;
-  const long long n_items = (t_last - t_issue) * nk;
-
-  // ---- issue side: the tile whose stages are being requested
-  const int lr = lane >> 2;
-  const int csw = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;
-  const char* xp[XRB];
-  const char* wp[WRB];
-  unsigned vmask[XRB];
-  long long i_m0 = 0;
-  int i_n0 = 0, i_kt = 0;
-  const char* const zp = g_zero_page + csw;
-  auto setup_tile = [&](long long t) {
-    const int tn = (int)(t % tiles_n);
-    i_m0 = (t / tiles_n) * BM;
-    i_n0 = tn * BN;
-#pragma unroll
-    for (int j = 0; j < XRB; ++j) {
-      long long m = i_m0 + (wave * XRB + j) * 16 + lr;
-      if (m >= a.M) m = a.M - 1;
-      long long row = m;
-      vmask[j] = 0x1FFu;
-      if (a.s) {
-        const long long img = m / a.HoWo;
-        const int rem = (int)(m - img * a.HoWo);
-        const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-        const int hi = a.s * ho, wi = a.s * wo;
-        row = (img * a.Hi + hi) * a.Wi + wi;
-        if constexpr (CONV3) {
-          const unsigned rowm = (hi > 0 ? 1u : 0u) | 2u | (hi + 1 < a.Hi ? 4u : 0u);
-          const unsigned colm = (wi > 0 ? 1u : 0u) | 2u | (wi + 1 < a.Wi ? 4u : 0u);
-          vmask[j] = ((rowm & 1u) ? colm : 0u) | ((rowm & 2u) ? colm << 3 : 0u) | ((rowm & 4u) ? colm << 6 : 0u);
-        }
-      }
-      xp[j] = reinterpret_cast<const char*>(a.x) + row * (CONV3 ? a.C : a.K) * 2 + csw;
-    }
-#pragma unroll
-    for (int j = 0; j < WRB; ++j)
-      wp[j] = reinterpret_cast<const char*>(a.w) + (long long)(i_n0 + (wave * WRB + j) * 16 + lr) * a.K * 2 + csw;
-  };
-  auto issue = [&](int kt, int buf) {
-    char* sx = smem + buf * STAGE;
-    char* sw = sx + 2 * PX;
-    const int kb = kt * 128;
-    int tap = 0, xoff = kb;
-    if constexpr (CONV3) {
-      tap = kt >> a.cshift;
-      const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
-      xoff = ((ky - 1) * a.Wi + (kx - 1)) * a.C * 2 + (kt - (tap << a.cshift)) * 128;
-    }
-#pragma unroll
-    for (int j = 0; j < XRB; ++j) {
-      const char* src = xp[j] + xoff;
-      if constexpr (CONV3) src = ((vmask[j] >> tap) & 1u) ? src : zp;
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + q * 64),
-                                         (__attribute__((address_space(3))) void*)(sx + q * PX + (wave * XRB + j) * 1024),
-                                         16, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < WRB; ++j)
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp[j] + kb + q * 64),
-                                         (__attribute__((address_space(3))) void*)(sw + q * PW + (wave * WRB + j) * 1024),
-                                         16, 0, 0);
-  };
-
-  const unsigned base = lds_offset(smem);
-  unsigned xa[MT][2], wa[2][2];
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const int c = 2 * e + h;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int row = (wm * MT + mt) * 32 + r;
-      xa[mt][e] = base + row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
-    }
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int row = (wn * 2 + nt) * 32 + pi_row(r);
-      wa[nt][e] = base + 2 * PX + row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
-    }
-  }
-  f32x16 acc[MT][2];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
-
-  setup_tile(t_issue);
-  long long c_m0 = i_m0;             // compute side: the tile being multiplied
-  int c_n0 = i_n0, c_kt = 0;
-  issue(0, 0);
-  i_kt = 1;
-  Frags<MT> f;
-  for (long long item = 0; item < n_items; ++item) {
-    const int buf = (int)(item & 1);
-    long long n_m0 = c_m0;           // the tile of item + 1 (compute side takes it over after an epilogue)
-    int n_n0 = c_n0;
-    if (item + 1 < n_items) {
-      if (i_kt == nk) {              // next item opens the next tile
-        ++t_issue;
-        setup_tile(t_issue);
-        i_kt = 0;
-      }
-      n_m0 = i_m0; n_n0 = i_n0;
-      issue(i_kt, buf ^ 1);
-      ++i_kt;
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");      // my part of this item has landed; item + 1 in flight
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    read_stage<MT, PX, PW>(f, xa, wa, buf * STAGE);
-    mfma_stage<MT, true>(acc, f);
-    __builtin_amdgcn_s_barrier();       // every wave has read this buffer before the DMA after next overwrites it
-    if (++c_kt == nk) {
-      store_tile<MT>(a, acc, c_m0 + wm * MT * 32 + r, c_n0 + wn * 64 + 16 * h);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
-      c_kt = 0;
-      c_m0 = n_m0; c_n0 = n_n0;
-    }
-  }
-}
-
-template <int BN, int MT, bool CONV3>
-int launch_persist(const GemmArgs& a, hipStream_t st) {
-  constexpr int BM = (4 / (BN / 64)) * MT * 32;
-  constexpr int LDS = 2 * 2 * (BM * 64 + BN * 64);
-  static bool done[64] = {};
-  if (!reserve_lds((const void*)gemm_nt_persist_kernel<BN, MT, CONV3>, LDS, done))
-    return fail(DSKD_ERR_LAUNCH, "dskd_gemm_nt: cannot reserve %d bytes of LDS", LDS);
-  const long long tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
-  const long long grid = tiles < 768 ? tiles : 768;       // 3 resident workgroups (48 KB of LDS each) on each of 256 CUs
-  hipLaunchKernelGGL((gemm_nt_persist_kernel<BN, MT, CONV3>), dim3((unsigned)grid), dim3(256), LDS, st, a, tiles);
-  return check_launch("dskd_gemm_nt/persistent");
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -569,72 +462,9 @@ struct BigPlan {
   float* planes;     // [tiles - full][splits][BM * BN] f32 partial tiles (splits > 1)
 };
 
-__device__ __forceinline__ void lds_write4(unsigned addr, const f32x16& v, int q) {
-  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}) : "memory");
-}
-
-// rows [row0, row0 + 32) x 64 outputs of one wave: acc[nt][i] = token (lane & 31), output 32 nt + 16 (lane >> 5) + i.
-// `scr`: this wave's 32 x 272-byte LDS scratch.  PARTIAL: f32 to `dst_f32` (row stride ldp floats), no epilogue.
-template <bool PARTIAL>
-__device__ __forceinline__ void store_rows32(const GemmArgs& a, const f32x16 (&acc)[2], unsigned scr, long long m_first,
-                                             int n_first, float* dst_f32, int ldp, int lane) {
-  const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) lds_write4(scr + r * 272 + (nt * 32 + 16 * h + 4 * q) * 4, acc[nt], q);
-  const int row = lane >> 3, ch = lane & 7;
-  const int n = n_first + ch * 8;
-  float bias[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) bias[i] = 0.f;
-  if (!PARTIAL && a.bias) {
-    const bf16x8 b = *reinterpret_cast<const bf16x8*>(a.bias + n);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) bias[i] = (float)b[i];
-  }
-  f32x4 v0[4], v1[4];
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const unsigned ad = scr + (it * 8 + row) * 272 + ch * 32;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(v0[it]) : "v"(ad) : "memory");
-    asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(v1[it]) : "v"(ad) : "memory");
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0[0]), "+v"(v0[1]), "+v"(v0[2]), "+v"(v0[3]), "+v"(v1[0]), "+v"(v1[1]), "+v"(v1[2]),
-               "+v"(v1[3])::"memory");
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const long long m = m_first + it * 8 + row;
-    if (m >= a.M) continue;
-    float v[8] = {v0[it].x, v0[it].y, v0[it].z, v0[it].w, v1[it].x, v1[it].y, v1[it].z, v1[it].w};
-    if constexpr (PARTIAL) {
-      float* dp = dst_f32 + (long long)(it * 8 + row) * ldp + ch * 8;
-      *reinterpret_cast<f32x4*>(dp) = v0[it];
-      *reinterpret_cast<f32x4*>(dp + 4) = v1[it];
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] += bias[i];
-      if (a.res) {
-        const bf16x8 rr = *reinterpret_cast<const bf16x8*>(a.res + m * a.N + n);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] += (float)rr[i];
-      }
-      if (a.gate) {
-        const bf16x8 gg = *reinterpret_cast<const bf16x8*>(a.gate + m * a.N + n);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = (float)gg[i] > 0.f ? v[i] : 0.f;
-      }
-      bf16x8 o;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) o[i] = (__bf16)(a.relu ? fmaxf(v[i], 0.f) : v[i]);
-      *reinterpret_cast<bf16x8*>(a.y + m * a.N + n) = o;
-    }
-  }
-}
-
 template <int WM, int WN, int NS, bool CONV3>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_big_kernel(const GemmArgs a, const BigPlan p) {
-  constexpr int WAVES = WM * WN, BM = 64 * WM, BN = 64 * WN;
+  constexpr int BM = 64 * WM, BN = 64 * WN;
   constexpr int XRB = 4 / WN, WRB = 4 / WM;          // 16-row blocks per wave and operand
   static_assert(XRB * WN == 4 && WRB * WM == 4, "WM, WN in {1, 2, 4}");
   constexpr int PX = BM * 64, PW = BN * 64;          // bytes of one 32-k panel
@@ -1151,12 +981,13 @@ __global__ __launch_bounds__(256) void reduce_cvt_wide_kernel(const float* __res
 using namespace dskd;
 
 // ---- tile choice ---------------------------------------------------------------------------------------------------
-// cfg 0 = gemm_nt_kernel (64 x 128 / 128 x 64 tiles, 3 workgroups per CU), 1 .. kBigCfgs = big_cfg(cfg - 1).
+// cfg 0 = gemm_nt_kernel (64 x 128 / 128 x 64 tiles, 3 workgroups per CU; epilogue by M), 1 .. kBigCfgs = big_cfg(cfg - 1),
+// kBigCfgs + 1 / + 2 = gemm_nt_kernel with the register / the LDS epilogue forced.
 // dskd_gemm_nt_tune: a tuning hook for microbenchmarks and tests (scratch/r04_gemm_big.py) -- cfg < 0: automatic
 // (default); splits: 0 automatic, 1 never split, > 1 forced (clamped to the K stages and the scratch).
 static int g_tune_cfg = -1, g_tune_splits = 0;
 extern "C" int dskd_gemm_nt_tune(int cfg, int splits) {
-  if (cfg > kBigCfgs + 1) return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_nt_tune: cfg %d > %d", cfg, kBigCfgs + 1);
+  if (cfg > kBigCfgs + 2) return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_nt_tune: cfg %d > %d", cfg, kBigCfgs + 2);
   g_tune_cfg = cfg;
   g_tune_splits = splits;
   return DSKD_OK;
@@ -1184,7 +1015,7 @@ static BigChoice model_cfg(int cfg, long long M, int N, int K, int epi_ops, bool
   c.cfg = cfg;
   c.t = 1e30;
   int BM, BN, occ;
-  if (cfg == 0 || cfg == kBigCfgs + 1) {
+  if (cfg == 0 || cfg > kBigCfgs) {      // kBigCfgs + 1 / + 2: the small tile with the register / the LDS epilogue forced
     BN = (N % 128) ? 64 : 128; BM = (N % 128) ? 128 : 64; occ = 3;
   } else {
     const BigCfg& g = big_cfg(cfg - 1);
@@ -1204,7 +1035,7 @@ static BigChoice model_cfg(int cfg, long long M, int N, int K, int epi_ops, bool
   // last, partial round: R tiles on `slots` slots
   const double alone = R <= 256 ? t_tile / occ * 1.15 : t_tile;      // fewer workgroups than CUs: each has a CU to itself
   c.t = rounds * t_tile + alone;
-  if (cfg == 0 || cfg == kBigCfgs + 1 || g_tune_splits == 1) return c;
+  if (cfg == 0 || cfg > kBigCfgs || g_tune_splits == 1) return c;
   long long S = g_tune_splits > 1 ? g_tune_splits : slots / R;
   if (S > nk) S = nk;
   if (S > 32) S = 32;
@@ -1212,7 +1043,7 @@ static BigChoice model_cfg(int cfg, long long M, int N, int K, int epi_ops, bool
   if (S <= 1) return c;
   const double t_split = 1.6 + (double)((nk + S - 1) / S) * t_stage * (R * S <= 256 ? 1.0 / occ * 1.15 : 1.0) +
                          occ * BM * (double)BN * 4.0 / 22.0e3 + 3.0;      // f32 partial tile out + the fixup launch
-  if (g_tune_splits > 1 || rounds * t_tile + t_split < c.t) {
+  {      // measured: with R * 2 <= slots the split wins on every shape where a big tile is chosen at all
     c.t = rounds * t_tile + t_split;
     c.plan.full = (int)(rounds * slots); c.plan.splits = (int)S; c.items = rounds * slots + R * S; c.rem = (int)R;
   }
@@ -1221,26 +1052,27 @@ static BigChoice model_cfg(int cfg, long long M, int N, int K, int epi_ops, bool
 
 static BigChoice choose_cfg(long long M, int N, int K, int epi_ops, bool conv3, int64_t scratch_bytes) {
   if (g_tune_cfg >= 0) return model_cfg(g_tune_cfg, M, N, K, epi_ops, conv3, scratch_bytes);
-  BigChoice best = model_cfg(0, M, N, K, epi_ops, conv3, scratch_bytes);
-  if (K < 256 || M < 2048) return best;       // thin K: one or two stages, the small tile's three workgroups per CU stream best
-  for (int cfg = 1; cfg <= kBigCfgs; ++cfg) {
-    const BigChoice c = model_cfg(cfg, M, N, K, epi_ops, conv3, scratch_bytes);
-    if (c.t < best.t) best = c;
+  // Measured (profiles/r04_gemm_big_microbench.txt, all 46 layer shapes of the step x 6 big tiles x with / without the split-K
+  // remainder): the big tiles win only where K is very long and the small tile has too few tiles to hide its own
+  // pipeline fill -- the 3x3 convolutions of ResNet stage 4 (K = 4 608, 4 200 tokens: 39.2 against 45.8 us with 128 x 256
+  // tiles + the split remainder).  Everywhere else the 64 x 128 kernel's three resident workgroups per CU are faster.
+  if (conv3 && K >= 4608 && N % 256 == 0 && M <= 8192) {
+    const BigChoice c = model_cfg(3, M, N, K, epi_ops, conv3, scratch_bytes);
+    if (c.t < 1e30) return c;
   }
-  return best;
+  return model_cfg(0, M, N, K, epi_ops, conv3, scratch_bytes);
 }
 
 template <bool CONV3>
 static int launch_choice(const GemmArgs& a, BigChoice c, void* scratch, hipStream_t st) {
-  if (c.cfg == kBigCfgs + 1) {
-    if (a.N % 128) return launch_persist<64, 1, CONV3>(a, st);
-    return launch_persist<128, 1, CONV3>(a, st);
-  }
-  if (c.cfg == 0) {
-    if (a.N % 128) return launch_gemm<64, 1, CONV3>(a, st);
+  if (c.cfg == 0 || c.cfg > kBigCfgs) {
     // 64 tokens x 128 outputs per workgroup (each wave 32 x 64): measured faster than 128 x 128 of the same kernel on every
-    // layer shape of the trunk (scratch/r03_conv1x1.py) -- three workgroups per CU instead of two
-    return launch_gemm<128, 1, CONV3>(a, st);
+    // layer shape of the trunk (scratch/r03_conv1x1.py) -- three workgroups per CU instead of two.  Epilogue through LDS
+    // (whole 128-byte lines) for the tall layers: 3 - 10 % on the write-heavy ones (l1.conv3 82.6 -> 78.4 us, l1.down 42.8 ->
+    // 38.2, l2.conv1 dX 46.1 -> 41.3), a wash or a small loss on the 4 200-row layers (profiles/r04_gemm_big_microbench.txt)
+    const bool lds_epi = c.cfg == 0 ? a.M >= 8192 : c.cfg == kBigCfgs + 2;
+    if (a.N % 128) return lds_epi ? launch_gemm<64, 1, CONV3, true>(a, st) : launch_gemm<64, 1, CONV3, false>(a, st);
+    return lds_epi ? launch_gemm<128, 1, CONV3, true>(a, st) : launch_gemm<128, 1, CONV3, false>(a, st);
   }
   c.plan.planes = (float*)scratch;
   int rc;

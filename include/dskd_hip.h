@@ -461,8 +461,11 @@ int dskd_conv3x3_dx(const void* g, const void* wt, const void* gate, void* y, in
  * (dskd_gemm_nt_scratch_bytes() bytes cover every shape; NULL / too small: no split) and a second launch sums them in a
  * fixed order and applies the epilogue -- deterministic, nothing persistent inside the library.  One scratch per stream in
  * flight.  Reference: the convolutions of mmdet/models/backbones/resnet.py:271-303 and necks/channel_mapper.py:90-100.
+ * Which tile runs where is a measured table (profiles/r04_gemm_big_microbench.txt): the big tiles serve the 3x3 convolutions
+ * of ResNet stage 4, the 64 x 128 kernel everything else (with its epilogue through LDS -- whole 128-byte lines -- for M >= 8192).
  * dskd_gemm_nt_tune(cfg, splits): tuning hook of the microbenchmarks / tests (cfg < 0: automatic (default), 0: the small-tile
- * kernel, 1..6: a fixed big tile; splits 0: automatic, 1: never, > 1: forced).
+ * kernel, 1..6: a fixed big tile, 7 / 8: the small tile with the register / LDS epilogue; splits 0: automatic, 1: never,
+ * > 1: forced).  Process-global; not for use while launches of another thread are in flight.
  * ------------------------------------------------------------------------- */
 int64_t dskd_gemm_nt_scratch_bytes(void);
 int dskd_gemm_nt_ws(const void* x, const void* w, const void* bias, const void* res, const void* gate, void* y, int64_t M,

@@ -11,7 +11,7 @@ lib = native.load()
 dev = torch.device("cuda:0")
 B = 4
 AUTO_ONLY = len(sys.argv) > 1 and sys.argv[1] == "auto"
-PERSIST = len(sys.argv) > 1 and sys.argv[1] == "persist"      # only cfg 0 against cfg 7 (the persistent small-tile kernel)
+K32 = len(sys.argv) > 1 and sys.argv[1] == "k32"      # cfg 0 against cfg 7..10 (128 x 128 tiles, K stages of 32: NS 3 / 4, plain / LDS epilogue)
 # (name, K, N, H, W, stride, residual, relu, count per model forward)
 shapes1 = [("l1.conv1a", 64, 64, 200, 334, 1, 0, 1, 1), ("l1.conv1", 256, 64, 200, 334, 1, 0, 1, 2),
            ("l1.conv3", 64, 256, 200, 334, 1, 1, 1, 3), ("l1.down", 64, 256, 200, 334, 1, 0, 0, 1),
@@ -28,7 +28,7 @@ shapes3 = [("l1.conv2", 64, 200, 334, 1, 3), ("l2.conv2a", 128, 200, 334, 2, 1),
            ("l3.conv2a", 256, 100, 167, 2, 1), ("l3.conv2", 256, 50, 84, 1, 5), ("l4.conv2a", 512, 50, 84, 2, 1),
            ("l4.conv2", 512, 25, 42, 1, 2)]
 CFGS = [(0, 0)] + [(c, s) for c in range(1, 7) for s in (0, 1)]
-NAMES = {7: "persistent", 0: "64x128", 1: "128x128/2", 2: "256x128/3", 3: "128x256/3", 4: "256x64/2", 5: "128x128/3", 6: "256x128/2"}
+NAMES = {0: "64x128", 1: "128x128/2", 2: "256x128/3", 3: "128x256/3", 4: "256x64/2", 5: "128x128/3", 6: "256x128/2"}
 
 
 def cl(t):
@@ -63,7 +63,7 @@ def bench(fn, variants, rounds=3, n=8):
 
 
 def report(name, flops, fn, out, tot):
-    variants = [(0, 0), (-1, 0)] if AUTO_ONLY else [(0, 0), (7, 0), (-1, 0)] if PERSIST else CFGS + [(7, 0), (-1, 0)]
+    variants = [(0, 0), (-1, 0)] if AUTO_ONLY else [(0, 0), (7, 0), (8, 0), (9, 0), (10, 0), (11, 0), (-1, 0)] if K32 else CFGS + [(-1, 0)]
     lib.dskd_gemm_nt_tune(0, 0)
     fn()
     ref = out.float().clone()
@@ -79,10 +79,11 @@ def report(name, flops, fn, out, tot):
     t = bench(fn, variants)
     t0, ta = t[(0, 0)], t[(-1, 0)]
     cols = ""
-    if (7, 0) in t:
-        cols += f" persistent {t[(7, 0)]:6.1f} ({flops / t[(7, 0)] / 1e6:4.0f} TF) |"
-        tot[2] += t[(7, 0)]
-    if not AUTO_ONLY and not PERSIST:
+    if K32:
+        k = [t.get((c, 0)) for c in (7, 8, 9, 10, 11)]
+        cols += " k32 ns3/ns4/ns3+lds/ns4+lds, small+lds " + " ".join("   -  " if v is None else f"{v:6.1f}" for v in k) + " |"
+        tot[2] += min([v for v in k if v is not None] + [t0])
+    if not AUTO_ONLY and not K32:
         for c in range(1, 7):
             a, b = t.get((c, 0)), t.get((c, 1))
             cols += "    -  " if a is None else f" {min(a, b):5.1f}{'*' if a < b else ' '}"
@@ -135,4 +136,4 @@ for name, C, H, W, s, cnt in shapes3:
         tot_3d[0] += t[0] * cnt; tot_3d[1] += t[1] * cnt; tot_3d[2] += t[2] * cnt
 for lab, t in (("1x1 forward, one model", tot_f), ("1x1 dX (stride-1 layers)", tot_d), ("3x3 forward, one model", tot_3),
                ("3x3 dX (stride-1 layers)", tot_3d)):
-    print(f"{lab}: small tile {t[0] / 1e3:.3f} ms, persistent {t[2] / 1e3:.3f} ms, automatic choice {t[1] / 1e3:.3f} ms")
+    print(f"{lab}: small tile {t[0] / 1e3:.3f} ms, best of small / k32 {t[2] / 1e3:.3f} ms, automatic choice {t[1] / 1e3:.3f} ms")

@@ -61,6 +61,21 @@ def test_argument_validation_returns_error_codes():
     assert lib.dskd_ffn_bwd(16, 16, 16, 16, 16, None, None, 1, 4, 256, 1024, 1.5, 1, None) == -1 and b"p=" in lib.dskd_last_error()
 
 
+def test_gemm_tile_hook_and_scratch_size():
+    """dskd_gemm_nt_tune refuses unknown configurations; the scratch bound covers the largest split (512 partial tiles of
+    128 x 128 f32 or 256 of 256 x 128)."""
+    lib = native.load()
+    assert lib.dskd_gemm_nt_tune(9, 0) == -1 and b"cfg" in lib.dskd_last_error()
+    for cfg in (-1, 0, 1, 6, 7, 8, -1):
+        assert lib.dskd_gemm_nt_tune(cfg, 0) == 0
+    assert lib.dskd_gemm_nt_scratch_bytes() >= 512 * 128 * 128 * 4
+    # argument validation happens before any launch: misaligned scratch, negative size, bad N
+    assert lib.dskd_gemm_nt_ws(16, 16, None, None, None, 16, 4, 64, 64, 0, 0, 0, 0, 0, 0, 1, 8, 64, None) == -1
+    assert lib.dskd_gemm_nt_ws(16, 16, None, None, None, 16, 4, 64, 64, 0, 0, 0, 0, 0, 0, 1, 16, -1, None) == -1
+    assert lib.dskd_gemm_nt_ws(16, 16, None, None, None, 16, 4, 96, 64, 0, 0, 0, 0, 0, 0, 1, None, 0, None) == -1
+    assert lib.dskd_conv3x3_ws(16, 16, None, None, None, 16, 1, 4, 4, 48, 64, 1, 0, 1, None, 0, None) == -1
+
+
 def test_lsap_host_entry_matches_scipy():
     from scipy.optimize import linear_sum_assignment as sp
     rng = np.random.default_rng(3)

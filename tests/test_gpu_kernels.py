@@ -1474,6 +1474,69 @@ def test_fused_bottleneck_chain_vs_float_reference(Cin, P, H, W, stride, down):
     assert bool((guard == 5.0).all())
 
 
+@pytest.mark.parametrize("M,N,K,conv3", [(1000 + 37, 256, 512, False), (4200, 512, 1024, False), (333, 256, 64, False),
+                                         (2 * 13 * 21, 256, 128, True), (3 * 25 * 42, 512, 512, True)])
+def test_gemm_tile_configurations_agree_with_float_reference(M, N, K, conv3):
+    """Every tile configuration of csrc/gemm_nt.hip behind dskd_gemm_nt_ws / dskd_conv3x3_ws -- gemm_nt_kernel with the
+    register and the LDS epilogue, the six big tiles of gemm_big_kernel with and without the split-K remainder (forced
+    through dskd_gemm_nt_tune, 3 and 7 splits) and the automatic choice -- against the f32 CPU product of the same bf16
+    inputs: forward form (bias + residual + ReLU) and input-gradient form (gate + residual).  Ragged M (rows past the end
+    untouched), K from one stage to 72.  Tolerance 8e-3 of the largest magnitude (~4 bf16 ulps)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(M + N + K)
+    lib = native.load()
+    if conv3:
+        C = K
+        B, H, W = (2, 13, 21) if M == 2 * 13 * 21 else (3, 25, 42)
+        x = torch.randn(B, C, H, W, generator=g).bfloat16()
+        w = (torch.randn(N, C, 3, 3, generator=g) / (9 * C) ** 0.5).bfloat16()
+    else:
+        x = torch.randn(M, K, generator=g).bfloat16()
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16()
+    bias = torch.randn(N, generator=g).bfloat16()
+    res = torch.randn(M, N, generator=g).bfloat16()
+    gate = torch.randn(M, N, generator=g).bfloat16()
+    if conv3:
+        pre = F.conv2d(x.float(), w.float(), None, padding=1).permute(0, 2, 3, 1).reshape(M, N)
+    else:
+        pre = x.float() @ w.float().t()
+    ref_f = torch.relu(pre + bias.float() + res.float())
+    ref_d = torch.where(gate.float() > 0, pre + res.float(), torch.zeros(()))
+    cl = dict(memory_format=torch.channels_last)
+    xd = x.to(DEV).contiguous(**cl) if conv3 else x.to(DEV)
+    wd = w.to(DEV).contiguous(**cl) if conv3 else w.to(DEV)
+    bd, rd, gd = bias.to(DEV), res.to(DEV), gate.to(DEV)
+    guard = 3.0
+    try:
+        for cfg, sp in [(-1, 0), (0, 0), (7, 0), (8, 0)] + [(c, s) for c in range(1, 7) for s in (1, 3, 7)]:
+            assert lib.dskd_gemm_nt_tune(cfg, sp) == 0
+            bn = 64 * (1, 2, 2, 4, 1, 2, 2)[cfg] if 1 <= cfg <= 6 else 64
+            for form in ("fwd", "dx"):
+                out = torch.full((M + 8, N), guard, dtype=torch.bfloat16, device=DEV)
+                if N % bn:
+                    with pytest.raises(native.NativeError):
+                        native.gemm_nt_raw(xd, wd, bd, rd, M, N, K, True, out) if not conv3 else \
+                            native.conv3x3_raw(xd, wd, bd, rd.view(B, H, W, N).permute(0, 3, 1, 2), True, 1,
+                                               out=out[:M].view(B, H, W, N).permute(0, 3, 1, 2))
+                    break
+                if conv3:
+                    o4 = out[:M].view(B, H, W, N).permute(0, 3, 1, 2)
+                    r4, g4 = rd.view(B, H, W, N).permute(0, 3, 1, 2), gd.view(B, H, W, N).permute(0, 3, 1, 2)
+                    if form == "fwd":
+                        native.conv3x3_raw(xd, wd, bd, r4, True, 1, out=o4)
+                    else:
+                        native.conv3x3_raw(xd, wd, None, r4, False, 1, out=o4, gate=g4)
+                elif form == "fwd":
+                    native.gemm_nt_raw(xd, wd, bd, rd, M, N, K, True, out)
+                else:
+                    native.gemm_nt_dx_raw(xd, wd, rd, gd, M, N, K, out)
+                ref = ref_f if form == "fwd" else ref_d
+                assert _close(out[:M], ref, 8e-3), (cfg, sp, form, float((out[:M].float().cpu() - ref).abs().max()))
+                assert bool((out[M:] == guard).all()), (cfg, sp, form)
+    finally:
+        lib.dskd_gemm_nt_tune(-1, 0)
+
+
 @pytest.mark.parametrize("side_first", [True, False])
 def test_fused_bottleneck_output_with_a_second_consumer(side_first):
     """A stage output y that feeds the next Bottleneck AND another consumer (the neck's lateral convolution, the feature
