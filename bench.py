@@ -111,7 +111,7 @@ def make_batch(B, num_prev, seed, device, n_gt=7, n_t=10):
     return dict(img=img.to(device), img_metas=metas, gt_bboxes=gt_b, gt_labels=gt_l), dict(t_b=t_b, t_l=t_l, keep=keep)
 
 
-def train_step(model, wrapped, optimizer, data, synth, amp_dtype, max_norm=0.1, ahead=None):
+def train_step(model, wrapped, optimizer, data, synth, amp_dtype, max_norm=0.1, ahead=None, gsync=None):
     """One distillation step.  ``ahead`` (a ``TeacherAhead``): the teacher of the next batch runs
     on a second stream behind the student's backward and its decode no longer drains the main
     stream; every step still contains one teacher forward + decode, one student
@@ -133,6 +133,8 @@ def train_step(model, wrapped, optimizer, data, synth, amp_dtype, max_norm=0.1, 
     if ahead is not None:       # the next batch (synthetic: the same tensors), enqueued behind the backward
         ahead.launch(data["img"], data["img_metas"], amp_dtype=amp_dtype)
     loss.backward()
+    if gsync is not None:       # data parallel: the buckets' all-reduces were started by the backward's hooks
+        gsync.finish()
     if hasattr(optimizer, "clip_and_step"):       # dskd_amd.optim.FusedClipAdamW: clip + AdamW of every tensor, two launches
         optimizer.clip_and_step(max_norm)
     else:
@@ -398,6 +400,7 @@ def main():
     # overlapped with backward.  --graph: hipGraph replay of the step, gradients exchanged as
     # ONE flat all-reduce over RCCL; falls back to eager if capture fails on any rank.
     mode = "hipgraph" if args.graph else "eager+ddp"
+    gsync = None
     stepper = None
     ahead = None
     extra_warmup = 0
@@ -424,9 +427,17 @@ def main():
                 p.grad = None
     if stepper is None:
         wrapped = model
+        gsync = None
         if world > 1 or ddp1:
-            from dskd_amd.dist import wrap_ddp
-            wrapped = wrap_ddp(model, device_ids=[local_rank])
+            # gradient exchange: flat buckets + hooks (dist.GradSync), not the DistributedDataParallel wrapper -- whose
+            # per-parameter bucket copies cost 3 ms per step at one rank (DSKD_BENCH_WRAP_DDP=1 brings it back for A/B)
+            if os.environ.get("DSKD_BENCH_WRAP_DDP"):
+                from dskd_amd.dist import wrap_ddp
+                wrapped = wrap_ddp(model, device_ids=[local_rank])
+                mode = "eager+DistributedDataParallel"
+            else:
+                from dskd_amd.dist import GradSync
+                gsync = GradSync(model, force=ddp1)
             if ddp1:
                 mode += "(1-rank rccl)"
         optimizer = build_optimizer(model, cfg.optimizer[0])
@@ -435,14 +446,14 @@ def main():
             ahead.use_graphs = not args.no_teacher_graph
             mode += "+teacher_ahead" + ("(hipgraph)" if ahead.use_graphs else "")
         for _ in range(args.warmup):     # the first step runs its teacher inline, then the pipeline is primed
-            loss, lv = train_step(model, wrapped, optimizer, data, synth, amp_dtype, ahead=ahead)
+            loss, lv = train_step(model, wrapped, optimizer, data, synth, amp_dtype, ahead=ahead, gsync=gsync)
         if ahead is not None and ahead.use_graphs and not any(ahead._graphs.values()):
             mode = mode.replace("(hipgraph)", "(hipgraph pending)" if not ahead._graphs else "(hipgraph rejected)")
 
     def one_step():
         if stepper is not None:
             return stepper.step(data, inject)
-        return train_step(model, wrapped, optimizer, data, synth, amp_dtype, ahead=ahead)[0]
+        return train_step(model, wrapped, optimizer, data, synth, amp_dtype, ahead=ahead, gsync=gsync)[0]
 
     step_events = [] if os.environ.get("DSKD_BENCH_STEPTIMES") else None    # diagnostic: per-step GPU/host times
     host_marks = []
@@ -458,6 +469,8 @@ def main():
             host_marks.append(time.perf_counter() - t0)
     sync()
     dt = time.perf_counter() - t0
+    if gsync is not None and rank == 0:
+        print(f"[bench] GradSync: {len(gsync.buckets)} buckets, {gsync.stats}", file=sys.stderr)
     if step_events:
         ms1 = torch.cuda.memory_stats(device)
         print("[bench] allocator over the timed region: " + ", ".join(

@@ -10,6 +10,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import native
+from .dist import grad_slot
 from .builder import BACKBONES
 
 
@@ -98,6 +99,7 @@ class _FoldTrainable(torch.autograd.Function):
     def forward(ctx, scales, dtype, *weights):
         ctx.scales, ctx.wdtype = scales, weights[0].dtype
         ctx.pstrides = [w.stride() for w in weights]
+        ctx.pids = [id(w) for w in weights]
         prod = torch._foreach_mul(list(weights), scales)
         if dtype == ctx.wdtype:
             return tuple(prod)
@@ -109,6 +111,12 @@ class _FoldTrainable(torch.autograd.Function):
     def backward(ctx, *grads):
         gs = [g if g is not None else torch.zeros_like(s) for g, s in zip(grads, ctx.scales)]
         if gs[0].dtype != ctx.wdtype:
+            # data parallel: cast into the parameters' slots of the flat gradient buffer (dist.GradSync) and scale in place
+            slots = [grad_slot(pid, g.shape, ctx.wdtype) for pid, g in zip(ctx.pids, gs)]
+            if all(s is not None for s in slots):
+                torch._foreach_copy_(slots, gs)
+                torch._foreach_mul_(slots, ctx.scales)
+                return (None, None) + tuple(slots)
             up = [torch.empty_like(g, dtype=ctx.wdtype) for g in gs]
             torch._foreach_copy_(up, gs)
             gs = up

@@ -97,3 +97,135 @@ def wrap_ddp(model, device_ids=None, bucket_cap_mb=50, find_unused_parameters=No
     return DistributedDataParallel(model, device_ids=device_ids, broadcast_buffers=False,
                                    find_unused_parameters=find_unused_parameters, bucket_cap_mb=bucket_cap_mb,
                                    gradient_as_bucket_view=True, **kwargs)
+
+
+_GRAD_SLOTS = {}      # id(parameter) -> its view in the flat buffer of the live GradSync
+
+
+def grad_slot(pid, shape, dtype):
+    """A fresh alias of the GradSync slot of the parameter with ``id`` ``pid`` (None without a live GradSync, or when shape
+    / dtype differ): the multi-tensor casts that produce most parameter gradients (transformer._CastParams, backbones.
+    _FoldTrainable) write straight into it, autograd adopts the alias as ``.grad`` (AccumulateGrad keeps a gradient that
+    nobody else references and that has the parameter's strides), and GradSync's bucket copy has nothing left to move."""
+    v = _GRAD_SLOTS.get(pid)
+    if v is None or v.dtype != dtype or tuple(v.shape) != tuple(shape):
+        return None
+    return v.detach()
+
+
+class GradSync:
+    """Data-parallel gradient exchange WITHOUT the DDP wrapper (r4): one persistent flat f32 buffer holds every trainable
+    parameter's gradient, cut into buckets in the order the backward produces them (reverse registration: head and
+    transformer first, backbone last).  A post-accumulate hook per parameter counts its bucket down; the last one packs
+    the bucket's fresh gradients into its slice with ONE multi-tensor copy, re-points ``.grad`` at the slice views and
+    starts the bucket's all-reduce (RCCL: on the process group's stream, overlapped with the rest of the backward).
+    :meth:`finish` (after ``backward()``, before the optimizer) flushes what is left, waits, and averages.
+
+    Why not ``DistributedDataParallel`` (what the reference wraps with, tools/train_increment.py:301-303): its reducer copies
+    every parameter's gradient into the bucket with a launch of its own (~200 per step: the hand-written weight-gradient
+    kernels hand autograd freshly allocated tensors, ``gradient_as_bucket_view`` cannot adopt them) and costs 3 ms per step
+    at ONE rank, before a byte crosses xGMI (profiles/r03_ddp_one_rank_rccl.json).  Same numbers as DDP: mean over ranks of
+    the local gradients; a parameter that received no gradient on this rank contributes zeros; ``*.prototype.weight``
+    (never used, transformer.py / head) is left out as in :func:`wrap_ddp`."""
+
+    def __init__(self, model, bucket_mb=48.0, overlap=True, force=False):
+        inited = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size() if inited else 1
+        self.active = self.world > 1 or force
+        self.comm = inited and self.active       # force: the collectives run even in a one-rank group (diagnostic)
+        if os.environ.get("DSKD_GRADSYNC_NOCOMM") and self.world == 1:
+            self.comm = False                    # diagnostic: hooks + packing only
+        bucket_mb = float(os.environ.get("DSKD_GRADSYNC_BUCKET_MB", bucket_mb))
+        self.overlap = overlap
+        if self.world > 1:                       # what DDP's constructor does: rank 0's parameters and buffers everywhere
+            with torch.no_grad():
+                for t in list(model.parameters()) + list(model.buffers()):
+                    dist.broadcast(t.data, 0)
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad and not n.endswith("prototype.weight")]
+        self.params = [p for _, p in reversed(named)]
+        self.buckets, self.handles = [], []
+        self.stats = dict(copied=0, adopted=0, zeroed=0, flushed_in_backward=0, flushed_in_finish=0)
+        if not self.active or not self.params:
+            return
+        dev, dt = self.params[0].device, torch.float32
+        if any(p.device != dev or p.dtype != dt or not (p.is_contiguous() or p.is_contiguous(memory_format=torch.channels_last))
+               for p in self.params):
+            raise ValueError("GradSync: dense f32 parameters on one device expected")
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=dt, device=dev)
+        cap = int(bucket_mb * (1 << 20) / 4)
+        lo = off = 0
+        cur = []
+        self.views = {}
+        for p in self.params:
+            v = self.flat[off:off + p.numel()]
+            # a dense parameter in any memory format (channels_last convolution weights): same strides as the parameter
+            # (as_strided also for 'contiguous' ones: a [N, C, 1, 1] channels_last weight reports both formats)
+            self.views[p] = v.as_strided(p.shape, p.stride())
+            cur.append(p)
+            off += p.numel()
+            if off - lo >= cap:
+                self.buckets.append(dict(params=cur, lo=lo, hi=off, pending=len(cur), work=None, done=False))
+                cur, lo = [], off
+        if cur:
+            self.buckets.append(dict(params=cur, lo=lo, hi=off, pending=len(cur), work=None, done=False))
+        self._avg = self.comm and dist.get_backend() == "nccl"
+        owner = {}
+        for b in self.buckets:
+            for p in b["params"]:
+                owner[p] = b
+        for p in self.params:
+            self.handles.append(p.register_post_accumulate_grad_hook(self._make_hook(owner[p])))
+            _GRAD_SLOTS[id(p)] = self.views[p]
+
+    def _make_hook(self, bucket):
+        def hook(param):
+            bucket["pending"] -= 1
+            if bucket["pending"] == 0 and self.overlap and not bucket["done"]:
+                self._flush(bucket)
+        return hook
+
+    @torch.no_grad()
+    def _flush(self, b):
+        have = [p for p in b["params"] if p.grad is not None and p.grad.data_ptr() != self.views[p].data_ptr()]
+        for p in b["params"]:
+            if p.grad is None:
+                self.views[p].zero_()
+        st = self.stats
+        st["copied"] += len(have)
+        st["zeroed"] += sum(1 for p in b["params"] if p.grad is None)
+        st["adopted"] += sum(1 for p in b["params"] if p.grad is not None) - len(have)
+        st["flushed_in_backward" if b["pending"] == 0 else "flushed_in_finish"] += 1
+        if have:
+            torch._foreach_copy_([self.views[p] for p in have], [p.grad for p in have])
+        for p in b["params"]:
+            p.grad = self.views[p]
+        if self.comm:
+            op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+            b["work"] = dist.all_reduce(self.flat[b["lo"]:b["hi"]], op=op, async_op=True)
+        b["done"] = True
+
+    @torch.no_grad()
+    def finish(self):
+        """Call between ``backward()`` and the optimizer step."""
+        if not self.active:
+            return
+        for b in self.buckets:
+            if not b["done"]:
+                self._flush(b)
+        for b in self.buckets:
+            if b["work"] is not None:
+                b["work"].wait()
+                b["work"] = None
+            b["pending"], b["done"] = len(b["params"]), False
+        if self.comm and not self._avg and self.world > 1:
+            self.flat.div_(self.world)
+
+    def remove(self):
+        for h in self.handles:
+            h.remove()
+        self.handles = []
+        if self.active:
+            for p in self.params:
+                if _GRAD_SLOTS.get(id(p)) is self.views.get(p):
+                    del _GRAD_SLOTS[id(p)]

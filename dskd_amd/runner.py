@@ -82,8 +82,9 @@ class StepLrWarmup:
 class TaskEpochBasedRunner:
     def __init__(self, model, optimizer, work_dir=None, logger=print, max_epochs=12, max_tasks=1, save_teacher=False,
                  grad_clip=None, lr_config=None, log_interval=50, checkpoint_interval=1, amp_dtype=None,
-                 max_iters_per_epoch=None, **kwargs):
+                 max_iters_per_epoch=None, grad_sync=None, **kwargs):
         self.model, self.optimizer, self.work_dir, self.log = model, optimizer, work_dir, logger
+        self.grad_sync = grad_sync       # dist.GradSync of a data-parallel run (None: one process, or a DDP-wrapped model)
         self.max_epochs, self.max_tasks, self.save_teacher = max_epochs, max_tasks, save_teacher
         self.grad_clip = dict(grad_clip) if grad_clip else None
         lr_config = dict(lr_config or dict(policy="step", step=[max_epochs + 1]))
@@ -121,6 +122,8 @@ class TaskEpochBasedRunner:
             if ahead is not None and next_data is not None:
                 ahead.launch(next_data["img"], next_data["img_metas"], amp_dtype=self.amp_dtype)
         out["loss"].backward()
+        if self.grad_sync is not None:          # data parallel without the DDP wrapper (dist.GradSync)
+            self.grad_sync.finish()
         if self.grad_clip and hasattr(self.optimizer, "clip_and_step") and self.grad_clip.get("norm_type", 2) == 2:
             out["grad_norm"] = self.optimizer.clip_and_step(self.grad_clip["max_norm"])      # two launches for both
         else:

@@ -22,6 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import native
+from .dist import grad_slot
 from .utils import device_const
 from .builder import (ATTENTION, FEEDFORWARD_NETWORK, POSITIONAL_ENCODING, TRANSFORMER, TRANSFORMER_LAYER,
                       TRANSFORMER_LAYER_SEQUENCE, build_attention, build_feedforward_network,
@@ -286,6 +287,7 @@ class _CastParams(torch.autograd.Function):
         is what lets a captured hipGraph read the step's parameters), or None for fresh tensors."""
         ctx.set_materialize_grads(False)
         ctx.pdtypes = [p.dtype for p in params]
+        ctx.pids = [id(p) for p in params]
         outs = [torch.empty_like(p, dtype=dtype) for p in params] if static is None else static
         torch._foreach_copy_(outs, [p.detach() for p in params])
         return tuple(outs) if static is None else tuple(o.detach() for o in outs)
@@ -293,7 +295,9 @@ class _CastParams(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         idx = [i for i, g in enumerate(grads) if g is not None]
-        ups = [torch.empty_like(grads[i], dtype=ctx.pdtypes[i]) for i in idx]
+        # data parallel: straight into the parameter's slot of the flat gradient buffer (dist.GradSync), else a fresh tensor
+        slots = [grad_slot(ctx.pids[i], grads[i].shape, ctx.pdtypes[i]) for i in idx]
+        ups = [s if s is not None else torch.empty_like(grads[i], dtype=ctx.pdtypes[i]) for s, i in zip(slots, idx)]
         if idx:
             torch._foreach_copy_(ups, [grads[i] for i in idx])
         out = [None] * len(grads)

@@ -47,6 +47,7 @@ def _worker(rank, world, port, out):
     model.set_teacher(model=copy.deepcopy(model))
     model.LableInPCNTask = {"prev": list(range(70)), "curr": list(range(70, 80)), "next": []}
     model.train()
+    model_gs = copy.deepcopy(model)                        # for dist.GradSync below (no DDP hooks on its parameters)
     ddp = wrap_ddp(model)
     g = torch.Generator().manual_seed(100 + rank)          # different data per rank
     H, W = 64, 96
@@ -64,6 +65,29 @@ def _worker(rank, world, port, out):
     gsum = torch.stack([p.grad.double().sum() for p in model.parameters() if p.grad is not None]).sum()
     gathered = [torch.zeros_like(gsum) for _ in range(world)]
     dist.all_gather(gathered, gsum)
+    # ---- dist.GradSync (what bench.py / the runner use instead of the DDP wrapper): same averaged gradients, parameter by
+    # parameter, with the bucket hooks firing during backward (two small buckets) and with everything left to finish()
+    from dskd_amd.dist import GradSync
+    ddp_grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    gs_worst = 0.0
+    model_gs.LableInPCNTask = model.LableInPCNTask
+    for overlap in (True, False):
+        for p in model_gs.parameters():
+            p.grad = None
+        gs = GradSync(model_gs, bucket_mb=40.0, overlap=overlap)
+        assert gs.active and len(gs.buckets) >= 2
+        losses2 = model_gs(img=img, img_metas=metas, gt_bboxes=gt_b, gt_labels=gt_l, teacher_info=ti)
+        loss2, _ = model_gs._parse_losses(losses2)
+        loss2.backward()
+        gs.finish()
+        gs.remove()
+        for n, p in model_gs.named_parameters():
+            if n.endswith("prototype.weight"):
+                continue
+            assert (p.grad is not None) == (n in ddp_grads) or (p.grad is not None and not p.grad.any()), n
+            if n in ddp_grads:
+                assert p.grad.data_ptr() == gs.views[p].data_ptr()
+                gs_worst = max(gs_worst, float((p.grad - ddp_grads[n]).abs().max() / (ddp_grads[n].abs().max() + 1e-12)))
     # ---- the graph-step driver's data-parallel exchange (eager on CPU): ONE flat gradient
     # all-reduce, no DDP wrapper; parameters must stay identical across ranks
     from dskd_amd.graph_step import GraphedDistillStep
@@ -92,7 +116,7 @@ def _worker(rank, world, port, out):
     rm = reduce_mean(torch.tensor([float(rank + 1)]))
     sc = allreduce_scalars([torch.tensor(float(rank)), torch.tensor(2.0)])
     if rank == 0:
-        out.put(dict(psums=[float(x) for x in pg], step_keys=sorted(step_logs.keys()),
+        out.put(dict(psums=[float(x) for x in pg], step_keys=sorted(step_logs.keys()), gradsync_vs_ddp=gs_worst,
                      gsums=[float(x) for x in gathered], reduce_mean=float(rm), scalars=sc.tolist(),
                      keys=sorted(log_vars.keys()), loss=float(log_vars["loss"]), local_loss=float(loss)))
     dist.barrier()
@@ -111,6 +135,7 @@ def test_two_rank_ddp_step_gloo():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert res["gsums"][0] == pytest.approx(res["gsums"][1], rel=1e-9)        # DDP averaged the gradients
+    assert res["gradsync_vs_ddp"] < 1e-5                                      # dist.GradSync: the same gradients, per parameter
     assert res["psums"][0] == pytest.approx(res["psums"][1], rel=1e-12)        # stepper keeps ranks in sync
     assert "loss" in res["step_keys"] and "loss_fg_feature" in res["step_keys"]
     assert res["reduce_mean"] == pytest.approx(1.5)

@@ -32,7 +32,7 @@ import dskd_amd  # noqa: E402,F401
 from dskd_amd.builder import build_detector  # noqa: E402
 from dskd_amd.config import Config  # noqa: E402
 from dskd_amd.datasets import build_dataloader, build_dataset  # noqa: E402
-from dskd_amd.dist import get_dist_info, init_dist, wrap_ddp  # noqa: E402
+from dskd_amd.dist import GradSync, get_dist_info, init_dist, wrap_ddp  # noqa: E402
 from dskd_amd.runner import TaskEpochBasedRunner, build_optimizer  # noqa: E402
 
 
@@ -177,7 +177,13 @@ def main(argv=None, cpu_checker=None):
                            pred_cat=train_dataset.PRED_CLASSES, load_cat=train_dataset.LOAD_CLASSES,
                            task_cat=train_dataset.TASK_CLASSES)
         model.to(device)
-        wrapped = wrap_ddp(model, device_ids=[device.index] if device.type == "cuda" else None) if distributed else model
+        # data parallel (reference: MMDistributedDataParallel, tools/train_increment.py:301-303): gradient buckets + hooks
+        # (dist.GradSync; same averaged gradients, none of DDP's per-parameter bucket copies); DSKD_WRAP_DDP=1: the wrapper
+        wrapped, grad_sync = model, None
+        if distributed and os.environ.get("DSKD_WRAP_DDP"):
+            wrapped = wrap_ddp(model, device_ids=[device.index] if device.type == "cuda" else None)
+        elif distributed:
+            grad_sync = GradSync(model)
         optimizer = build_optimizer(wrapped, per_task(cfg.optimizer, tid))
         rcfg = dict(per_task(cfg.runner, tid))
         rcfg.pop("type", None)
@@ -189,7 +195,7 @@ def main(argv=None, cpu_checker=None):
                                       log_interval=cfg.get("log_config", {}).get("interval", 50),
                                       checkpoint_interval=cfg.get("checkpoint_config", {}).get("interval", 1),
                                       amp_dtype=torch.bfloat16 if args.amp == "bf16" else None,
-                                      max_iters_per_epoch=args.max_iters, **rcfg)
+                                      max_iters_per_epoch=args.max_iters, grad_sync=grad_sync, **rcfg)
         if args.print_model and rank == 0 and not runners:
             log(model)
         if resume_from:                # student + optimizer + epoch / iteration counters of an interrupted task
@@ -198,6 +204,8 @@ def main(argv=None, cpu_checker=None):
             resume_from = ""
         tic = time.time()
         runner.run([loader], cfg.get("workflow", [("train", 1)]), cur_task=tid)
+        if grad_sync is not None:
+            grad_sync.remove()         # the next task builds its own (its hooks would otherwise pile up on shared parameters)
         log(f"======== Task-{tid} done in {time.time() - tic:.1f}s ========")
         runners.append(runner)
     return runners
