@@ -276,6 +276,137 @@ def test_bf16_tall_step_tracks_fp32_step():
     assert cosines[len(cosines) // 2][0] > 0.97
 
 
+def _rel(a, b):
+    a, b = a.detach().double().flatten(), b.detach().double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def test_benched_mode_step_at_800x1333_vs_fp32():
+    """BASELINE configs[1] exactly as bench.py runs it -- 800 x 1333 synthetic COCO-shaped batch (bench.make_batch: 7 ground
+    truth + 10 injected teacher detections per image), 70 + 10 classes, bf16 autocast, channels_last, the student head as
+    two hipGraph replays and the teacher's forward as a hipGraph replay on its side stream (TeacherAhead) -- against the
+    same step in fp32 (eager, no graphs) on the GPU from the same weights.  B = 2, dropout off.  This is the only test in
+    which the bf16-only kernels (gemm_nt / gemm_big / gemm_tn, the fused FFN, lin256, the matrix-core grad_value, the fused
+    Bottleneck node, the pre-packed weight images) and the size-gated tall paths run TOGETHER at the benchmark's size.
+      (i)   trunk outputs -- neck features, encoder memory, every decoder layer's query embedding, logits and boxes --
+            within a relative Frobenius bound per tensor (bf16 residual streams: ~0.4 % per rounding, six layers deep);
+      (ii)  ``loss()`` on IDENTICAL head inputs (the bf16 run's outputs handed to both heads): every term to rtol 1e-3;
+      (iii) every trainable parameter's gradient against fp32 in the relative Frobenius norm, exceptions named."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    dev = torch.device("cuda:0")
+    cfg, m32 = _build(seed=3)
+    m16 = copy.deepcopy(m32)
+    B = 2
+    data, synth = bench.make_batch(B, cfg.num_prev, 111, dev)
+    metas = data["img_metas"]
+
+    def info(feats, outs):
+        return dict(neck_feats=feats, head_outs=outs, pred_keepid=synth["keep"], pred_logits=None, pred_scores=None,
+                    pred_labels=synth["t_l"], pred_bboxes=synth["t_b"])
+
+    # ---- fp32 reference: eager, NCHW, no graphs
+    m32.to(dev).train()
+    m32.bbox_head.graph_head = False
+    with torch.no_grad():
+        tf32, to32, *_ = m32.out_teacher(data["img"], metas)
+    feats32 = m32.extract_feat(data["img"])
+    outs32 = m32.bbox_head(feats32, metas)
+    out = m32.train_step(dict(data, teacher_info=info(tf32, to32)))
+    out["loss"].backward()
+    lv32 = out["log_vars"]
+
+    # ---- the benched mode
+    m16.to(dev).train()
+    m16.to(memory_format=torch.channels_last)
+    m16.teacher_model.to(memory_format=torch.channels_last)
+    img16 = data["img"].contiguous(memory_format=torch.channels_last)
+    m16.bbox_head.graph_head = True
+    ahead = m16.teacher_ahead()
+    ahead.use_graphs = True
+    lv16 = outs16 = feats16 = ti16 = None
+    for step in range(5):                     # head graphs: two eager calls, capture, replays; teacher graph likewise
+        for p in m16.parameters():
+            p.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            ti = ahead.finish(img16, metas)
+            ti16 = info(ti["neck_feats"], ti["head_outs"])
+            out = m16.train_step(dict(data, img=img16, teacher_info=ti16))
+            ahead.launch(img16, metas, amp_dtype=torch.bfloat16)
+        out["loss"].backward()
+        lv16 = out["log_vars"]
+    # the trunk outputs of the same mode, in an autocast region of their own (a no-grad forward inside the training step's
+    # region would leave detached weight casts in autocast's cache and the step after it without those gradients)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        feats16 = m16.extract_feat(img16)
+        outs16 = m16.bbox_head(feats16, metas)
+    torch.cuda.synchronize()
+    hg = m16.bbox_head.__dict__.get("_head_graphs", {})
+    assert len(hg) == 1 and all(v not in (None, False) for v in hg.values()), hg        # the head really was replayed
+    assert any(ahead._graphs.values()), ahead._graphs                                      # ... and the teacher
+
+    # ---- (i) trunk outputs
+    rep = {}
+    for i, (a, b) in enumerate(zip(feats16, feats32)):
+        rep[f"neck{i}"] = _rel(a.float(), b)
+    for i, (a, b) in enumerate(zip(ti16["neck_feats"], tf32)):
+        rep[f"teacher_neck{i}"] = _rel(a.float(), b)
+    cls16, box16, info16, hs16 = outs16
+    cls32, box32, info32_, hs32 = outs32
+    rep["memory"] = _rel(info16[0].float(), info32_[0])
+    for l in range(hs32.shape[0]):
+        rep[f"hs{l}"] = _rel(hs16[l].float(), hs32[l])
+    rep["cls"] = _rel(cls16.float(), cls32)
+    rep["box"] = _rel(box16.float(), box32)
+    print("trunk outputs, relative Frobenius distance bf16 (benched mode) vs fp32:", {k: round(v, 4) for k, v in rep.items()})
+    # measured 0.13 % (boxes) .. 0.96 % (teacher's coarse neck levels): bf16 activations and residual streams
+    for k, v in rep.items():
+        assert v <= 2e-2, (k, v)
+
+    # ---- (ii) loss() on identical head inputs
+    def loss_on(model, amp):
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            ls = model.bbox_head.loss(cls16.float(), box16.float(), (info16[0].float(), info16[1]), hs16.float(),
+                                      data["gt_bboxes"], data["gt_labels"], metas,
+                                      student_feat=[f.float() for f in feats16],
+                                      teacher_info=dict(ti16, neck_feats=[f.float() for f in ti16["neck_feats"]]),
+                                      task_labels=m32.LableInPCNTask)
+        return {k: float(v) for k, v in ls.items() if "loss" in k}
+    la, lb = loss_on(m16, True), loss_on(m32, False)
+    worst_loss = max(abs(la[k] - lb[k]) / max(abs(lb[k]), 1e-6) for k in lb)
+    print("loss() on identical head inputs, worst relative difference:", worst_loss)
+    assert set(la) == set(lb) and worst_loss <= 1e-3, (worst_loss, la, lb)       # measured: bit-equal (the loss stage is f32)
+
+    # ---- (iii) gradients
+    p32 = dict(m32.named_parameters())
+    rows = []
+    for name, p in m16.named_parameters():
+        if not p.requires_grad or name.startswith("teacher_model") or p32[name].grad is None:
+            continue
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), name
+        if float(p32[name].grad.norm()) > 1e-9:
+            rows.append((_rel(p.grad, p32[name].grad), name, p.numel()))
+    rows.sort(reverse=True)
+    print("gradients, relative Frobenius distance: worst 25:", [(round(r, 3), n) for r, n, _ in rows[:25]])
+    print("median", rows[len(rows) // 2][0], "p90", rows[len(rows) // 10][0], "n", len(rows))
+    print("losses bf16 / fp32:", {k: (round(lv16[k], 4), round(lv32[k], 4)) for k in lv32})
+    assert set(lv16) == set(lv32)
+    for k in lv32:       # measured: <= 4e-3 on the classification terms (a logit moved by bf16), <= 3e-4 elsewhere
+        assert lv16[k] == pytest.approx(lv32[k], rel=1.5e-2 if "cls" in k else 3e-3, abs=1e-4), (k, lv16[k], lv32[k])
+    # Gradients.  Measured: median 5 %, 90th percentile 18 %; the tail is ONE family -- parameters whose gradient arrives
+    # through the sampling LOCATIONS of the deformable attention (sampling_offsets / attention_weights, the decoder's
+    # reference_points and the query embedding behind them): d(out)/d(loc) is a difference of neighbouring value pixels,
+    # and a difference of bf16-rounded values carries several per cent of noise that the sums over 22 223 x 128 samples do
+    # not average out completely (38 % worst).  Every other parameter -- all of the ResNet, the neck, every projection, FFN
+    # and norm of the transformer, the branches -- agrees to 30 %, half of them to 5 %.
+    loc_path = ("sampling_offsets", "attention_weights", "reference_points", "query_embedding")
+    assert len(rows) >= 240
+    for r, name, _ in rows:
+        assert r <= (0.6 if any(t in name for t in loc_path) else 0.3), (name, r)
+    assert rows[len(rows) // 2][0] <= 0.1 and rows[len(rows) // 10][0] <= 0.3, (rows[len(rows) // 2], rows[len(rows) // 10])
+
+
 def test_teacher_ahead_graph_replay_tracks_eager_teacher():
     """After the batch signature has repeated, the ahead-of-time teacher forward is a hipGraph
     replay (two alternating graphs): with a NEW image every step its outputs must keep tracking
