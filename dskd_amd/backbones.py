@@ -92,15 +92,29 @@ def conv_bn(conv, bn, x, relu=False, identity=None):
 
 
 class _FoldTrainable(torch.autograd.Function):
-    """w_i * scale_i for every trainable conv of the backbone in two multi-tensor launches
-    (foreach mul + foreach cast) instead of ~5 small launches per conv; backward likewise."""
+    """w_i * scale_i (per output channel) for every trainable conv of a backbone stage, cast to the compute dtype, and the
+    way back of the gradients.  bf16 on the GPU: ONE launch each way (native.MultiCast / dskd_cast_scale_many: the weight is
+    read once, the scale is a [Cout] vector).  Otherwise two multi-tensor launches on scales expanded to the weights' shapes
+    (foreach mul + foreach cast) instead of ~5 small launches per conv."""
 
     @staticmethod
-    def forward(ctx, scales, dtype, *weights):
-        ctx.scales, ctx.wdtype = scales, weights[0].dtype
+    def forward(ctx, scales, dtype, tables, *weights):
+        """``scales``: per conv (vector [Cout] f32, the same expanded to the weight's shape and strides | None);
+        ``tables``: (forward, backward) MultiCast of this stage | None."""
+        ctx.scales, ctx.wdtype, ctx.tables = scales, weights[0].dtype, tables
         ctx.pstrides = [w.stride() for w in weights]
         ctx.pids = [id(w) for w in weights]
-        prod = torch._foreach_mul(list(weights), scales)
+        ctx.wshapes = [w.shape for w in weights]
+        vecs = [v for v, _ in scales]
+        srcs = [w.detach() for w in weights]
+        if tables is not None and dtype == torch.bfloat16 and ctx.wdtype == torch.float32:
+            outs = [torch.empty_like(w, dtype=dtype) for w in srcs]
+            if native.MultiCast.ok(srcs, outs, vecs, 0):
+                tables[0].run(srcs, outs, vecs)
+                ctx.fast = True
+                return tuple(outs)
+        ctx.fast = False
+        prod = torch._foreach_mul(srcs, [_full_scale(sc, w) for sc, w in zip(scales, weights)])
         if dtype == ctx.wdtype:
             return tuple(prod)
         outs = [torch.empty_like(p, dtype=dtype) for p in prod]
@@ -109,23 +123,48 @@ class _FoldTrainable(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        gs = [g if g is not None else torch.zeros_like(s) for g, s in zip(grads, ctx.scales)]
+        gdt = next((g.dtype for g in grads if g is not None), ctx.wdtype)
+        gs = [g if g is not None else torch.zeros(sh, dtype=gdt, device=ctx.scales[0][0].device)
+              for g, sh in zip(grads, ctx.wshapes)]
+        if ctx.fast and gs[0].dtype == torch.bfloat16:
+            # bf16 gradients -> f32 * scale in ONE launch, into the parameters' slots of the flat gradient buffer of a
+            # data-parallel run (dist.GradSync) when there is one
+            gs = [g if g.stride() == st else g.as_strided(g.shape, st) if g.shape[2:] == (1, 1) else g.contiguous(
+                memory_format=torch.channels_last if st[1] == 1 else torch.contiguous_format) for g, st in zip(gs, ctx.pstrides)]
+            slots = [grad_slot(pid, g.shape, ctx.wdtype) for pid, g in zip(ctx.pids, gs)]
+            ups = [s if s is not None else torch.empty_like(g, dtype=ctx.wdtype) for s, g in zip(slots, gs)]
+            vecs = [v for v, _ in ctx.scales]
+            if native.MultiCast.ok(gs, ups, vecs, 1):
+                ctx.tables[1].run(gs, ups, vecs)
+                return (None, None, None) + tuple(ups)
+        full = [_full_scale(sc, g) for sc, g in zip(ctx.scales, gs)]
         if gs[0].dtype != ctx.wdtype:
-            # data parallel: cast into the parameters' slots of the flat gradient buffer (dist.GradSync) and scale in place
             slots = [grad_slot(pid, g.shape, ctx.wdtype) for pid, g in zip(ctx.pids, gs)]
             if all(s is not None for s in slots):
                 torch._foreach_copy_(slots, gs)
-                torch._foreach_mul_(slots, ctx.scales)
-                return (None, None) + tuple(slots)
+                torch._foreach_mul_(slots, full)
+                return (None, None, None) + tuple(slots)
             up = [torch.empty_like(g, dtype=ctx.wdtype) for g in gs]
             torch._foreach_copy_(up, gs)
             gs = up
-        outs = torch._foreach_mul(gs, ctx.scales)
+        outs = torch._foreach_mul(gs, full)
         # 1x1 kernels: [Cin, 1, 1, 1] and the parameter's channels_last [Cin, 1, Cin, Cin] describe the
         # same memory; hand DDP the parameter's strides so it does not copy into its bucket view
         outs = [o.as_strided(o.shape, st) if (o.stride() != st and o.shape[2:] == (1, 1)) else o
                 for o, st in zip(outs, ctx.pstrides)]
-        return (None, None) + tuple(outs)
+        return (None, None, None) + tuple(outs)
+
+
+def _full_scale(sc, like):
+    """The per-channel scale expanded to ``like``'s shape and strides (built on first use: only the paths without the
+    multi-tensor kernel need it -- fp32 runs, host tensors)."""
+    vec, full = sc
+    if full is None or full.shape != like.shape or full.stride() != like.stride():
+        # same strides as the weight (channels_last models): a stride mismatch sends torch._foreach_mul down its
+        # per-tensor slow path -- ~80 single launches per step instead of 6
+        full = torch.empty_like(like, dtype=vec.dtype).copy_(vec.view(-1, 1, 1, 1).expand(like.shape))
+        sc[1] = full
+    return full
 
 
 def _bn(ch, requires_grad):
@@ -315,19 +354,18 @@ class ResNet(nn.Module):
             scales, biases = [], []
             with torch.no_grad():
                 for c, b, _ in pairs:
-                    sc = b.weight * torch.rsqrt(b.running_var + b.eps)
-                    # same strides as the weight (channels_last models): a stride mismatch sends torch._foreach_mul down
-                    # its per-tensor slow path -- ~80 single launches per step instead of 6
-                    scales.append(torch.empty_like(c.weight).copy_(sc.view(-1, 1, 1, 1).expand_as(c.weight)))
+                    sc = (b.weight * torch.rsqrt(b.running_var + b.eps)).contiguous()
+                    scales.append([sc, None])          # [vector, the same expanded to the weight (built on demand)]
                     biases.append((b.bias - b.running_mean * sc).to(dtype))
-            self._fold_key, self._fold_const = key, (scales, biases)
-        scales, biases = self._fold_const
+            tables = {st: (native.MultiCast(0), native.MultiCast(1)) for st in {p[2] for p in pairs}} if x.is_cuda else {}
+            self._fold_key, self._fold_const = key, (scales, biases, tables)
+        scales, biases, tables = self._fold_const
         # One fold per stage: its backward hands the stage's weight gradients over as soon as that
         # stage's backward is done (layer4 first: 2/3 of the backbone's parameters), so DDP can
         # all-reduce them while the earlier stages still run their backward.
         for st in sorted({p[2] for p in pairs}):
             idx = [i for i, p in enumerate(pairs) if p[2] == st]
-            ws = _FoldTrainable.apply([scales[i] for i in idx], dtype, *[pairs[i][0].weight for i in idx])
+            ws = _FoldTrainable.apply([scales[i] for i in idx], dtype, tables.get(st), *[pairs[i][0].weight for i in idx])
             for i, w in zip(idx, ws):
                 pairs[i][0].__dict__["_folded_live"] = (w, biases[i])
         return [c for c, _, _ in pairs]

@@ -151,7 +151,7 @@ class GradSync:
         if any(p.device != dev or p.dtype != dt or not (p.is_contiguous() or p.is_contiguous(memory_format=torch.channels_last))
                for p in self.params):
             raise ValueError("GradSync: dense f32 parameters on one device expected")
-        total = sum(p.numel() for p in self.params)
+        total = sum((p.numel() + 7) // 8 * 8 for p in self.params)      # every slot 32-byte aligned (vector casts into it)
         self.flat = torch.zeros(total, dtype=dt, device=dev)
         cap = int(bucket_mb * (1 << 20) / 4)
         lo = off = 0
@@ -163,7 +163,7 @@ class GradSync:
             # (as_strided also for 'contiguous' ones: a [N, C, 1, 1] channels_last weight reports both formats)
             self.views[p] = v.as_strided(p.shape, p.stride())
             cur.append(p)
-            off += p.numel()
+            off += (p.numel() + 7) // 8 * 8
             if off - lo >= cap:
                 self.buckets.append(dict(params=cur, lo=lo, hi=off, pending=len(cur), work=None, done=False))
                 cur, lo = [], off

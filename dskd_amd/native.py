@@ -70,6 +70,8 @@ _SIGNATURES = {
     "dskd_winattn_bwd": (C.c_int, [_vp] * 6 + [C.c_int] * 5 + [_f32, C.c_int, _vp]),
     "dskd_clip_adamw_chunk": (C.c_int, []),
     "dskd_clip_adamw": (C.c_int, [_vp] * 5 + [C.c_int, C.c_int, _vp, _vp, C.c_int, _f32, _f32, _f32, _i64, _f32, _vp]),
+    "dskd_cast_scale_chunk": (C.c_int, []),
+    "dskd_cast_scale_many": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_gn_workspace": (_i64, [C.c_int, _i64]),
     "dskd_nhwc_to_nchw_f32": (C.c_int, [_vp, _vp, C.c_int, _i64, C.c_int, _i64, C.c_int, _vp]),
     "dskd_gn_fwd": (C.c_int, [_vp] * 6 + [C.c_int, _i64, C.c_int, C.c_int, _i64, _i64, _f32, C.c_int, C.c_int, _vp]),
@@ -1107,6 +1109,53 @@ def conv3x3(x, w, bias=None, identity=None, relu=False, stride=1):
     if identity is not None and (identity.dtype != x.dtype or not identity.is_contiguous(memory_format=torch.channels_last)):
         identity = identity.to(x.dtype).contiguous(memory_format=torch.channels_last)
     return _Conv3x3Function.apply(x, w, bias, identity, bool(relu), int(stride))
+
+
+# --------------------------------------------------------------------------- multi-tensor cast (+ per-row scale)
+class MultiCast:
+    """One multi-tensor cast of dskd_cast_scale_many: ``dst_t = src_t * scale_t[row]`` for a list of tensors in ONE launch
+    (direction 0: f32 -> bf16, 1: bf16 -> f32).  The device table is rebuilt only when an address changes (parameters and
+    their persistent copies never move; gradients usually come back at the same addresses: caching allocator)."""
+
+    def __init__(self, direction: int):
+        self.direction, self.key, self.table, self.first, self.n, self.chunks = direction, None, None, None, 0, 0
+
+    @staticmethod
+    def ok(srcs, dsts, scales, direction) -> bool:
+        sd, dd = (torch.float32, torch.bfloat16) if direction == 0 else (torch.bfloat16, torch.float32)
+        if not srcs or len(srcs) != len(dsts) or len(srcs) != len(scales):
+            return False
+        dev = srcs[0].device
+        for s, d, sc in zip(srcs, dsts, scales):
+            if not (s.is_cuda and s.device == dev and d.device == dev and s.dtype == sd and d.dtype == dd
+                    and s.shape == d.shape and s.stride() == d.stride() and s.numel() > 0
+                    and (s.is_contiguous() or s.is_contiguous(memory_format=torch.channels_last))):
+                return False
+            if sc is not None and not (sc.device == dev and sc.dtype == torch.float32 and sc.is_contiguous()
+                                       and sc.numel() > 0 and s.numel() % sc.numel() == 0):
+                return False
+        return True
+
+    def run(self, srcs, dsts, scales):
+        key = tuple((s.data_ptr(), d.data_ptr(), 0 if sc is None else sc.data_ptr(), s.numel(), 0 if sc is None else sc.numel())
+                    for s, d, sc in zip(srcs, dsts, scales))
+        dev = srcs[0].device
+        if key != self.key:
+            chunk = int(load().dskd_cast_scale_chunk())
+            rows, first = [], [0]
+            for sp, dp, cp, n, rows_sc in key:
+                rows += [sp, dp, cp, n, n // rows_sc if rows_sc else n]
+                first.append(first[-1] + (n + chunk - 1) // chunk)
+            # a NEW pinned source per upload (the host runs ahead of the GPU: see optim.FusedClipAdamW)
+            t_host = torch.tensor(rows + first, dtype=torch.int64).pin_memory()
+            if self.table is None or self.table.numel() != t_host.numel() or self.table.device != dev:
+                self.table = torch.empty(t_host.numel(), dtype=torch.int64, device=dev)
+                self.first = torch.empty(len(first), dtype=torch.int32, device=dev)
+            self.table.copy_(t_host, non_blocking=True)
+            self.first.copy_(self.table[len(rows):], non_blocking=True)         # int64 -> int32 on the device
+            self.key, self.n, self.chunks = key, len(key), first[-1]
+        _check(load().dskd_cast_scale_many(self.table.data_ptr(), self.first.data_ptr(), self.n, self.chunks, self.direction,
+                                           _stream(srcs[0])), "dskd_cast_scale_many")
 
 
 # --------------------------------------------------------------------------- a whole Bottleneck, backward fused

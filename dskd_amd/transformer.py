@@ -289,7 +289,15 @@ class _CastParams(torch.autograd.Function):
         ctx.pdtypes = [p.dtype for p in params]
         ctx.pids = [id(p) for p in params]
         outs = [torch.empty_like(p, dtype=dtype) for p in params] if static is None else static
-        torch._foreach_copy_(outs, [p.detach() for p in params])
+        srcs = [p.detach() for p in params]
+        # r4: ONE launch of dskd_cast_scale_many (its table lives with the persistent buffers); ATen's multi-tensor copy
+        # otherwise
+        cache = _CAST_TABLES.setdefault(id(static), (native.MultiCast(0), native.MultiCast(1))) if static is not None else None
+        ctx.cache = cache
+        if cache is not None and dtype == torch.bfloat16 and native.MultiCast.ok(srcs, outs, [None] * len(srcs), 0):
+            cache[0].run(srcs, outs, [None] * len(srcs))
+        else:
+            torch._foreach_copy_(outs, srcs)
         return tuple(outs) if static is None else tuple(o.detach() for o in outs)
 
     @staticmethod
@@ -299,11 +307,18 @@ class _CastParams(torch.autograd.Function):
         slots = [grad_slot(ctx.pids[i], grads[i].shape, ctx.pdtypes[i]) for i in idx]
         ups = [s if s is not None else torch.empty_like(grads[i], dtype=ctx.pdtypes[i]) for s, i in zip(slots, idx)]
         if idx:
-            torch._foreach_copy_(ups, [grads[i] for i in idx])
+            gs = [grads[i] for i in idx]
+            if ctx.cache is not None and native.MultiCast.ok(gs, ups, [None] * len(gs), 1):
+                ctx.cache[1].run(gs, ups, [None] * len(gs))
+            else:
+                torch._foreach_copy_(ups, gs)
         out = [None] * len(grads)
         for j, i in enumerate(idx):
             out[i] = ups[j]
         return (None, None, *out)
+
+
+_CAST_TABLES = {}      # id(list of persistent low-precision buffers) -> (forward, backward) MultiCast tables
 
 
 class _AddLevelEmbed(torch.autograd.Function):

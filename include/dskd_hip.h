@@ -528,6 +528,19 @@ int dskd_clip_adamw(const int64_t* ptrs, const int32_t* meta, const int32_t* chu
                     float beta2, float eps, int64_t step, float max_norm, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * Multi-tensor cast with an optional per-row scale in ONE launch (r4): the step's low-precision parameter copies and the
+ * way back of their gradients -- what ext-mmcv's fp16 hooks / torch.autocast do tensor by tensor, and the fold of the frozen
+ * BatchNorm into the trainable convolution weights, w * gamma / sqrt(var + eps) (mmdet/models/backbones/resnet.py:271-303
+ * with norm_eval=True, configs/deformable_detr/.._il.py:30-37).
+ *   table  device int64 [n][5] = {src, dst, scale (0: none), numel, inner}: dst[i] = src[i] * scale[i / inner], i in memory
+ *          order (inner = elements per output channel of a dense conv weight in either memory format)
+ *   first  device int32 [n + 1]: prefix sums of ceil(numel / dskd_cast_scale_chunk()) (workgroup -> row by binary search)
+ *   direction 0: src f32 -> dst bf16;  1: src bf16 -> dst f32.  16-byte accesses where both pointers allow, else scalar.
+ * ------------------------------------------------------------------------- */
+int dskd_cast_scale_chunk(void);
+int dskd_cast_scale_many(const int64_t* table, const int32_t* first, int n, int total_chunks, int direction, void* stream);
+
+/* ---------------------------------------------------------------------------
  * GroupNorm(32 groups, 256 channels) on a channels_last activation -- the norm of every ChannelMapper level
  * (mmdet/models/necks/channel_mapper.py:10-100: ext-mmcv ConvModule(conv, GN)); replaces F.group_norm and, under
  * autocast, the f32 casts and layout copies around it.  Other channel / group counts are refused.

@@ -1474,6 +1474,45 @@ def test_fused_bottleneck_chain_vs_float_reference(Cin, P, H, W, stride, down):
     assert bool((guard == 5.0).all())
 
 
+def test_multi_tensor_cast_scale_vs_torch():
+    """dskd_cast_scale_many (native.MultiCast): f32 -> bf16 and bf16 -> f32 of a list of tensors in one launch, with and
+    without a per-output-channel scale, against the PyTorch expression -- bit-exact (one rounding, same order: the product
+    is formed in f32 and rounded once).  Sizes that are no multiple of 8, tensors longer than one 8 192-element chunk,
+    channels_last weights, a destination whose address only allows scalar stores (odd offset in a flat buffer)."""
+    g = torch.Generator().manual_seed(3)
+    shapes = [(256, 256), (70,), (70, 256), (64, 64, 3, 3), (128, 256, 1, 1), (3, 5), (1000, 37)]
+    srcs = [torch.randn(sh, generator=g).to(DEV) for sh in shapes]
+    srcs[3] = srcs[3].contiguous(memory_format=torch.channels_last)
+    srcs[4] = srcs[4].contiguous(memory_format=torch.channels_last)
+    scales = [None, None, torch.rand(70, generator=g).to(DEV) + 0.5, torch.rand(64, generator=g).to(DEV) + 0.5,
+              torch.rand(128, generator=g).to(DEV) + 0.5, torch.rand(3, generator=g).to(DEV), None]
+    dsts = [torch.empty_like(s_, dtype=torch.bfloat16) for s_ in srcs]
+    assert native.MultiCast.ok(srcs, dsts, scales, 0)
+    mc = native.MultiCast(0)
+    mc.run(srcs, dsts, scales)
+    mc.run(srcs, dsts, scales)                      # second call: cached table
+    for s_, d, sc in zip(srcs, dsts, scales):
+        ref = s_ if sc is None else s_ * sc.view(-1, *[1] * (s_.dim() - 1))
+        assert torch.equal(d, ref.to(torch.bfloat16)), s_.shape
+    # the way back, into odd offsets of one flat buffer (scalar path) and into fresh tensors (vector path)
+    gsrc = [d.clone() for d in dsts]
+    flat = torch.full((sum(t.numel() for t in gsrc) + 16,), 7.0, device=DEV)
+    outs, off = [], 1
+    for t in gsrc:
+        outs.append(flat[off:off + t.numel()].as_strided(t.shape, t.stride()))
+        off += t.numel()
+    fresh = [torch.empty_like(t, dtype=torch.float32) for t in gsrc]
+    mb = native.MultiCast(1)
+    for target in (outs, fresh):
+        assert native.MultiCast.ok(gsrc, target, scales, 1)
+        mb.run(gsrc, target, scales)
+        for t, o, sc in zip(gsrc, target, scales):
+            ref = t.float() if sc is None else t.float() * sc.view(-1, *[1] * (t.dim() - 1))
+            assert torch.equal(o, ref), t.shape
+    assert float(flat[0]) == 7.0 and bool((flat[off:] == 7.0).all())
+    assert not native.MultiCast.ok(srcs, [d.float() for d in dsts], scales, 0)          # wrong destination dtype
+
+
 @pytest.mark.parametrize("M,N,K,conv3", [(1000 + 37, 256, 512, False), (4200, 512, 1024, False), (333, 256, 64, False),
                                          (2 * 13 * 21, 256, 128, True), (3 * 25 * 42, 512, 512, True)])
 def test_gemm_tile_configurations_agree_with_float_reference(M, N, K, conv3):

@@ -1,5 +1,5 @@
 """Which ATen ops (name, input shapes) launch the elementwise / copy / reduce kernels of one step, and from where?"""
-import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import collections
 import torch, bench
 from torch.profiler import profile, ProfilerActivity
@@ -36,8 +36,8 @@ for ev in prof.events():
             tot += k.duration
 rows = sorted(agg.items(), key=lambda kv: -kv[1][0])
 os.makedirs("gpurun_out", exist_ok=True)
-with open("gpurun_out/r03_aten_tail.txt", "w") as f:
+with open(os.environ.get("ATEN_TAIL_OUT", "gpurun_out/aten_tail.txt"), "w") as f:
     f.write(f"ATen / memcpy kernels of one step: {tot / 1e3:.2f} ms\n")
     for (name, shapes, where), (t, n, ks) in rows[:120]:
         f.write(f"{t / 1e3:7.3f} ms {n:4d}  {name:32s} {shapes:90s} {where}\n")
-print(open("gpurun_out/r03_aten_tail.txt").read()[:6000])
+print(open(os.environ.get("ATEN_TAIL_OUT", "gpurun_out/aten_tail.txt")).read()[:6000])

@@ -1,8 +1,8 @@
-"""Per-phase shader clocks of gemm_nt_kernel / gemm_big_kernel (build: scratch/build_variant.sh gemmprof -DDSKD_GEMM_PROFILE,
-run with DSKD_HIP_LIB=scratch/libs/libdskd_gemmprof.so): every workgroup's wave 0 stamps start / first stage landed / loop
+"""Per-phase shader clocks of gemm_nt_kernel / gemm_big_kernel (build: tools/prof/build_variant.sh gemmprof -DDSKD_GEMM_PROFILE,
+run with DSKD_HIP_LIB=tools/prof/libs/libdskd_gemmprof.so): every workgroup's wave 0 stamps start / first stage landed / loop
 end / epilogue end (s_memtime) + the 100 MHz wall clock at start and end, into a buffer nothing else reads."""
 import sys, os, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from dskd_amd import native
 lib = native.load()

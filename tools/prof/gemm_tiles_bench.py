@@ -2,9 +2,9 @@
 cfg 1..6, with and without the split-K remainder) on every 1x1 / 3x3 convolution shape of ResNet-50 + ChannelMapper at
 B=4, 800x1333 (bf16, channels_last): forward (bias + residual + ReLU) and the input-gradient form (gate + residual).
 Interleaved rounds in one process, random data (cdna_hip_programming.md rules 24, 25).
-Usage: python scratch/r04_gemm_big.py [auto]      ("auto": only cfg 0 against the automatic choice)"""
+Usage: python tools/prof/gemm_tiles_bench.py [auto | k32]      ("auto": only cfg 0 against the automatic choice)"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from dskd_amd import native
 lib = native.load()

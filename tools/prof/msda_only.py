@@ -5,7 +5,7 @@ import math
 import os
 import sys
 
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R)
 sys.path.insert(0, R + "/tests")
 import torch  # noqa: E402

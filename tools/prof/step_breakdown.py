@@ -69,3 +69,26 @@ for t, n in at[:60]:
 tot = sum(t for t, _ in at)
 big = sum(t for t, _ in at if t >= 15000)
 print(f"ATen total {tot/1e6:.2f} ms in {len(at)} launches; launches >= 15 us: {big/1e6:.2f} ms in {sum(1 for t,_ in at if t>=15000)}")
+# ---- idle time of the busiest queue by the kernel that FOLLOWS the gap, and the gap-size histogram (r4): where the main
+# stream's dependency gaps sit
+mainq = max(qs.items(), key=lambda kv: len(kv[1]))[0]
+mrows = [r for r in step if r.get('Queue_Id', r.get('Stream_Id', '?')) == mainq]
+mrows.sort(key=lambda r: int(r['Start_Timestamp']))
+gaps = collections.defaultdict(lambda: [0, 0])
+hist = collections.Counter()
+tot_gap = 0
+pend = int(mrows[0]['End_Timestamp'])
+for prev, r in zip(mrows, mrows[1:]):
+    g_ = int(r['Start_Timestamp']) - pend
+    pend = max(pend, int(r['End_Timestamp']))
+    if g_ <= 0:
+        continue
+    tot_gap += g_
+    key = cat(prev['Kernel_Name'])[:60] + '  ->  ' + cat(r['Kernel_Name'])[:60]
+    gaps[key][0] += g_; gaps[key][1] += 1
+    hist[min(int(g_ / 1000), 50)] += 1
+print(f"queue {mainq}: {len(mrows)} launches, idle between them {tot_gap/1e6:.2f} ms; gap histogram (us: count): " +
+      " ".join(f"{k}:{v}" for k, v in sorted(hist.items())))
+print("largest idle contributions (previous kernel -> next kernel): total us, count, avg us")
+for k, (t, c) in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:45]:
+    print(f"{t/1e3:8.1f} us {c:4d} {t/c/1e3:6.1f}  {k}")
