@@ -756,7 +756,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define DSKD_TN_TOK 64
 #endif
 #ifndef DSKD_TN_NS
-#define DSKD_TN_NS 2
+#define DSKD_TN_NS 3
 #endif
 #ifndef DSKD_TN_ATOMIC_MB
 #define DSKD_TN_ATOMIC_MB 16.0
@@ -779,7 +779,7 @@ __device__ __forceinline__ bf16x8 tr_pair(unsigned a0, unsigned a1) {      // to
 }
 
 template <bool ATOMIC>
-__global__ __launch_bounds__(256, 1) void gemm_tn_kernel(const TnArgs a) {
+__global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const TnArgs a) {
   constexpr int ROWB = 256;                  // bytes of one token's 128 channels
   constexpr int TOK = DSKD_TN_TOK;           // tokens per stage
   constexpr int TILE = TOK * ROWB;           // one operand's tile of a stage
@@ -788,14 +788,24 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_kernel(const TnArgs a) {
   constexpr int LD = TOK / 8;                // LDS-DMA instructions per wave and stage
   extern __shared__ __attribute__((aligned(16))) char smem[];      // NS stages
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // r4: waves 0-3 multiply (one per SIMD), waves 4-7 only issue the LDS-DMA -- every global_load_lds costs the issuing wave
+  // ~100-180 cycles, and with the loads issued by the multiplying waves themselves (r3: one wave per SIMD doing both) those
+  // stalls came straight out of the MFMA stream: 1 970 cycles per stage in every layer shape, of which 512 are MFMA and only
+  // ~220 waiting for data, barrier or fragments (profiles/r04_gemm_tn_phases.txt).
+  const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool producer = wave_all >= 4;
+  const int wave = wave_all & 3;
   const int wn = wave >> 1, wk = wave & 1;
 
   const int tiles_k = a.K >> 7, tiles_n = a.N >> 7;
-  int vb = xcd_remap(blockIdx.x, gridDim.x);
-  const int sp = vb % a.splits; vb /= a.splits;
-  const int tk = vb % tiles_k, tn = vb / tiles_k;
-  (void)tiles_n;
+  // r4: the TILES of one token range are neighbours (tile index fastest), so that the workgroups an XCD receives (a
+  // contiguous range of vb) share their operand rows through its L2: with the split index fastest (r3) the 32 workgroups
+  // of an XCD read 32 different token ranges and every g / x row was pulled from beyond L2 by up to tiles_k + tiles_n XCDs
+  // (FFN dW1: 713 MB of fill for 227 MB of operands, i.e. the launch ran at the Infinity Cache's ~8 TB/s)
+  const int vb = xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles = tiles_k * tiles_n;
+  const int sp = vb / tiles, t_ = vb - sp * tiles;
+  const int tk = t_ % tiles_k, tn = t_ / tiles_k;
   const long long m_begin = (long long)sp * a.chunk;
   const long long m_end = m_begin + a.chunk < a.M ? m_begin + a.chunk : a.M;
   if (m_begin >= m_end) return;
@@ -809,11 +819,12 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_kernel(const TnArgs a) {
   const char* gp = reinterpret_cast<const char*>(a.g) + (long long)tn * 256;
   const char* xp = reinterpret_cast<const char*>(a.x) + (long long)tk * 256;
   const char* const zp = g_zero_page;
-  auto issue = [&](int st) {
+  auto issue = [&](int st, int j0, int j1) {          // the LDS-DMA instructions of token groups [j0, j1) of stage st
     char* sg = smem + (st % NS) * STAGE;
     char* sx = sg + TILE;
 #pragma unroll
     for (int j = 0; j < TOK / 16; ++j) {
+      if (j < j0 || j >= j1) continue;
       const int row = wave * (TOK / 4) + j * 4 + lrow;
       const long long m = m_begin + (long long)st * TOK + row;
       const bool ok = m < m_end;                               // rows past this split's tokens contribute zeros
@@ -849,58 +860,105 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_kernel(const TnArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-#pragma unroll
-  for (int i = 0; i < NS - 1; ++i)
-    if (i < nst) issue(i);
-  for (int st = 0; st < nst; ++st) {
-    if (st + NS - 1 < nst) issue(st + NS - 1);
-    // stage st has landed (my part): all but the loads of the stages behind it are done
-    const int ahead = min(NS - 1, nst - 1 - st);
-    if (ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LD) : "memory");
-    else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LD) : "memory");
-    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD) : "memory");
+  // r4 loop: ONE barrier per stage, placed in front of the stage's LAST MFMA group; the first fragments of stage s + 1 are
+  // requested right behind it (while that group runs), and the LDS-DMA instructions of stage s + NS are issued between the
+  // MFMA groups.  The r3 loop ran barrier -> 8 DMA issues -> fragment reads -> MFMAs in a row on one wave per SIMD:
+  // ~1 400 cycles per stage for 512 of MFMA (what the phase stamps of the same structure in gemm_big_kernel showed,
+  // profiles/r04_gemm_phases.txt).
+  auto wait_stages = [&](int n) {           // all but my n youngest stages have landed
+    if (n >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LD) : "memory");
+    else if (n == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    const unsigned so = (st % NS) * STAGE;
-    // fragments of k-step s + 1 are requested before the MFMAs of k-step s (asm: hipcc would sink every read to its use,
-    // and with one wave per SIMD nothing else covers the LDS latency); LDS returns in order: counted waits
-    bf16x4 fr[2][8];                          // [buffer][g0.lo, g0.hi, g1.lo, g1.hi, x0.lo, x0.hi, x1.lo, x1.hi]
-    auto request = [&](int buf, int ks) {
-      const unsigned o = so + ks * 16 * ROWB;
+  };
+  // Barrier k (k = 0 .. nst - 1) means: stage k has landed (the producers waited for their loads) AND stage k - 1 has been
+  // read (the consumers waited for their fragments) -- so behind it the producers refill the buffer of stage k - 1 with
+  // stage k - 1 + NS.  Both roles pass exactly nst barriers.
+  if (producer) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fr[buf][2 * t + e]) : "v"(ga[t][e] + o));
-          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fr[buf][4 + 2 * t + e]) : "v"(xa[t][e] + o));
-        }
-    };
-    request(0, 0);
-#pragma unroll
-    for (int ks = 0; ks < TOK / 16; ++ks) {
-      const int b = ks & 1;
-      if (ks + 1 < TOK / 16) {
-        request(b ^ 1, ks + 1);
-        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(fr[b][0]), "+v"(fr[b][1]), "+v"(fr[b][2]), "+v"(fr[b][3]), "+v"(fr[b][4]),
-                     "+v"(fr[b][5]), "+v"(fr[b][6]), "+v"(fr[b][7]));
-      } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr[b][0]), "+v"(fr[b][1]), "+v"(fr[b][2]), "+v"(fr[b][3]), "+v"(fr[b][4]),
-                     "+v"(fr[b][5]), "+v"(fr[b][6]), "+v"(fr[b][7]));
-      }
-      bf16x8 gf[2], xf[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const bf16x4 gl = fr[b][2 * t], gh = fr[b][2 * t + 1], xl = fr[b][4 + 2 * t], xh = fr[b][4 + 2 * t + 1];
-        gf[t] = bf16x8{gl[0], gl[1], gl[2], gl[3], gh[0], gh[1], gh[2], gh[3]};
-        xf[t] = bf16x8{xl[0], xl[1], xl[2], xl[3], xh[0], xh[1], xh[2], xh[3]};
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[i], xf[j], acc[i][j], 0, 0, 0);
+    for (int i = 0; i < NS; ++i)
+      if (i < nst) issue(i, 0, TOK / 16);
+    wait_stages(min(NS - 1, nst - 1));
+    __builtin_amdgcn_s_barrier();                          // barrier 0
+    for (int st = 0; st + 1 < nst; ++st) {
+      wait_stages(min(NS - 2, nst - 2 - st));              // my part of stage st + 1 has landed
+      __builtin_amdgcn_s_barrier();                        // barrier st + 1
+      if (st + NS < nst) issue(st + NS, 0, TOK / 16);      // ... into the buffer of stage st
     }
-    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
   }
+  // Consumer stream.  One wave per SIMD: whatever the wave issues besides its MFMAs has to fit into the gaps behind them
+  // (an MFMA holds the issue port for 8 of its 32 cycles), so (1) the 16 fragment reads of k-step s + 1 are interleaved with
+  // the four MFMAs of k-step s instead of standing in front of them, (2) their addresses are 8 per-stage bases + immediate
+  // offsets (64 v_add per stage before), (3) the stage's barrier sits in front of its last MFMA group, whose gaps take the
+  // first reads of the next stage.
+  bf16x4 fr[2][8];                          // [buffer][g0.lo, g0.hi, g1.lo, g1.hi, x0.lo, x0.hi, x1.lo, x1.hi]
+  unsigned sa[8];                           // this stage's fragment bases: g (t, e) = sa[2 t + e], x (t, e) = sa[4 + 2 t + e]
+  auto set_bases = [&](int st) {
+    const unsigned o = (st % NS) * STAGE;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) { sa[2 * t + e] = ga[t][e] + o; sa[4 + 2 * t + e] = xa[t][e] + o; }
+  };
+#define TN_READ(buf, idx, KS) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fr[buf][idx]) : "v"(sa[idx]), "n"((KS) * 16 * ROWB))
+#define TN_READS(BUF, KS, F) TN_READ(BUF, F, KS); TN_READ(BUF, F + 1, KS); TN_READ(BUF, F + 2, KS); TN_READ(BUF, F + 3, KS)
+  auto frag = [&](int b, int i) { return bf16x8{fr[b][i][0], fr[b][i][1], fr[b][i][2], fr[b][i][3], fr[b][i + 1][0], fr[b][i + 1][1], fr[b][i + 1][2], fr[b][i + 1][3]}; };
+#define TN_MFMA(B, I, J) acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(B, 2 * (I)), frag(B, 4 + 2 * (J)), acc[I][J], 0, 0, 0)
+#define TN_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define TN_WAIT0(B) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr[B][0]), "+v"(fr[B][1]), "+v"(fr[B][2]), "+v"(fr[B][3]), "+v"(fr[B][4]), \
+                                 "+v"(fr[B][5]), "+v"(fr[B][6]), "+v"(fr[B][7])::"memory")
+  // one k-step: the 4 MFMAs on buffer B with the 8 reads of (buffer NB, k-step NK) in their gaps
+#define TN_GROUP(B, NB, NK)                                                   \
+  TN_MFMA(B, 0, 0); TN_FENCE(); TN_READS(NB, NK, 0); TN_FENCE();              \
+  TN_MFMA(B, 0, 1); TN_FENCE(); TN_READS(NB, NK, 4); TN_FENCE();              \
+  TN_MFMA(B, 1, 0); TN_MFMA(B, 1, 1); TN_FENCE();
+#ifdef DSKD_GEMM_PROFILE
+  long long t_wait = 0, t_bar = 0, t_lgkm = 0, t_mark;
+#define TN_T0() t_mark = (long long)__builtin_amdgcn_s_memtime()
+#define TN_ACC(v) do { const long long n_ = (long long)__builtin_amdgcn_s_memtime(); v += n_ - t_mark; t_mark = n_; } while (0)
+#else
+#define TN_T0()
+#define TN_ACC(v)
+#endif
+  PROF(0);
+  __builtin_amdgcn_s_barrier();                            // barrier 0: stage 0 has landed
+  PROF(1);
+  set_bases(0);
+  TN_READS(0, 0, 0); TN_READS(0, 0, 4);
+  for (int st = 0; st < nst; ++st) {
+    TN_T0(); TN_WAIT0(0); TN_ACC(t_lgkm); TN_FENCE();
+    TN_GROUP(0, 1, 1)                                     // k-step 0 (buffer 0), reads of k-step 1 -> buffer 1
+    TN_T0(); TN_WAIT0(1); TN_ACC(t_lgkm); TN_FENCE();
+    TN_GROUP(1, 0, 2)                                     // k-step 1, reads of k-step 2 -> buffer 0
+    TN_T0(); TN_WAIT0(0); TN_ACC(t_lgkm); TN_FENCE();
+    TN_GROUP(0, 1, 3)                                     // k-step 2, reads of k-step 3 -> buffer 1
+    TN_T0(); TN_WAIT0(1); TN_ACC(t_lgkm); TN_FENCE();      // every read of this stage has returned
+    if (st + 1 < nst) {
+      TN_T0();
+      __builtin_amdgcn_s_barrier();                        // barrier st + 1: stage st + 1 has landed; stage st is read
+      TN_ACC(t_bar);
+      set_bases(st + 1);
+      TN_FENCE();
+      TN_GROUP(1, 0, 0)                                   // k-step 3 (buffer 1), reads of the next stage's k-step 0 -> buffer 0
+    } else {
+      TN_MFMA(1, 0, 0); TN_MFMA(1, 0, 1); TN_MFMA(1, 1, 0); TN_MFMA(1, 1, 1);
+    }
+    TN_FENCE();
+  }
+#undef TN_GROUP
+#undef TN_WAIT0
+#undef TN_FENCE
+#undef TN_MFMA
+#undef TN_READS
+#undef TN_READ
+  PROF(2);
+#ifdef DSKD_GEMM_PROFILE
+  if (g_gemm_prof && threadIdx.x == 0) {
+    long long* pp = g_gemm_prof + (long long)blockIdx.x * 8;
+    pp[3] = t_wait; pp[5] = ((long long)nst << 40) | (t_bar & 0xFFFFFFFFFFll); pp[7] = t_lgkm;
+  }
+#endif
   // acc[i][j]: rows = n (register index), column = k (lane): 32 consecutive k per half-wave -> 128-byte atomic rows
   const int r = lane & 31;
 #pragma unroll
@@ -1214,7 +1272,7 @@ static int gemm_tn_launch(const TnArgs& a, long long tiles, hipStream_t st) {
       return fail(DSKD_ERR_LAUNCH, "dskd_gemm_tn: cannot reserve %d bytes of LDS", lds);
     done[dev] = true;
   }
-  hipLaunchKernelGGL(gemm_tn_kernel<ATOMIC>, dim3((unsigned)(tiles * a.splits)), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(gemm_tn_kernel<ATOMIC>, dim3((unsigned)(tiles * a.splits)), dim3(512), lds, st, a);
   return check_launch("dskd_gemm_tn");
 }
 

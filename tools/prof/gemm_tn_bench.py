@@ -1,6 +1,6 @@
 """gemm_tn per layer shape of the step: us, TFLOP/s (scratch; B=4 800x1333 token counts)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from dskd_amd import native
 native.load()
