@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void add_ln_fwd_kernel(
 
 template <typename T>
 __global__ __launch_bounds__(kRowsPerBlock * 64) void add_ln_bwd_kernel(
-    const T* __restrict__ dy, const T* __restrict__ dq, const T* __restrict__ z,
+    const T* __restrict__ dy, const T* __restrict__ dy2, const T* __restrict__ dq, const T* __restrict__ z,
     const float* __restrict__ stats, const float* __restrict__ gamma, T* __restrict__ dres,
     T* __restrict__ dh, float* __restrict__ dgamma, float* __restrict__ dbeta, int copies, long long rows,
     Drop dr) {
@@ -203,6 +203,12 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void add_ln_bwd_kernel(
     const long long rr = ok ? row : rows - 1;
     float g[E], zv[E];
     load_vec(dy + rr * kD + c, g);
+    if (dy2) {          // r4: y had two consumers -- their gradients arrive as two tensors and are summed here, not by a launch
+      float t[E];
+      load_vec(dy2 + rr * kD + c, t);
+#pragma unroll
+      for (int i = 0; i < E; ++i) g[i] += t[i];
+    }
     if (dq) {
       float t[E];
       load_vec(dq + rr * kD + c, t);
@@ -340,16 +346,29 @@ extern "C" int dskd_add_ln_fwd(const void* h, const void* res, const float* pos,
   return check_launch("dskd_add_ln_fwd");
 }
 
+extern "C" int dskd_add_ln_bwd2(const void* dy, const void* dy2, const void* dq, const void* z, const float* stats,
+                                const float* gamma, void* dres, void* dh, float* dgamma, float* dbeta,
+                                int copies, int64_t rows, int D, float drop_p, uint64_t seed,
+                                uint64_t offset, const uint64_t* epoch, int dtype, void* stream);
+
 extern "C" int dskd_add_ln_bwd(const void* dy, const void* dq, const void* z, const float* stats,
                                const float* gamma, void* dres, void* dh, float* dgamma, float* dbeta,
                                int copies, int64_t rows, int D, float drop_p, uint64_t seed,
                                uint64_t offset, const uint64_t* epoch, int dtype, void* stream) {
+  return dskd_add_ln_bwd2(dy, nullptr, dq, z, stats, gamma, dres, dh, dgamma, dbeta, copies, rows, D, drop_p, seed, offset,
+                          epoch, dtype, stream);
+}
+
+extern "C" int dskd_add_ln_bwd2(const void* dy, const void* dy2, const void* dq, const void* z, const float* stats,
+                                const float* gamma, void* dres, void* dh, float* dgamma, float* dbeta,
+                                int copies, int64_t rows, int D, float drop_p, uint64_t seed,
+                                uint64_t offset, const uint64_t* epoch, int dtype, void* stream) {
   if (D != kD) return fail(DSKD_ERR_INVALID_ARG, "dskd_add_ln_bwd: only D=256 supported (got %d)", D);
   if (dtype != DSKD_DTYPE_F32 && dtype != DSKD_DTYPE_BF16)
     return fail(DSKD_ERR_INVALID_ARG, "dskd_add_ln_bwd: unknown dtype %d", dtype);
   if (rows < 0 || copies < 1 || !dy || !z || !stats || !gamma || !dres || !dgamma || !dbeta)
     return fail(DSKD_ERR_INVALID_ARG, "dskd_add_ln_bwd: null pointer, negative row count or copies < 1");
-  if (!aligned16(dy) || !aligned16(dq) || !aligned16(z) || !aligned16(stats) || !aligned16(gamma) ||
+  if (!aligned16(dy) || !aligned16(dy2) || !aligned16(dq) || !aligned16(z) || !aligned16(stats) || !aligned16(gamma) ||
       !aligned16(dres) || !aligned16(dh))
     return fail(DSKD_ERR_INVALID_ARG, "dskd_add_ln_bwd: pointers must be 16-byte aligned");
   Drop dr;
@@ -360,10 +379,10 @@ extern "C" int dskd_add_ln_bwd(const void* dy, const void* dq, const void* z, co
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(grid_for(rows, dtype == DSKD_DTYPE_F32 ? 1 : 2)), block(kRowsPerBlock * 64);
   if (dtype == DSKD_DTYPE_F32)
-    hipLaunchKernelGGL(add_ln_bwd_kernel<float>, grid, block, 0, st, (const float*)dy, (const float*)dq,
+    hipLaunchKernelGGL(add_ln_bwd_kernel<float>, grid, block, 0, st, (const float*)dy, (const float*)dy2, (const float*)dq,
                        (const float*)z, stats, gamma, (float*)dres, (float*)dh, dgamma, dbeta, copies, (long long)rows, dr);
   else
-    hipLaunchKernelGGL(add_ln_bwd_kernel<__bf16>, grid, block, 0, st, (const __bf16*)dy, (const __bf16*)dq,
+    hipLaunchKernelGGL(add_ln_bwd_kernel<__bf16>, grid, block, 0, st, (const __bf16*)dy, (const __bf16*)dy2, (const __bf16*)dq,
                        (const __bf16*)z, stats, gamma, (__bf16*)dres, (__bf16*)dh, dgamma, dbeta, copies,
                        (long long)rows, dr);
   return check_launch("dskd_add_ln_bwd");

@@ -39,6 +39,7 @@ _SIGNATURES = {
     "dskd_add_ln_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, _f32, _f32,
                                    C.c_uint64, C.c_uint64, _vp, C.c_int, _vp]),
     "dskd_add_ln_bwd": (C.c_int, [_vp] * 9 + [C.c_int, _i64, C.c_int, _f32, C.c_uint64, C.c_uint64, _vp, C.c_int, _vp]),
+    "dskd_add_ln_bwd2": (C.c_int, [_vp] * 10 + [C.c_int, _i64, C.c_int, _f32, C.c_uint64, C.c_uint64, _vp, C.c_int, _vp]),
     "dskd_add_pos": (C.c_int, [_vp, _vp, _vp, _i64, _i64, C.c_int, C.c_int, _vp]),
     "dskd_bias_act": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_dropout_fwd": (C.c_int, [_vp, _i64, _f32, C.c_uint64, C.c_uint64, _vp, C.c_int, _vp]),
@@ -495,7 +496,7 @@ def _pos_f32(pos):
 
 class _AddLNFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, h, res, gamma, beta, pos, eps, p, want_q):
+    def forward(ctx, h, res, gamma, beta, pos, eps, p, want_q, fork=False):
         dt = {torch.float32: DTYPE_F32, torch.bfloat16: DTYPE_BF16}[h.dtype]
         h, res = h.contiguous(), res.contiguous()
         rows, D = h.numel() // h.shape[-1], h.shape[-1]
@@ -518,25 +519,31 @@ class _AddLNFunction(torch.autograd.Function):
             ctx.save_for_backward(z, stats, gamma_f)
         ctx.meta = (dt, rows, D, p, seed, offset, None if pos is None else tuple(pos.shape), gamma.dtype, want_q)
         ctx.pos_dtype = None if pos is None else pos.dtype
-        return y, q
+        # fork: y is handed out TWICE (the second an alias): a caller that feeds y to two consumers gives each its own, and
+        # their gradients come back here as two tensors that the backward kernel sums itself (no add launch by autograd)
+        return y, (y.detach() if fork else None), q
 
     @staticmethod
-    def backward(ctx, dy, dq):
+    def backward(ctx, dy, dy2, dq):
         z, stats, gamma_f = ctx.saved_tensors
         dt, rows, D, p, seed, offset, pos_shape, gdtype, want_q = ctx.meta
         if dy is None:
+            dy, dy2 = dy2, None
+        if dy is None:
             dy = zeros(z.shape, z.dtype, z.device)
         dy = dy.contiguous().to(z.dtype)
+        dy2 = dy2.contiguous().to(z.dtype) if dy2 is not None else None
         dq = dq.contiguous().to(z.dtype) if (want_q and dq is not None) else None
         dres = torch.empty_like(z)
         dh = torch.empty_like(z) if p > 0 else None
         copies = _colsum_copies(rows)
         dgb = _persistent_acc((2, copies, D), z.device)
-        rc = load().dskd_add_ln_bwd(dy.data_ptr(), None if dq is None else dq.data_ptr(), z.data_ptr(), stats.data_ptr(),
-                                    gamma_f.data_ptr(), dres.data_ptr(), None if dh is None else dh.data_ptr(),
-                                    dgb[0].data_ptr(), dgb[1].data_ptr(), copies, rows, D, p, seed, offset,
-                                    dropout_epoch(z.device).data_ptr() if p > 0 else None, dt, _stream(z))
-        _check(rc, "dskd_add_ln_bwd")
+        rc = load().dskd_add_ln_bwd2(dy.data_ptr(), None if dy2 is None else dy2.data_ptr(),
+                                     None if dq is None else dq.data_ptr(), z.data_ptr(), stats.data_ptr(),
+                                     gamma_f.data_ptr(), dres.data_ptr(), None if dh is None else dh.data_ptr(),
+                                     dgb[0].data_ptr(), dgb[1].data_ptr(), copies, rows, D, p, seed, offset,
+                                     dropout_epoch(z.device).data_ptr() if p > 0 else None, dt, _stream(z))
+        _check(rc, "dskd_add_ln_bwd2")
         dgb = sum_clear(dgb, 2, copies, D)
         dpos = None
         if pos_shape is not None and ctx.needs_input_grad[4] and dq is not None:
@@ -548,7 +555,7 @@ class _AddLNFunction(torch.autograd.Function):
                 dpos = dq.view(pos_shape)          # nothing to sum: hand the gradient over as it is (a view, no pass)
             else:
                 dpos = dq.view(rows // pos_rows, pos_rows, D).sum(0, dtype=torch.float32).view(pos_shape)
-        return (dres if dh is None else dh), dres, dgb[0].to(gdtype), dgb[1].to(gdtype), dpos, None, None, None
+        return (dres if dh is None else dh), dres, dgb[0].to(gdtype), dgb[1].to(gdtype), dpos, None, None, None, None
 
 
 class _AddPosFunction(torch.autograd.Function):
@@ -587,20 +594,23 @@ def add_pos(x: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:
 
 
 def add_layer_norm(h: torch.Tensor, res: torch.Tensor, norm: torch.nn.LayerNorm, p: float = 0.0,
-                   pos: Optional[torch.Tensor] = None, want_q: bool = False):
+                   pos: Optional[torch.Tensor] = None, want_q: bool = False, fork: bool = False):
     """``y = norm(res + dropout_p(h))`` and, with ``want_q``, ``q = y + pos`` -- the tail of a
     transformer sub-layer (ext-mmcv BaseTransformerLayer: ``identity + dropout(out)`` then
     'norm', then the next layer's ``query + query_pos``) as ONE launch each way.
     h, res: [..., 256] f32 | bf16 (same dtype); pos: [..., Nv, 256] broadcast over the leading
-    (batch) dimension of a batch-first token tensor.  Returns (y, q or None)."""
+    (batch) dimension of a batch-first token tensor.  Returns (y, q or None); with ``fork`` (y, y', q or None) where
+    y' is y again as a second autograd output: feed y to one consumer and y' to the other (e.g. the FFN and the residual of
+    the next LayerNorm) and their two gradients are summed inside the backward launch instead of by an add launch."""
     f = _dispatch_cpu("add_layer_norm", h)
     if f is not None:
-        return f(h, res, norm, p, pos, want_q)
+        y, q = f(h, res, norm, p, pos, want_q)
+        return (y, y, q) if fork else (y, q)
     _need_gpu(h, res)
     if res.dtype != h.dtype:
         res = res.to(h.dtype)
-    y, q = _AddLNFunction.apply(h, res, norm.weight, norm.bias, pos, float(norm.eps), float(p), bool(want_q))
-    return y, q
+    y, y2, q = _AddLNFunction.apply(h, res, norm.weight, norm.bias, pos, float(norm.eps), float(p), bool(want_q), bool(fork))
+    return (y, y2, q) if fork else (y, q)
 
 
 # --------------------------------------------------------------------------- FFN hidden activation

@@ -973,10 +973,12 @@ class BaseTransformerLayer(nn.Module):
         tag = getattr(query, "_dskd_q", None)
         q_next = tag[0] if (can_q and tag is not None and tag[1] is query_pos and tag[0].shape == x.shape) else None
         ai = 0
+        x_ffn = None
         for k, (op, mod, norm) in enumerate(plan):
             p = mod.tail_dropout_p()
             if op == "ffn":
-                h = mod.core(x, final_dropout=False)
+                h = mod.core(x if x_ffn is None else x_ffn, final_dropout=False)
+                x_ffn = None
             elif op == "self_attn":
                 if q_next is not None:        # q = k = x + pos already formed; v = x
                     h = mod(q_next, q_next, x, None, query_pos=None, key_pos=None, attn_mask=attn_masks[ai],
@@ -995,7 +997,13 @@ class BaseTransformerLayer(nn.Module):
                 ai += 1
             nxt = plan[(k + 1) % len(plan)][0]          # the sub-layer that reads this LayerNorm's output (next layer: same plan)
             want_q = can_q and nxt != "ffn" and (nxt == "self_attn" or key_pos is None)
-            x, q_next = native.add_layer_norm(h.to(dtype), x, norm, p=p, pos=query_pos if want_q else None, want_q=want_q)
+            if nxt == "ffn" and k + 1 < len(plan) and x.is_cuda:
+                # the FFN and the residual of the LayerNorm behind it both read this output: two autograd outputs, their
+                # gradients summed inside add_ln_bwd (see the encoder)
+                x_ffn, x, q_next = native.add_layer_norm(h.to(dtype), x, norm, p=p, fork=True)
+            else:
+                x_ffn = None
+                x, q_next = native.add_layer_norm(h.to(dtype), x, norm, p=p, pos=query_pos if want_q else None, want_q=want_q)
         if q_next is not None:
             x._dskd_q = (q_next, query_pos)
         return x
@@ -1129,13 +1137,20 @@ class DetrTransformerEncoder(TransformerLayerSequence):
             pos = pos_in
         q = native.add_pos(x, pos)                  # one pass; ATen: generic mixed-dtype add (120 us) + cast
         last = len(self.layers) - 1
+        # Every LayerNorm output feeds TWO consumers (the next sub-layer and the next residual add).  The LayerNorm hands it
+        # out as two autograd outputs (fork) and sums their gradients inside add_ln_bwd: autograd's own sum was an add
+        # launch over [B, 22 223, 256] per LayerNorm and step (12 of the 21 such adds, profiles/r04_aten_tail.txt).
+        xv = xr = x                                  # value_proj input / residual of the attention sub-layer
         for i, layer in enumerate(self.layers):
             att, ffn = layer.attentions[0], layer.ffns[0]
-            h = att.core(q, x, reference_points, spatial_shapes, query_key_padding_mask)
-            x1, _ = native.add_layer_norm(h, x, layer.norms[0], p=att.dropout.p if att.training else 0.0)
+            h = att.core(q, xv, reference_points, spatial_shapes, query_key_padding_mask)
+            x1f, x1r, _ = native.add_layer_norm(h, xr, layer.norms[0], p=att.dropout.p if att.training else 0.0, fork=True)
             p_tail = ffn.layers[-1].p if ffn.training else 0.0
-            f = ffn.core(x1, final_dropout=False)
-            x, q = native.add_layer_norm(f, x1, layer.norms[1], p=p_tail, pos=None if i == last else pos, want_q=i != last)
+            f = ffn.core(x1f, final_dropout=False)
+            if i == last:
+                x, _ = native.add_layer_norm(f, x1r, layer.norms[1], p=p_tail)
+            else:
+                xv, xr, q = native.add_layer_norm(f, x1r, layer.norms[1], p=p_tail, pos=pos, want_q=True, fork=True)
         return x
 
 

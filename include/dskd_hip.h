@@ -319,6 +319,12 @@ int dskd_add_ln_bwd(const void* dy, const void* dq, const void* z, const float* 
                     const float* gamma, void* dres, void* dh, float* dgamma, float* dbeta,
                     int copies, int64_t rows, int D, float drop_p, uint64_t seed, uint64_t offset,
                     const uint64_t* epoch, int dtype, void* stream);
+/* The same with a SECOND gradient of y (dy2, same shape, may be NULL): when y feeds two consumers (the next sub-layer and the
+ * next residual add) their gradients arrive as two tensors and are summed in this launch instead of by an add launch (r4). */
+int dskd_add_ln_bwd2(const void* dy, const void* dy2, const void* dq, const void* z, const float* stats,
+                     const float* gamma, void* dres, void* dh, float* dgamma, float* dbeta,
+                     int copies, int64_t rows, int D, float drop_p, uint64_t seed, uint64_t offset,
+                     const uint64_t* epoch, int dtype, void* stream);
 /* q = bf16(x + pos[r % pos_rows]): x, q device [rows, D] bf16, pos device f32 [pos_rows, D]; D % 8 == 0 -- the first
  * encoder layer's `query + query_pos` (ext-mmcv MultiScaleDeformableAttention.forward), later ones come from
  * dskd_add_ln_fwd(want q). */

@@ -1474,6 +1474,46 @@ def test_fused_bottleneck_chain_vs_float_reference(Cin, P, H, W, stride, down):
     assert bool((guard == 5.0).all())
 
 
+@pytest.mark.parametrize("dtype,want_q", [(torch.float32, True), (torch.bfloat16, True), (torch.bfloat16, False)])
+def test_add_layer_norm_fork_sums_the_two_gradients_in_the_kernel(dtype, want_q):
+    """native.add_layer_norm(fork=True) hands y out as two autograd outputs; the gradients of the two consumers reach
+    dskd_add_ln_bwd2 as dy / dy2 and are summed there (f32) -- same d(h), d(res), d(gamma), d(beta) as the single-output form,
+    where autograd adds them with a launch of its own.  One consumer may also be absent (gradient None)."""
+    g = torch.Generator().manual_seed(9)
+    rows = 3 * 37
+    h = torch.randn(3, 37, 256, generator=g).to(DEV, dtype)
+    res = torch.randn(3, 37, 256, generator=g).to(DEV, dtype)
+    pos = torch.randn(1, 37, 256, generator=g).to(DEV)
+    a, b, c = (torch.randn(3, 37, 256, generator=g).to(DEV, dtype) for _ in range(3))
+    norm = torch.nn.LayerNorm(256).to(DEV)
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5)
+        norm.bias.normal_()
+
+    def run(fork, drop_second=False):
+        hh, rr = h.clone().requires_grad_(True), res.clone().requires_grad_(True)
+        norm.zero_grad()
+        if fork:
+            y1, y2, q = native.add_layer_norm(hh, rr, norm, 0.0, pos if want_q else None, want_q, fork=True)
+        else:
+            y1, q = native.add_layer_norm(hh, rr, norm, 0.0, pos if want_q else None, want_q)
+            y2 = y1
+        loss = (y1.float() * a.float()).sum()
+        if not drop_second:
+            loss = loss + (y2.float() * b.float()).sum()
+        if want_q:
+            loss = loss + (q.float() * c.float()).sum()
+        loss.backward()
+        return [hh.grad.float(), rr.grad.float(), norm.weight.grad.float().clone(), norm.bias.grad.float().clone()]
+
+    tol = 1e-5 if dtype == torch.float32 else 2e-2       # bf16: autograd's own sum rounds dy1 + dy2 to bf16 first
+    for drop in (False, True):
+        ref, got = run(False, drop), run(True, drop)
+        for r_, g_ in zip(ref, got):
+            assert float((r_ - g_).abs().max()) <= tol * float(r_.abs().max()) + 1e-6, (dtype, want_q, drop)
+    assert rows == h.shape[0] * h.shape[1]
+
+
 def test_multi_tensor_cast_scale_vs_torch():
     """dskd_cast_scale_many (native.MultiCast): f32 -> bf16 and bf16 -> f32 of a list of tensors in one launch, with and
     without a per-output-channel scale, against the PyTorch expression -- bit-exact (one rounding, same order: the product
