@@ -770,6 +770,7 @@ struct TnArgs {
   int N, K, ldg, ldx;
   int splits;            // workgroups along M per output tile
   long long chunk;       // tokens per split (a multiple of 32)
+  int tn;                // 128-row groups of the output tile (1: 128 x 128, 2: 256 x 128)
 };
 
 __device__ __forceinline__ bf16x8 tr_pair(unsigned a0, unsigned a1) {      // tokens t .. t+3 (a0) and t+4 .. t+7 (a1) of one channel column
@@ -778,14 +779,19 @@ __device__ __forceinline__ bf16x8 tr_pair(unsigned a0, unsigned a1) {      // to
   return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-template <bool ATOMIC>
-__global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const TnArgs a) {
+template <bool ATOMIC, int TN>
+__global__ __launch_bounds__((4 * TN + 4) * 64) void gemm_tn_kernel(const TnArgs a) {
+  // TN = 2 (r4): a 256 (N) x 128 (K) output tile, eight multiplying waves (two per SIMD) + four producers: per stage 48 KB of
+  // operands for 4.2 MFLOP instead of 32 KB for 2.1 -- with the 128 x 128 tile the matrix pipe (512 cycles per stage), the
+  // vector-memory path (32 KB at 64 B/clk) and the LDS (32 KB written + 64 KB read) were all "about 500 cycles" each and the
+  // stage took ~1 400.
   constexpr int ROWB = 256;                  // bytes of one token's 128 channels
   constexpr int TOK = DSKD_TN_TOK;           // tokens per stage
-  constexpr int TILE = TOK * ROWB;           // one operand's tile of a stage
-  constexpr int STAGE = 2 * TILE;
+  constexpr int TILE = TOK * ROWB;           // one [tokens][128 channels] image of a stage
+  constexpr int STAGE = (TN + 1) * TILE;     // TN images of g, one of x
   constexpr int NS = DSKD_TN_NS;             // stages in LDS; the DMA runs NS - 1 stages ahead
-  constexpr int LD = TOK / 8;                // LDS-DMA instructions per wave and stage
+  constexpr int LD = (TN + 1) * TOK / 16;    // LDS-DMA instructions per producer wave and stage
+  constexpr int NC = 4 * TN;                 // multiplying waves
   extern __shared__ __attribute__((aligned(16))) char smem[];      // NS stages
   const int lane = threadIdx.x & 63;
   // r4: waves 0-3 multiply (one per SIMD), waves 4-7 only issue the LDS-DMA -- every global_load_lds costs the issuing wave
@@ -793,11 +799,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const TnArgs a) {
   // stalls came straight out of the MFMA stream: 1 970 cycles per stage in every layer shape, of which 512 are MFMA and only
   // ~220 waiting for data, barrier or fragments (profiles/r04_gemm_tn_phases.txt).
   const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const bool producer = wave_all >= 4;
-  const int wave = wave_all & 3;
-  const int wn = wave >> 1, wk = wave & 1;
+  const bool producer = wave_all >= NC;
+  const int wave = producer ? wave_all - NC : wave_all;      // producer: 0 .. 3 (token rows it fills); consumer: 0 .. NC - 1
+  const int wn = wave >> 1, wk = wave & 1;                   // consumer: 64 output rows wn, 64 output columns wk
 
-  const int tiles_k = a.K >> 7, tiles_n = a.N >> 7;
+  const int tiles_k = a.K >> 7, tiles_n = a.N / (128 * TN);
   // r4: the TILES of one token range are neighbours (tile index fastest), so that the workgroups an XCD receives (a
   // contiguous range of vb) share their operand rows through its L2: with the split index fastest (r3) the 32 workgroups
   // of an XCD read 32 different token ranges and every g / x row was pulled from beyond L2 by up to tiles_k + tiles_n XCDs
@@ -816,12 +822,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const TnArgs a) {
   // without it the four rows of a transposing read fall on the same banks) -- applied on the SOURCE address, the LDS
   // image of one DMA instruction stays lane-linear.
   const int lrow = lane >> 4;
-  const char* gp = reinterpret_cast<const char*>(a.g) + (long long)tn * 256;
+  const char* gp = reinterpret_cast<const char*>(a.g) + (long long)tn * 256 * TN;
   const char* xp = reinterpret_cast<const char*>(a.x) + (long long)tk * 256;
   const char* const zp = g_zero_page;
   auto issue = [&](int st, int j0, int j1) {          // the LDS-DMA instructions of token groups [j0, j1) of stage st
     char* sg = smem + (st % NS) * STAGE;
-    char* sx = sg + TILE;
+    char* sx = sg + TN * TILE;
 #pragma unroll
     for (int j = 0; j < TOK / 16; ++j) {
       if (j < j0 || j >= j1) continue;
@@ -829,8 +835,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const TnArgs a) {
       const long long m = m_begin + (long long)st * TOK + row;
       const bool ok = m < m_end;                               // rows past this split's tokens contribute zeros
       const int lcol = ((lane & 15) ^ ((lrow << 2) | ((wave * (TOK / 16) + j) & 3))) * 16;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ok ? gp + m * a.ldg * 2 + lcol : zp),
-                                       (__attribute__((address_space(3))) void*)(sg + (wave * (TOK / 4) + j * 4) * ROWB), 16, 0, 0);
+#pragma unroll
+      for (int im = 0; im < TN; ++im)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ok ? gp + m * a.ldg * 2 + im * 256 + lcol : zp),
+                                         (__attribute__((address_space(3))) void*)(sg + im * TILE + (wave * (TOK / 4) + j * 4) * ROWB), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ok ? xp + m * a.ldx * 2 + lcol : zp),
                                        (__attribute__((address_space(3))) void*)(sx + (wave * (TOK / 4) + j * 4) * ROWB), 16, 0, 0);
     }
@@ -848,9 +856,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const TnArgs a) {
     for (int e = 0; e < 2; ++e) {
       const int row = 8 * h + q + 4 * e;
       const int f = ((row & 3) << 2) | ((row >> 2) & 3);
-      const int cg = wn * 64 + t * 32 + 16 * g1 + 4 * p, cx = wk * 64 + t * 32 + 16 * g1 + 4 * p;
-      ga[t][e] = base + row * ROWB + ((((cg >> 3) ^ f)) << 4) + ((cg & 7) << 1);
-      xa[t][e] = base + TILE + row * ROWB + ((((cx >> 3) ^ f)) << 4) + ((cx & 7) << 1);
+      const int cg = (wn & 1) * 64 + t * 32 + 16 * g1 + 4 * p, cx = wk * 64 + t * 32 + 16 * g1 + 4 * p;
+      ga[t][e] = base + (wn >> 1) * TILE + row * ROWB + ((((cg >> 3) ^ f)) << 4) + ((cg & 7) << 1);
+      xa[t][e] = base + TN * TILE + row * ROWB + ((((cx >> 3) ^ f)) << 4) + ((cx & 7) << 1);
     }
   f32x16 acc[2][2];
 #pragma unroll
@@ -939,13 +947,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const TnArgs a) {
       __builtin_amdgcn_s_barrier();                        // barrier st + 1: stage st + 1 has landed; stage st is read
       TN_ACC(t_bar);
       set_bases(st + 1);
-      TN_FENCE();
-      TN_GROUP(1, 0, 0)                                   // k-step 3 (buffer 1), reads of the next stage's k-step 0 -> buffer 0
-    } else {
-      TN_MFMA(1, 0, 0); TN_MFMA(1, 0, 1); TN_MFMA(1, 1, 0); TN_MFMA(1, 1, 1);
     }
     TN_FENCE();
+    // k-step 3 (buffer 1) with the reads of the next stage's k-step 0 -> buffer 0 in its gaps.  After the last stage the same
+    // reads go to this stage's buffer again and are never used: ONE copy of the group keeps the accumulators in place (an
+    // if / else pair made the compiler hold a second set of 64 registers)
+    TN_GROUP(1, 0, 0)
+    TN_FENCE();
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the look-ahead reads of the last stage land in dead registers
 #undef TN_GROUP
 #undef TN_WAIT0
 #undef TN_FENCE
@@ -969,7 +979,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const TnArgs a) {
       // and writes it with plain stores (the chip's float-atomic rate is ~1.3 TB/s: the 16 MB flush of a launch was 12 us
       // of its 26-90); reduce_cvt_kernel sums the planes and hands the result over in the parameter's dtype.
       float* cp = a.c + (ATOMIC ? 0ll : (long long)sp * a.N * a.K) +
-                  (long long)(tn * 128 + wn * 64 + i * 32 + 4 * h) * a.K + tk * 128 + wk * 64 + j * 32 + r;
+                  (long long)(tn * 128 * TN + wn * 64 + i * 32 + 4 * h) * a.K + tk * 128 + wk * 64 + j * 32 + r;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         if constexpr (ATOMIC) atomicAdd(cp + (long long)((e & 3) + 8 * (e >> 2)) * a.K, acc[i][j][e]);
@@ -1044,7 +1054,10 @@ using namespace dskd;
 // dskd_gemm_nt_tune: a tuning hook for microbenchmarks and tests (scratch/r04_gemm_big.py) -- cfg < 0: automatic
 // (default); splits: 0 automatic, 1 never split, > 1 forced (clamped to the K stages and the scratch).
 static int g_tune_cfg = -1, g_tune_splits = 0;
+static int g_tn_force = 0;      // tuning hook (dskd_gemm_nt_tune with cfg -2 / -3): force the 128 x 128 / 256 x 128 dW tile
 extern "C" int dskd_gemm_nt_tune(int cfg, int splits) {
+  if (cfg == -2 || cfg == -3) { g_tn_force = cfg == -2 ? 1 : 2; return DSKD_OK; }      // dW tile: 128 x 128 / 256 x 128
+  if (cfg == -1) g_tn_force = 0;
   if (cfg > kBigCfgs + 2) return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_nt_tune: cfg %d > %d", cfg, kBigCfgs + 2);
   g_tune_cfg = cfg;
   g_tune_splits = splits;
@@ -1245,7 +1258,11 @@ static int gemm_tn_plan(const void* g, const void* x, const void* c, int64_t M, 
   if ((reinterpret_cast<uintptr_t>(g) & 15) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(c) & 15))
     return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_tn: pointers must be 16-byte aligned");
   a->g = (const __bf16*)g; a->x = (const __bf16*)x; a->c = (float*)c; a->M = M; a->N = N; a->K = K; a->ldg = ldg; a->ldx = ldx;
-  const long long tiles = (long long)(N >> 7) * (K >> 7);
+  // 256 x 128 output tiles only for the large products of the encoder FFN (N K >= 256 K, M >= 64 K tokens: 3 % faster there,
+  // 10-25 % slower on the convolution shapes: profiles/r04_gemm_tn_phases.txt)
+  a->tn = (N % 256 == 0 && (long long)N * K >= 262144 && M >= 65536) ? 2 : 1;
+  if (g_tn_force) a->tn = (g_tn_force == 2 && N % 256 == 0) ? 2 : 1;
+  const long long tiles = (long long)(N / (128 * a->tn)) * (K >> 7);
   // splits: one workgroup per CU (256 in all: each flushes its 64 KB tile, 16 MB per launch), two per CU
   // where that still leaves the flush volume small and >= 1 024 tokens per workgroup; never fewer than 256 tokens each
   long long sp = 256 / tiles;
@@ -1261,19 +1278,18 @@ static int gemm_tn_plan(const void* g, const void* x, const void* c, int64_t M, 
   return DSKD_OK;
 }
 
+template <bool ATOMIC, int TN>
+static int gemm_tn_launch_t(const TnArgs& a, long long tiles, hipStream_t st) {
+  constexpr int lds = DSKD_TN_NS * (TN + 1) * DSKD_TN_TOK * 256;
+  static bool done[64] = {};
+  if (!reserve_lds((const void*)gemm_tn_kernel<ATOMIC, TN>, lds, done))
+    return fail(DSKD_ERR_LAUNCH, "dskd_gemm_tn: cannot reserve %d bytes of LDS", lds);
+  hipLaunchKernelGGL((gemm_tn_kernel<ATOMIC, TN>), dim3((unsigned)(tiles * a.splits)), dim3((4 * TN + 4) * 64), lds, st, a);
+  return check_launch("dskd_gemm_tn");
+}
 template <bool ATOMIC>
 static int gemm_tn_launch(const TnArgs& a, long long tiles, hipStream_t st) {
-  constexpr int lds = DSKD_TN_NS * 2 * DSKD_TN_TOK * 256;
-  static bool done[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (!done[dev]) {
-    if (hipFuncSetAttribute((const void*)gemm_tn_kernel<ATOMIC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return fail(DSKD_ERR_LAUNCH, "dskd_gemm_tn: cannot reserve %d bytes of LDS", lds);
-    done[dev] = true;
-  }
-  hipLaunchKernelGGL(gemm_tn_kernel<ATOMIC>, dim3((unsigned)(tiles * a.splits)), dim3(512), lds, st, a);
-  return check_launch("dskd_gemm_tn");
+  return a.tn == 2 ? gemm_tn_launch_t<ATOMIC, 2>(a, tiles, st) : gemm_tn_launch_t<ATOMIC, 1>(a, tiles, st);
 }
 
 extern "C" int dskd_gemm_tn(const void* g, const void* x, float* c, int64_t M, int N, int K, int ldg, int ldx, int dtype,
