@@ -109,7 +109,7 @@ class _FoldTrainable(torch.autograd.Function):
         srcs = [w.detach() for w in weights]
         if tables is not None and dtype == torch.bfloat16 and ctx.wdtype == torch.float32:
             outs = [torch.empty_like(w, dtype=dtype) for w in srcs]
-            if native.MultiCast.ok(srcs, outs, vecs, 0):
+            if tables[0].ready(srcs, outs, vecs):
                 tables[0].run(srcs, outs, vecs)
                 ctx.fast = True
                 return tuple(outs)
@@ -134,7 +134,7 @@ class _FoldTrainable(torch.autograd.Function):
             slots = [grad_slot(pid, g.shape, ctx.wdtype) for pid, g in zip(ctx.pids, gs)]
             ups = [s if s is not None else torch.empty_like(g, dtype=ctx.wdtype) for s, g in zip(slots, gs)]
             vecs = [v for v, _ in ctx.scales]
-            if native.MultiCast.ok(gs, ups, vecs, 1):
+            if ctx.tables[1].ready(gs, ups, vecs):
                 ctx.tables[1].run(gs, ups, vecs)
                 return (None, None, None) + tuple(ups)
         full = [_full_scale(sc, g) for sc, g in zip(ctx.scales, gs)]

@@ -8,7 +8,7 @@ mkdir -p "$out"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -munsafe-fp-atomics -fno-fast-math -ffp-contract=on -Wall -Wno-unused-function"
 objs=()
-for f in msda msda_mm msda_pull msda_prep denseloss addln biasact ffnact ffn_mfma gemm_nt optim winattn gn lsap cost corr fgkd; do
+for f in msda msda_mm msda_pull msda_prep denseloss addln biasact ffnact ffn_mfma gemm_nt optim winattn attn gn lsap cost corr fgkd; do
   "$HIPCC" $FLAGS "$@" -c "$here/$f.hip" -o "$out/$f.o" &
   objs+=("$out/$f.o")
 done

@@ -10,6 +10,7 @@ implementation with :func:`install_cpu_checker`; the package itself never import
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 from typing import List, Optional, Sequence, Tuple
 
@@ -69,6 +70,8 @@ _SIGNATURES = {
     "dskd_gemm_tn_bf16": (C.c_int, [_vp] * 4 + [_i64, _i64] + [C.c_int] * 5 + [_vp]),
     "dskd_winattn_fwd": (C.c_int, [_vp] * 4 + [C.c_int] * 5 + [_f32, C.c_int, _vp]),
     "dskd_winattn_bwd": (C.c_int, [_vp] * 6 + [C.c_int] * 5 + [_f32, C.c_int, _vp]),
+    "dskd_attn_fwd": (C.c_int, [_vp] * 5 + [C.c_int] * 4 + [_vp, _f32, _f32, C.c_uint64, C.c_uint64, _vp, C.c_int, _vp]),
+    "dskd_attn_bwd": (C.c_int, [_vp] * 10 + [C.c_int] * 4 + [_vp, _f32, _f32, C.c_uint64, C.c_uint64, _vp, C.c_int, _vp]),
     "dskd_clip_adamw_chunk": (C.c_int, []),
     "dskd_clip_adamw": (C.c_int, [_vp] * 5 + [C.c_int, C.c_int, _vp, _vp, C.c_int, _f32, _f32, _f32, _i64, _f32, _vp]),
     "dskd_cast_scale_chunk": (C.c_int, []),
@@ -100,10 +103,29 @@ def lib_path() -> str:
     return _LIB_PATH
 
 
+# every DSKD_* environment switch something in this repository reads (package, library, bench.py, tools/): a variable that
+# is set but not listed here does nothing -- load() says so, instead of an A/B run quietly timing the same code twice
+KNOWN_ENV = frozenset((
+    "DSKD_HIP_LIB", "DSKD_CONV_LIB", "DSKD_SDPA_ATTN", "DSKD_NO_GRAPHS", "DSKD_FORCE_GRAPHS", "DSKD_EAGER_HEAD",
+    "DSKD_EAGER_LOSSES", "DSKD_GRAPH_TRACE", "DSKD_MSDA_MM", "DSKD_MSDA_PULL_LEVELS", "DSKD_GRADSYNC_NOCOMM",
+    "DSKD_GRADSYNC_BUCKET_MB", "DSKD_WRAP_DDP", "DSKD_BENCH_REHEARSE", "DSKD_BENCH_STEPTIMES", "DSKD_BENCH_DDP1",
+    "DSKD_BENCH_WRAP_DDP"))
+
+
+def unknown_env():
+    """Names of set ``DSKD_*`` variables that nothing reads."""
+    return sorted(k for k in os.environ if k.startswith("DSKD_") and k not in KNOWN_ENV)
+
+
 def load() -> C.CDLL:
     """Load the HIP library or raise: the product path has no fallback."""
     global _lib
     if _lib is None:
+        stray = unknown_env()
+        if stray:
+            import warnings
+            warnings.warn(f"environment variables {stray} are set but no DSKD switch of that name exists (known: "
+                          f"{sorted(KNOWN_ENV)}): they have no effect", RuntimeWarning, stacklevel=2)
         if not os.path.exists(_LIB_PATH):
             raise NativeError(
                 f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
@@ -137,18 +159,40 @@ _acc_cache = {}
 
 def _persistent_acc(shape, device) -> torch.Tensor:
     """A zeroed f32 accumulator of ``shape`` that STAYS zeroed between uses: the kernels add their column sums into it and
-    :func:`sum_clear` hands the result over and clears it again -- no zero-fill launch per call.  One per shape and device,
-    used on one stream at a time (the backward's); it must exist before a hipGraph capture (run one eager step first)."""
+    :func:`sum_clear` hands the result over and clears it again -- no zero-fill launch per call.  One per (shape, device,
+    STREAM): two streams never add into the same words.  It must exist before a hipGraph capture (the warm-up on the
+    capture stream creates it).  Use it under :func:`_acc_guard`."""
     device = torch.device(device)
     if device.index is None and device.type == "cuda":
         device = torch.device("cuda", torch.cuda.current_device())
-    key = (tuple(shape), device)
+    key = (tuple(shape), device, torch.cuda.current_stream(device).cuda_stream)
     t = _acc_cache.get(key)
     if t is None:
         if torch.cuda.is_current_stream_capturing():
-            raise NativeError("a column-sum accumulator must exist before a hipGraph capture (run one eager step)")
+            raise NativeError("a column-sum accumulator must exist before a hipGraph capture (run one eager step on the "
+                              "capture stream)")
         t = _acc_cache[key] = torch.zeros(shape, dtype=torch.float32, device=device)
     return t
+
+
+class _acc_guard:
+    """``with _acc_guard(acc):`` around the accumulating launch and its hand-over: if anything between them raises (a failed
+    launch, an allocation failure in the hand-over), the accumulator is zeroed again before the error travels on -- a
+    training loop that catches the error and skips the batch must not find the residue in every later gradient."""
+
+    def __init__(self, acc):
+        self.acc = acc
+
+    def __enter__(self):
+        return self.acc
+
+    def __exit__(self, etype, evalue, tb):
+        if etype is not None and self.acc is not None:
+            try:
+                self.acc.zero_()
+            except Exception:          # the device itself is gone: nothing left to protect
+                pass
+        return False
 
 
 def sum_clear(acc: torch.Tensor, planes: int, copies: int, Cc: int, out_dtype=torch.float32) -> torch.Tensor:
@@ -317,11 +361,13 @@ _msda_ws_cache = {}
 
 def _msda_bwd_workspace(device, B, Nv, Nq, heads, L, P) -> torch.Tensor:
     """Workspace of ``dskd_msda_bwd_ws`` (stray-sample list; header zeroed once, the library leaves it zeroed),
-    one per device: a training step runs its backward launches one after the other (eagerly on the main stream or as
-    a hipGraph replay on it), never two encoder backwards at once; a capture stream finds the buffer the eager
-    warm-up steps made."""
+    one per (device, stream): launches of one stream run one after the other, two streams never share a stray list; a
+    hipGraph capture finds the buffer its warm-up on the capture stream made."""
     need = int(load().dskd_msda_bwd_workspace(B, Nv, Nq, heads, L, P))
-    key = torch.device(device)
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
     ws = _msda_ws_cache.get(key)
     if ws is None or ws.numel() < need:
         if torch.cuda.is_current_stream_capturing():
@@ -337,9 +383,9 @@ def graph_pins(device):
     device = torch.device(device)
     if device.index is None and device.type == "cuda":
         device = torch.device("cuda", torch.cuda.current_device())
-    return [t for t in (_msda_ws_cache.get(device), _drop_epochs.get(device)) if t is not None] + \
+    return [t for t in (_drop_epochs.get(device),) if t is not None] + [t for k, t in _msda_ws_cache.items() if k[0] == device] + \
         [t for k, t in _tn_acc.items() if k[2] == device] + [t for k, t in _acc_cache.items() if k[1] == device] + \
-        [t for d, t in _tn_scratch.items() if d == device] + \
+        [t for (d, _), t in _tn_scratch.items() if d == device] + \
         [t for (d, _), t in _gemm_ws_cache.items() if d == device.index] + \
         [t for pre in set(_prepacked.values()) for t in pre.pins() if t.device == device]
 
@@ -538,13 +584,14 @@ class _AddLNFunction(torch.autograd.Function):
         dh = torch.empty_like(z) if p > 0 else None
         copies = _colsum_copies(rows)
         dgb = _persistent_acc((2, copies, D), z.device)
-        rc = load().dskd_add_ln_bwd2(dy.data_ptr(), None if dy2 is None else dy2.data_ptr(),
-                                     None if dq is None else dq.data_ptr(), z.data_ptr(), stats.data_ptr(),
-                                     gamma_f.data_ptr(), dres.data_ptr(), None if dh is None else dh.data_ptr(),
-                                     dgb[0].data_ptr(), dgb[1].data_ptr(), copies, rows, D, p, seed, offset,
-                                     dropout_epoch(z.device).data_ptr() if p > 0 else None, dt, _stream(z))
-        _check(rc, "dskd_add_ln_bwd2")
-        dgb = sum_clear(dgb, 2, copies, D)
+        with _acc_guard(dgb):
+            rc = load().dskd_add_ln_bwd2(dy.data_ptr(), None if dy2 is None else dy2.data_ptr(),
+                                         None if dq is None else dq.data_ptr(), z.data_ptr(), stats.data_ptr(),
+                                         gamma_f.data_ptr(), dres.data_ptr(), None if dh is None else dh.data_ptr(),
+                                         dgb[0].data_ptr(), dgb[1].data_ptr(), copies, rows, D, p, seed, offset,
+                                         dropout_epoch(z.device).data_ptr() if p > 0 else None, dt, _stream(z))
+            _check(rc, "dskd_add_ln_bwd2")
+            dgb = sum_clear(dgb, 2, copies, D)
         dpos = None
         if pos_shape is not None and ctx.needs_input_grad[4] and dq is not None:
             # q = y + pos[r % pos_rows]: d(pos) = sum of dq over the repeats (the images of a batch)
@@ -637,12 +684,13 @@ def relu_dropout_bwd(g: torch.Tensor, y_dropped: torch.Tensor, p: float, want_co
     out = torch.empty_like(g)
     copies = _colsum_copies(rows)
     colsum = _persistent_acc((copies, Cc), g.device) if want_colsum else None
-    rc = load().dskd_relu_dropout_bwd(g.data_ptr(), y_dropped.data_ptr(), out.data_ptr(),
-                                      None if colsum is None else colsum.data_ptr(), copies, rows, Cc, p, DTYPE_BF16,
-                                      _stream(g))
-    _check(rc, "dskd_relu_dropout_bwd")
-    if colsum is not None:
-        colsum = sum_clear(colsum, 1, copies, Cc, colsum_dtype)[0]
+    with _acc_guard(colsum):
+        rc = load().dskd_relu_dropout_bwd(g.data_ptr(), y_dropped.data_ptr(), out.data_ptr(),
+                                          None if colsum is None else colsum.data_ptr(), copies, rows, Cc, p, DTYPE_BF16,
+                                          _stream(g))
+        _check(rc, "dskd_relu_dropout_bwd")
+        if colsum is not None:
+            colsum = sum_clear(colsum, 1, copies, Cc, colsum_dtype)[0]
     return out, colsum
 
 
@@ -713,15 +761,16 @@ def ffn_bwd_raw(grad_y: torch.Tensor, h: torch.Tensor, packed_bwd: torch.Tensor,
     if add_to_gx is not None and (add_to_gx.dtype != grad_y.dtype or add_to_gx.shape != grad_y.shape or
                                   not add_to_gx.is_contiguous()):
         raise NativeError("ffn_bwd_raw: add_to_gx must be a contiguous bf16 [tokens, d] tensor")
-    rc = load().dskd_ffn_bwd(grad_y.data_ptr(), h.data_ptr(), packed_bwd.data_ptr(), gh.data_ptr(), gx.data_ptr(),
-                             None if add_to_gx is None else add_to_gx.data_ptr(),
-                             None if cs is None else cs.data_ptr(), copies, tokens, d, h.shape[1], p, DTYPE_BF16,
-                             _stream(grad_y))
-    _check(rc, "dskd_ffn_bwd")
     global _ffn_flops
-    _ffn_flops += 4 * tokens * d * h.shape[1]
-    if want_colsum:
-        return gh, gx, sum_clear(cs, 1, copies, h.shape[1], colsum_dtype)[0]
+    with _acc_guard(cs):
+        rc = load().dskd_ffn_bwd(grad_y.data_ptr(), h.data_ptr(), packed_bwd.data_ptr(), gh.data_ptr(), gx.data_ptr(),
+                                 None if add_to_gx is None else add_to_gx.data_ptr(),
+                                 None if cs is None else cs.data_ptr(), copies, tokens, d, h.shape[1], p, DTYPE_BF16,
+                                 _stream(grad_y))
+        _check(rc, "dskd_ffn_bwd")
+        _ffn_flops += 4 * tokens * d * h.shape[1]
+        if want_colsum:
+            return gh, gx, sum_clear(cs, 1, copies, h.shape[1], colsum_dtype)[0]
     return gh, gx
 
 
@@ -742,9 +791,10 @@ def colsum(x: torch.Tensor, out_dtype=torch.float32) -> torch.Tensor:
     rows = x.numel() // Cc
     copies = _colsum_copies(rows)
     acc = _persistent_acc((copies, Cc), x.device)
-    rc = load().dskd_colsum(x.data_ptr(), acc.data_ptr(), copies, rows, Cc, DTYPE_BF16, _stream(x))
-    _check(rc, "dskd_colsum")
-    return sum_clear(acc, 1, copies, Cc, out_dtype)[0]
+    with _acc_guard(acc):
+        rc = load().dskd_colsum(x.data_ptr(), acc.data_ptr(), copies, rows, Cc, DTYPE_BF16, _stream(x))
+        _check(rc, "dskd_colsum")
+        return sum_clear(acc, 1, copies, Cc, out_dtype)[0]
 
 
 def colsum_short_ok(x: torch.Tensor) -> bool:
@@ -999,23 +1049,24 @@ def gemm_tn(g2: torch.Tensor, x2: torch.Tensor, out: Optional[torch.Tensor] = No
     return out
 
 
-_tn_acc = {}          # (N, K, device) -> f32 accumulators of gemm_tn_bf16_atomic (kept for A/B runs and tests)
-_tn_scratch = {}      # device -> the split-K scratch of gemm_tn_bf16
+_tn_acc = {}          # (N, K, device, stream) -> f32 accumulators of gemm_tn_bf16_atomic (kept for A/B runs and tests)
+_tn_scratch = {}      # (device, stream) -> the split-K scratch of gemm_tn_bf16
 
 
 def gemm_tn_bf16_atomic(g2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     """The round-3 form of :func:`gemm_tn_bf16`: the split-K kernel adds into a PERSISTENT f32 accumulator of that shape
     with float atomics, ``dskd_cvt_clear`` hands the result over as bf16 and zeroes the accumulator again."""
     N, K = g2.shape[1], x2.shape[1]
-    key = (N, K, g2.device)
+    key = (N, K, g2.device, _stream(g2))
     acc = _tn_acc.get(key)
     if acc is None:
         if torch.cuda.is_current_stream_capturing():
             raise NativeError("gemm_tn_bf16: the accumulator must exist before a hipGraph capture (run one eager step)")
         acc = _tn_acc[key] = torch.zeros((N, K), dtype=torch.float32, device=g2.device)
-    gemm_tn(g2, x2, out=acc)
-    out = torch.empty((N, K), dtype=torch.bfloat16, device=g2.device)
-    _check(load().dskd_cvt_clear(acc.data_ptr(), out.data_ptr(), N * K, DTYPE_BF16, _stream(g2)), "dskd_cvt_clear")
+    with _acc_guard(acc):
+        gemm_tn(g2, x2, out=acc)
+        out = torch.empty((N, K), dtype=torch.bfloat16, device=g2.device)
+        _check(load().dskd_cvt_clear(acc.data_ptr(), out.data_ptr(), N * K, DTYPE_BF16, _stream(g2)), "dskd_cvt_clear")
     return out
 
 
@@ -1023,8 +1074,8 @@ def gemm_tn_bf16(g2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     """``(g2^T @ x2).to(bf16)`` -- a weight gradient in the low-precision parameter's dtype -- in two launches without
     atomics: the split-K kernel writes every split's partial product into a persistent scratch ([splits, N, K] f32, plain
     stores), a second launch sums the planes in a fixed order and casts (dskd_gemm_tn_bf16).  The float-atomic flush of the
-    earlier form ran at the chip's ~1.3 TB/s atomic rate: 12 us of every launch.  Calls on one stream only (one scratch per
-    device); the scratch must exist before a hipGraph capture."""
+    earlier form ran at the chip's ~1.3 TB/s atomic rate: 12 us of every launch.  One scratch per (device, stream); it must
+    exist before a hipGraph capture."""
     _need_gpu(g2, x2)
     M, N = g2.shape
     K = x2.shape[1]
@@ -1032,11 +1083,12 @@ def gemm_tn_bf16(g2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     if need < 0:
         raise NativeError("gemm_tn_bf16: " + load().dskd_last_error().decode())
     dev = g2.device
-    ws = _tn_scratch.get(dev)
+    key = (dev, _stream(g2))
+    ws = _tn_scratch.get(key)
     if ws is None or ws.numel() < need:
         if torch.cuda.is_current_stream_capturing():
             raise NativeError("gemm_tn_bf16: the scratch must exist before a hipGraph capture (run one eager step)")
-        ws = _tn_scratch[dev] = torch.empty(max(need, 32 << 20), dtype=torch.uint8, device=dev)
+        ws = _tn_scratch[key] = torch.empty(max(need, 32 << 20), dtype=torch.uint8, device=dev)
     out = torch.empty((N, K), dtype=torch.bfloat16, device=dev)
     rc = load().dskd_gemm_tn_bf16(g2.data_ptr(), x2.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), M, N, K,
                                   g2.stride(0), x2.stride(0), DTYPE_BF16, _stream(g2))
@@ -1129,6 +1181,7 @@ class MultiCast:
 
     def __init__(self, direction: int):
         self.direction, self.key, self.table, self.first, self.n, self.chunks = direction, None, None, None, 0, 0
+        self.captured, self.retired = False, []
 
     @staticmethod
     def ok(srcs, dsts, scales, direction) -> bool:
@@ -1146,11 +1199,27 @@ class MultiCast:
                 return False
         return True
 
+    @staticmethod
+    def _key(srcs, dsts, scales):
+        return tuple((s.data_ptr(), d.data_ptr(), 0 if sc is None else sc.data_ptr(), s.numel(), 0 if sc is None else sc.numel())
+                     for s, d, sc in zip(srcs, dsts, scales))
+
+    def ready(self, srcs, dsts, scales) -> bool:
+        """:meth:`ok`, and the launch can be issued NOW: a changed address means a new table upload (pinned allocation +
+        host-to-device copy), which a stream capture forbids -- the caller then takes its per-tensor path for that capture."""
+        if not MultiCast.ok(srcs, dsts, scales, self.direction):
+            return False
+        return not torch.cuda.is_current_stream_capturing() or self._key(srcs, dsts, scales) == self.key
+
     def run(self, srcs, dsts, scales):
-        key = tuple((s.data_ptr(), d.data_ptr(), 0 if sc is None else sc.data_ptr(), s.numel(), 0 if sc is None else sc.numel())
-                    for s, d, sc in zip(srcs, dsts, scales))
+        key = self._key(srcs, dsts, scales)
         dev = srcs[0].device
         if key != self.key:
+            if torch.cuda.is_current_stream_capturing():
+                raise NativeError("MultiCast.run: new addresses inside a stream capture (ask ready() first)")
+            if self.captured:           # a captured launch reads this table on every replay: leave it as it is
+                self.retired.append((self.table, self.first))
+                self.table, self.captured = None, False
             chunk = int(load().dskd_cast_scale_chunk())
             rows, first = [], [0]
             for sp, dp, cp, n, rows_sc in key:
@@ -1164,6 +1233,8 @@ class MultiCast:
             self.table.copy_(t_host, non_blocking=True)
             self.first.copy_(self.table[len(rows):], non_blocking=True)         # int64 -> int32 on the device
             self.key, self.n, self.chunks = key, len(key), first[-1]
+        if torch.cuda.is_current_stream_capturing():
+            self.captured = True
         _check(load().dskd_cast_scale_many(self.table.data_ptr(), self.first.data_ptr(), self.n, self.chunks, self.direction,
                                            _stream(srcs[0])), "dskd_cast_scale_many")
 
@@ -1378,6 +1449,72 @@ def window_attention(qkv: torch.Tensor, bias: torch.Tensor, mask_types: Optional
     [heads, 49, 49] (differentiable); mask_types [types, 49, 49] with wtype [windows per image] int32 (type of each window
     of an image) or both None.  Returns [windows, 49, heads * 32], the input of the output projection."""
     return _WindowAttentionFunction.apply(qkv, bias, mask_types, wtype, int(num_heads), float(scale))
+
+
+# --------------------------------------------------------------------------- self-attention of the decoder's queries
+ATTN_HEAD_DIM, ATTN_MAX_TOKENS = 32, 320
+
+
+def self_attention_ok(qk: torch.Tensor, v: torch.Tensor, num_heads: int) -> bool:
+    """Can csrc/attn.hip take this call: bf16 CUDA, heads of 32 channels, up to 320 tokens, q | k side by side in ``qk``
+    [.., L, 2 E] and v [.., L, E] as the projections wrote them?"""
+    E = num_heads * ATTN_HEAD_DIM
+    return (qk.is_cuda and qk.dtype == torch.bfloat16 and v.dtype == torch.bfloat16 and qk.dim() == 3 and v.dim() == 3
+            and qk.shape[-1] == 2 * E and v.shape[-1] == E and qk.shape[:2] == v.shape[:2]
+            and qk.is_contiguous() and v.is_contiguous() and qk.data_ptr() % 16 == 0 and v.data_ptr() % 16 == 0)
+
+
+class _SelfAttentionFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qk, v, num_heads, scale, p, batch_first):
+        E = num_heads * ATTN_HEAD_DIM
+        B, L = (qk.shape[0], qk.shape[1]) if batch_first else (qk.shape[1], qk.shape[0])
+        if L > ATTN_MAX_TOKENS:
+            raise NativeError(f"self_attention: {L} tokens, built for up to {ATTN_MAX_TOKENS}")
+        # (batch, row) strides in elements of q, k (inside qk), v and the output
+        rows = (L, 1) if batch_first else (1, B)
+        strides = [rows[0] * 2 * E, rows[1] * 2 * E] * 2 + [rows[0] * E, rows[1] * E] * 2
+        st = (C.c_int64 * 8)(*strides)
+        train = any(ctx.needs_input_grad[:2])
+        out = torch.empty_like(v)
+        stats = torch.empty((B, num_heads, L, 2), dtype=torch.float32, device=qk.device) if train else None
+        seed, offset = _next_drop_key() if p > 0 else (0, 0)
+        ep = dropout_epoch(qk.device).data_ptr() if p > 0 else None
+        rc = load().dskd_attn_fwd(qk.data_ptr(), qk.data_ptr() + 2 * E, v.data_ptr(), out.data_ptr(),
+                                  None if stats is None else stats.data_ptr(), B, num_heads, L, ATTN_HEAD_DIM, st, scale, p,
+                                  seed, offset, ep, DTYPE_BF16, _stream(qk))
+        _check(rc, "dskd_attn_fwd")
+        if train:
+            ctx.save_for_backward(qk, v, out, stats)
+        ctx.meta = (num_heads, scale, p, seed, offset, B, L, strides)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qk, v, out, stats = ctx.saved_tensors
+        num_heads, scale, p, seed, offset, B, L, strides = ctx.meta
+        E = num_heads * ATTN_HEAD_DIM
+        dout = dout.contiguous()
+        dqk, dv = torch.empty_like(qk), torch.empty_like(v)
+        delta = torch.empty((B, num_heads, L), dtype=torch.float32, device=qk.device)
+        st = (C.c_int64 * 8)(*strides)
+        ep = dropout_epoch(qk.device).data_ptr() if p > 0 else None
+        rc = load().dskd_attn_bwd(qk.data_ptr(), qk.data_ptr() + 2 * E, v.data_ptr(), out.data_ptr(), dout.data_ptr(),
+                                  stats.data_ptr(), delta.data_ptr(), dqk.data_ptr(), dqk.data_ptr() + 2 * E, dv.data_ptr(),
+                                  B, num_heads, L, ATTN_HEAD_DIM, st, scale, p, seed, offset, ep, DTYPE_BF16, _stream(qk))
+        _check(rc, "dskd_attn_bwd")
+        return dqk, dv, None, None, None, None
+
+
+def self_attention(qk: torch.Tensor, v: torch.Tensor, num_heads: int, dropout_p: float = 0.0,
+                   batch_first: bool = True) -> torch.Tensor:
+    """``dropout(softmax(q k^T / sqrt(32))) v`` per (image, head): the core of ext-mmcv ``MultiheadAttention`` /
+    ``nn.MultiheadAttention`` for the decoder's object queries (self-attention: configs/deformable_detr/*_il.py:82-87, run by
+    mmdet/models/utils/transformer.py:639-709).  ``qk`` [B, L, 2 E] (or [L, B, 2 E]) = output of the joint q | k projection,
+    ``v`` [B, L, E]; returns [B, L, E], the input of the output projection.  Gradients arrive as d(qk), d(v) in the same
+    layouts: nothing is split, permuted or concatenated around the kernels (csrc/attn.hip)."""
+    return _SelfAttentionFunction.apply(qk, v, int(num_heads), 1.0 / math.sqrt(ATTN_HEAD_DIM), float(dropout_p),
+                                        bool(batch_first))
 
 
 # --------------------------------------------------------------------------- GroupNorm of the neck

@@ -88,13 +88,17 @@ class FusedClipAdamW(torch.optim.Optimizer):
             src = torch.tensor(gp, dtype=torch.int64).pin_memory()
             tb["ptrs"][1].copy_(src, non_blocking=True)
             self._grad_ptrs = gp
-        steps = set()
+        # validate BEFORE touching any state: a raise must leave the optimizer as it was
+        steps = {int(self.state[p]["step"]) + 1 for _, p in live}
+        if len(steps) != 1:
+            raise native.NativeError("FusedClipAdamW: parameters with different step counts %s (a parameter that got its first "
+                                     "gradient later than the others, or partially loaded state): the kernel applies ONE "
+                                     "bias correction per launch -- build the optimizer with "
+                                     "runner.build_optimizer(..., fused_clip=False) (torch.optim.AdamW, per-parameter "
+                                     "steps) for such a schedule" % sorted(steps))
         for _, p in live:
             st = self.state[p]
             st["step"] = st["step"] + 1            # a host scalar (tensor or int), as in torch.optim.AdamW's state
-            steps.add(int(st["step"]))
-        if len(steps) != 1:
-            raise native.NativeError("FusedClipAdamW: parameters with different step counts (partially loaded state?)")
         g0 = self.param_groups[0]
         ng = len(self.param_groups)
         lr = (C.c_float * ng)(*[float(g["lr"]) for g in self.param_groups])
@@ -106,7 +110,7 @@ class FusedClipAdamW(torch.optim.Optimizer):
             float(g0["eps"]), steps.pop(), float(max_norm) if max_norm else 0.0, torch.cuda.current_stream(dev).cuda_stream)
         native._check(rc, "dskd_clip_adamw")
         self.last_norm = tb["norm"]
-        return tb["norm"][0]
+        return tb["norm"][0].clone()       # the buffer is rewritten by the next step: a logger may keep what it gets
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -120,6 +124,13 @@ class FusedClipAdamW(torch.optim.Optimizer):
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self._tables = None            # moments were replaced
+        for _, p in self._params():    # a checkpoint written from a differently laid-out model (contiguous vs channels_last)
+            st = self.state.get(p)
+            for k in ("exp_avg", "exp_avg_sq"):
+                if st and k in st and st[k].stride() != p.stride():
+                    m = torch.empty_like(p, memory_format=torch.preserve_format)
+                    m.copy_(st[k])
+                    st[k] = m
 
     def zero_grad(self, set_to_none=True):
         super().zero_grad(set_to_none=set_to_none)

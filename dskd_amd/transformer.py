@@ -29,6 +29,7 @@ from .builder import (ATTENTION, FEEDFORWARD_NETWORK, POSITIONAL_ENCODING, TRANS
                       build_transformer_layer, build_transformer_layer_sequence)
 
 
+_ATTN_KERNEL = not os.environ.get("DSKD_SDPA_ATTN")      # A/B switch: PyTorch's scaled_dot_product_attention for the decoder's queries
 _CHUNK_CACHE = {}
 
 
@@ -294,7 +295,7 @@ class _CastParams(torch.autograd.Function):
         # otherwise
         cache = _CAST_TABLES.setdefault(id(static), (native.MultiCast(0), native.MultiCast(1))) if static is not None else None
         ctx.cache = cache
-        if cache is not None and dtype == torch.bfloat16 and native.MultiCast.ok(srcs, outs, [None] * len(srcs), 0):
+        if cache is not None and dtype == torch.bfloat16 and cache[0].ready(srcs, outs, [None] * len(srcs)):
             cache[0].run(srcs, outs, [None] * len(srcs))
         else:
             torch._foreach_copy_(outs, srcs)
@@ -308,7 +309,7 @@ class _CastParams(torch.autograd.Function):
         ups = [s if s is not None else torch.empty_like(grads[i], dtype=ctx.pdtypes[i]) for s, i in zip(slots, idx)]
         if idx:
             gs = [grads[i] for i in idx]
-            if ctx.cache is not None and native.MultiCast.ok(gs, ups, [None] * len(gs), 1):
+            if ctx.cache is not None and ctx.cache[1].ready(gs, ups, [None] * len(gs)):
                 ctx.cache[1].run(gs, ups, [None] * len(gs))
             else:
                 torch._foreach_copy_(ups, gs)
@@ -739,18 +740,23 @@ class MultiheadAttention(nn.Module):
     def _attend(self, query, key, value, batch_first=False):
         """``nn.MultiheadAttention`` without masks on the GPU, same arithmetic with fewer launches:
         q and k projected by ONE GEMM when they are the same tensor (DETR self-attention: q = k =
-        query + query_pos, v = query), fused ``scaled_dot_product_attention``, the step's
+        query + query_pos, v = query), the attention core in csrc/attn.hip (``scaled_dot_product_attention`` for other shapes), the step's
         low-precision parameter copies (``lowp_params``) when present.  [L, B, E] in and out."""
         E, H = self.embed_dims, self.num_heads
         live = self.__dict__.get("_live_lp")
         w, b, wo, bo = live if live is not None else (self.attn.in_proj_weight, self.attn.in_proj_bias,
                                                       self.attn.out_proj.weight, self.attn.out_proj.bias)
+        p_drop = self.attn.dropout if self.training else 0.0
+        v = tall_linear(value, w[2 * E:], b[2 * E:])
         if query is key:
-            q, k = tall_linear(query, w[:2 * E], b[:2 * E]).split(E, dim=-1)
+            qk = tall_linear(query, w[:2 * E], b[:2 * E])
+            if _ATTN_KERNEL and E == H * native.ATTN_HEAD_DIM and query.shape[1 if batch_first else 0] <= native.ATTN_MAX_TOKENS \
+                    and native.self_attention_ok(qk, v, H):
+                # own kernels (csrc/attn.hip): q | k, v and the result stay where the projections wrote / read them
+                return tall_linear(native.self_attention(qk, v, H, p_drop, batch_first=batch_first), wo, bo)
+            q, k = qk.split(E, dim=-1)
         else:
             q, k = tall_linear(query, w[:E], b[:E]), tall_linear(key, w[E:2 * E], b[E:2 * E])
-        v = tall_linear(value, w[2 * E:], b[2 * E:])
-        p_drop = self.attn.dropout if self.training else 0.0
         if batch_first:         # [B, L, E] tokens: the head split is a view either way, nothing is permuted + copied on the way in
             B, L, _ = query.shape
             S = key.shape[1]

@@ -518,6 +518,29 @@ int dskd_winattn_bwd(const void* qkv, const float* table, const int32_t* wtype, 
                      int windows, int heads, int nW, int tokens, int head_dim, float scale, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * Self-attention of the decoder's object queries: dropout(softmax(q k^T * scale)) v per (image, head), 8 heads of 32
+ * channels, up to 320 tokens -- the core of ext-mmcv MultiheadAttention (nn.MultiheadAttention between its input and output
+ * projections; configs/deformable_detr/*_il.py:82-87, first sub-layer of each decoder layer, mmdet/models/utils/
+ * transformer.py:639-709) -- and its backward, one wave per 32 queries / 32 keys of an (image, head) on the matrix cores
+ * (csrc/attn.hip).  bf16.  q, k, v, out and their gradients are [B, L, heads * 32] in ANY (batch, row) strides, so q | k
+ * are read in place from the joint projection's [.., 2 E] rows and both token layouts ([B, L, E], [L, B, E]) need no copy:
+ *   strides [8] int64, elements          batch, row stride of q; of k; of v; of out.  dq / dk / dv / dout use the strides
+ *                                        of q / k / v / out.  Multiples of 8; pointers 16-byte aligned.
+ *   stats   [B, heads, L, 2] f32         row maximum of the scaled scores, 1 / row sum: forward writes (NULL: inference),
+ *                                        backward reads
+ *   delta   [B, heads, L] f32            backward scratch (sum_d dout * out per query), written by its pre-pass
+ *   drop_p, seed, offset, epoch          attention dropout: element (b, h, query, key) is dropped when a counter hash of
+ *                                        its index keyed by (seed, offset + *epoch) falls below drop_p; the backward must
+ *                                        get the forward's values.  epoch: device word (NULL = 0), see dskd_dropout_fwd.
+ * ------------------------------------------------------------------------- */
+int dskd_attn_fwd(const void* q, const void* k, const void* v, void* out, float* stats, int B, int heads, int L, int head_dim,
+                  const int64_t* strides, float scale, float drop_p, uint64_t seed, uint64_t offset, const uint64_t* epoch,
+                  int dtype, void* stream);
+int dskd_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* stats,
+                  float* delta, void* dq, void* dk, void* dv, int B, int heads, int L, int head_dim, const int64_t* strides,
+                  float scale, float drop_p, uint64_t seed, uint64_t offset, const uint64_t* epoch, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------
  * Global-norm gradient clipping + AdamW for every trainable tensor in two launches -- the reference's optimizer hook
  * (configs/deformable_detr/..._il.py:213-224: AdamW, grad_clip max_norm 0.1; ext-mmcv OptimizerHook = clip_grad_norm_ then
  * optimizer.step()), f32 parameters / gradients / moments.  Device tables (int64 addresses, filled by the caller):

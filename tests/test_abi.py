@@ -134,3 +134,21 @@ def test_round3_late_entry_points_validate_their_arguments():
     assert lib.dskd_sum_clear(None, 1, 1, 256, p, f32, None) == -1
     assert lib.dskd_sum_clear(p, 1, 0, 256, p, f32, None) == -1
     assert lib.dskd_sum_clear(p, 1, 1, 256, p, 7, None) == -1 and b"out_dtype" in lib.dskd_last_error()
+
+
+def test_every_environment_switch_is_listed_and_unknown_ones_are_reported(monkeypatch):
+    """an A/B script that sets a switch which no longer exists must not time the same code twice in silence.
+    native.KNOWN_ENV lists every DSKD_* variable read anywhere (python: os.environ lookups; library: getenv), and
+    native.unknown_env() -- which load() turns into a RuntimeWarning -- names the rest."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    read = set()
+    for f in glob.glob(root + "/dskd_amd/*.py") + glob.glob(root + "/tools/*.py") + [root + "/bench.py", root + "/__graft_entry__.py"]:
+        read |= set(re.findall(r"environ(?:\.get|\.setdefault)?\(?\[?\s*[\"'](DSKD_[A-Z0-9_]+)[\"']", open(f).read()))
+    for f in glob.glob(root + "/dskd_amd/csrc/*.hip") + glob.glob(root + "/dskd_amd/csrc/*.cpp") + glob.glob(root + "/dskd_amd/csrc/*.h"):
+        read |= set(re.findall(r"getenv\(\"(DSKD_[A-Z0-9_]+)\"\)", open(f).read()))
+    assert read and read <= native.KNOWN_ENV, sorted(read - native.KNOWN_ENV)
+    monkeypatch.setenv("DSKD_MSDA_BWD", "r2")            # a switch round 3 removed
+    monkeypatch.setenv("DSKD_NO_GRAPHS", "1")
+    assert native.unknown_env() == ["DSKD_MSDA_BWD"]

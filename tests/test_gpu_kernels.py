@@ -1319,6 +1319,114 @@ def test_window_attention_vs_float_reference(nH, nW, images, shifted):
     assert _close(db, gb, 2e-2), float((db.float().cpu() - gb).abs().max()) / float(gb.abs().max())
 
 
+def _self_attention_reference(qk, v, H, keep=None, p=0.0):
+    """softmax(q k^T / sqrt(32)) (* keep / (1 - p)) @ v in fp32; qk [B, L, 2 E], v [B, L, E] -> [B, L, E]."""
+    B, L, E = v.shape
+    q, k = qk[..., :E], qk[..., E:]
+    q, k, vh = (t.reshape(B, L, H, 32).permute(0, 2, 1, 3) for t in (q, k, v))
+    P = ((q @ k.transpose(-1, -2)) * 32 ** -0.5).softmax(-1)
+    if keep is not None:
+        P = P * keep / (1.0 - p)
+    return (P @ vh).permute(0, 2, 1, 3).reshape(B, L, E), P
+
+
+@pytest.mark.parametrize("B,L,batch_first", [(4, 300, True), (2, 300, False), (1, 37, True), (3, 320, True), (2, 32, False)])
+def test_decoder_self_attention_vs_float_reference(B, L, batch_first):
+    """dskd_attn_fwd / dskd_attn_bwd (native.self_attention, the core of the decoder's MultiheadAttention) against the
+    formula in fp32 on the CPU from the same bf16 inputs, for both token layouts, the training shape (300 queries) and ragged
+    / full / single tiles.  Tolerances as for the window attention: output 8e-3 of the largest magnitude (P rounded to bf16
+    before P V), gradients 2e-2 (dS rounded to bf16 before the dQ / dK products)."""
+    H, E = 8, 256
+    g = torch.Generator().manual_seed(L * 3 + B)
+    qk = (torch.randn(B, L, 2 * E, generator=g) * 1.5).bfloat16()
+    v = torch.randn(B, L, E, generator=g).bfloat16()
+    up = torch.randn(B, L, E, generator=g).bfloat16()
+    qr, vr = qk.float().requires_grad_(True), v.float().requires_grad_(True)
+    ref, _ = _self_attention_reference(qr, vr, H)
+    gq, gv = torch.autograd.grad(ref, (qr, vr), up.float())
+
+    lay = (lambda t: t) if batch_first else (lambda t: t.transpose(0, 1).contiguous())
+    qd, vd = lay(qk).to(DEV).requires_grad_(True), lay(v).to(DEV).requires_grad_(True)
+    assert native.self_attention_ok(qd, vd, H)
+    out = native.self_attention(qd, vd, H, 0.0, batch_first=batch_first)
+    assert out.shape == vd.shape and out.dtype == torch.bfloat16
+    assert _close((out if batch_first else out.transpose(0, 1)).detach(), ref.detach(), 8e-3)
+    dq, dv = torch.autograd.grad(out, (qd, vd), lay(up).to(DEV))
+    if not batch_first:
+        dq, dv = dq.transpose(0, 1), dv.transpose(0, 1)
+    assert _close(dq, gq, 2e-2), float((dq.float().cpu() - gq).abs().max()) / float(gq.abs().max())
+    assert _close(dv, gv, 2e-2), float((dv.float().cpu() - gv).abs().max()) / float(gv.abs().max())
+    with torch.no_grad():                # inference: no statistics buffer
+        assert torch.equal(native.self_attention(qd.detach(), vd.detach(), H, 0.0, batch_first=batch_first), out)
+
+
+def test_decoder_self_attention_dropout_mask_is_the_same_in_forward_and_backward():
+    """Attention dropout (p = 0.1 in the benchmark config): the mask is a counter hash of (image, head, query, key) keyed by
+    (seed, offset + epoch).  Recovered here through the C-ABI with one-hot value probes (32 keys per launch, the SAME key
+    every launch): the kept entries equal P / (1 - p) of the fp32 reference, the dropped fraction is p, another offset or
+    epoch draws another mask; and the backward -- which regenerates the mask in BOTH of its orientations (key-tile waves for
+    dK / dV, query-tile waves for dQ) -- matches autograd through the reference with that recovered mask."""
+    import ctypes as C
+    B, H, L, E, p = 2, 8, 96, 256, 0.25
+    g = torch.Generator().manual_seed(11)
+    qk = (torch.randn(B, L, 2 * E, generator=g)).bfloat16().to(DEV)
+    lib, st = native.load(), (C.c_int64 * 8)(L * 2 * E, 2 * E, L * 2 * E, 2 * E, L * E, E, L * E, E)
+    epoch = torch.zeros((), dtype=torch.int64, device=DEV)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def probe(seed, offset):
+        Pd = torch.zeros(B, H, L, L)
+        for t in range(L // 32):
+            v = torch.zeros(B, L, H, 32)
+            v[:, 32 * t + torch.arange(32), :, torch.arange(32)] = 1.0       # key 32 t + d lights channel d of every head
+            vd, out = v.view(B, L, E).bfloat16().to(DEV), torch.empty(B, L, E, dtype=torch.bfloat16, device=DEV)
+            rc = lib.dskd_attn_fwd(qk.data_ptr(), qk.data_ptr() + 2 * E, vd.data_ptr(), out.data_ptr(), None, B, H, L, 32, st,
+                                   32 ** -0.5, p, seed, offset, epoch.data_ptr(), native.DTYPE_BF16, stream)
+            assert rc == 0
+            Pd[..., 32 * t:32 * t + 32] = out.float().cpu().view(B, L, H, 32).permute(0, 2, 1, 3)
+        return Pd
+
+    Pd = probe(1234, 7)
+    _, P = _self_attention_reference(qk.float().cpu(), torch.zeros(B, L, E), H)
+    keep = Pd != 0
+    frac = 1.0 - keep.float().mean().item()
+    assert abs(frac - p) < 0.01, frac
+    assert (keep.float().mean((-1, -2)) > 0.6).all()                    # every (image, head) has its own mask, none degenerate
+    assert float((Pd - P / (1 - p) * keep).abs().max()) < 8e-3 * float(P.max() / (1 - p))
+    assert torch.equal(probe(1234, 7), Pd)
+    assert not torch.equal(probe(1234, 8) != 0, keep) and not torch.equal(probe(1235, 7) != 0, keep)
+    epoch.add_(1 << 32)
+    assert not torch.equal(probe(1234, 7) != 0, keep)
+    epoch.zero_()
+
+    v = torch.randn(B, L, E, generator=g).bfloat16()
+    up = torch.randn(B, L, E, generator=g).bfloat16()
+    qr, vr = qk.float().cpu().requires_grad_(True), v.float().requires_grad_(True)
+    ref, _ = _self_attention_reference(qr, vr, H, keep.float(), p)
+    gq, gv = torch.autograd.grad(ref, (qr, vr), up.float())
+    vd, upd = v.to(DEV), up.to(DEV)
+    out = torch.empty(B, L, E, dtype=torch.bfloat16, device=DEV)
+    stats = torch.empty(B, H, L, 2, device=DEV)
+    delta = torch.empty(B, H, L, device=DEV)
+    dqk, dv = torch.full_like(qk, float("nan")), torch.full_like(vd, float("nan"))
+    assert lib.dskd_attn_fwd(qk.data_ptr(), qk.data_ptr() + 2 * E, vd.data_ptr(), out.data_ptr(), stats.data_ptr(), B, H, L, 32,
+                             st, 32 ** -0.5, p, 1234, 7, epoch.data_ptr(), native.DTYPE_BF16, stream) == 0
+    assert _close(out, ref.detach(), 8e-3)
+    assert lib.dskd_attn_bwd(qk.data_ptr(), qk.data_ptr() + 2 * E, vd.data_ptr(), out.data_ptr(), upd.data_ptr(),
+                             stats.data_ptr(), delta.data_ptr(), dqk.data_ptr(), dqk.data_ptr() + 2 * E, dv.data_ptr(), B, H, L,
+                             32, st, 32 ** -0.5, p, 1234, 7, epoch.data_ptr(), native.DTYPE_BF16, stream) == 0
+    assert _close(dqk, gq, 2e-2), float((dqk.float().cpu() - gq).abs().max()) / float(gq.abs().max())
+    assert _close(dv, gv, 2e-2), float((dv.float().cpu() - gv).abs().max()) / float(gv.abs().max())
+    # argument checks: wrong head dimension, too many tokens, odd strides
+    assert lib.dskd_attn_fwd(qk.data_ptr(), qk.data_ptr(), vd.data_ptr(), out.data_ptr(), None, B, H, L, 64, st, 1.0, 0.0, 0, 0,
+                             None, native.DTYPE_BF16, stream) != 0
+    assert lib.dskd_attn_fwd(qk.data_ptr(), qk.data_ptr(), vd.data_ptr(), out.data_ptr(), None, B, H, 321, 32, st, 1.0, 0.0, 0, 0,
+                             None, native.DTYPE_BF16, stream) != 0
+    bad = (C.c_int64 * 8)(L * 2 * E, 2 * E + 4, L * 2 * E, 2 * E, L * E, E, L * E, E)
+    assert lib.dskd_attn_fwd(qk.data_ptr(), qk.data_ptr(), vd.data_ptr(), out.data_ptr(), None, B, H, L, 32, bad, 1.0, 0.0, 0, 0,
+                             None, native.DTYPE_BF16, stream) != 0
+
+
 @pytest.mark.parametrize("shift", [0, 3])
 def test_shift_window_msa_module_uses_the_mfma_kernel(shift):
     """swin.ShiftWindowMSA on the GPU under bf16 autocast (window attention through csrc/winattn.hip) against the same
@@ -1694,13 +1802,14 @@ def test_gemm_tn_vs_float_reference(M, N, K):
     assert _close(out2, 2 * ref, 2e-3)
     # the bf16 forms.  dskd_gemm_tn_bf16: split-K planes in a scratch + a fixed-order reduction: deterministic (two calls
     # bit-equal) and independent of what the scratch held before
-    native._tn_scratch.pop(gd.device, None)
+    skey = (gd.device, torch.cuda.current_stream(gd.device).cuda_stream)
+    native._tn_scratch.pop(skey, None)
     b1 = native.gemm_tn_bf16(gd, xd)
-    native._tn_scratch[gd.device].fill_(0x7F)                           # NaN-ish garbage in every plane
+    native._tn_scratch[skey].fill_(0x7F)                           # NaN-ish garbage in every plane
     b2 = native.gemm_tn_bf16(gd, xd)
     assert b1.dtype == torch.bfloat16 and _close(b1, ref, 6e-3) and torch.equal(b1, b2)
     # the atomic form (persistent accumulator + dskd_cvt_clear): same values, and the accumulator is zero again
     a1 = native.gemm_tn_bf16_atomic(gd, xd)
     a2 = native.gemm_tn_bf16_atomic(gd, xd)
     assert _close(a1, ref, 6e-3) and _close(a2, ref, 6e-3)
-    assert float(native._tn_acc[(N, K, gd.device)].abs().max()) == 0.0
+    assert float(native._tn_acc[(N, K, gd.device, skey[1])].abs().max()) == 0.0

@@ -598,8 +598,22 @@ def test_adamw_clip_update_gpu_matches_cpu(fused_clip):
         opts[1].load_state_dict(ref.state_dict())
         for n in train[:3]:
             pg[n].grad = torch.zeros_like(pg[n])
-        opts[1].clip_and_step(0.1)
+        kept = opts[1].clip_and_step(0.1)
         assert int(opts[1].state[pg[train[0]]]["step"]) == 4
+        # a parameter whose step count differs is refused BEFORE any state moves, and the returned norm is
+        # the caller's own tensor, not the buffer the next step rewrites
+        st1 = opts[1].state[pg[train[1]]]
+        st1["step"] = st1["step"] + 5
+        before = [int(opts[1].state[pg[n]]["step"]) for n in train[:3]]
+        with pytest.raises(native.NativeError, match="different step counts"):
+            opts[1].clip_and_step(0.1)
+        assert [int(opts[1].state[pg[n]]["step"]) for n in train[:3]] == before
+        st1["step"] = st1["step"] - 5
+        v = float(kept)
+        for n in train[:3]:
+            pg[n].grad = torch.ones_like(pg[n])
+        opts[1].clip_and_step(0.1)
+        assert float(kept) == v and float(opts[1].last_norm[0]) != v
 
 
 def test_teacher_ahead_is_invalidated_by_set_teacher():

@@ -2,7 +2,8 @@
 cfg 1..6, with and without the split-K remainder) on every 1x1 / 3x3 convolution shape of ResNet-50 + ChannelMapper at
 B=4, 800x1333 (bf16, channels_last): forward (bias + residual + ReLU) and the input-gradient form (gate + residual).
 Interleaved rounds in one process, random data (cdna_hip_programming.md rules 24, 25).
-Usage: python tools/prof/gemm_tiles_bench.py [auto | k32]      ("auto": only cfg 0 against the automatic choice)"""
+Usage: python tools/prof/gemm_tiles_bench.py [auto | epi]      ("auto": only cfg 0 against the automatic choice; "epi": the
+small tile with the register epilogue (cfg 7) against the LDS epilogue (cfg 8))"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -11,7 +12,7 @@ lib = native.load()
 dev = torch.device("cuda:0")
 B = 4
 AUTO_ONLY = len(sys.argv) > 1 and sys.argv[1] == "auto"
-K32 = len(sys.argv) > 1 and sys.argv[1] == "k32"      # cfg 0 against cfg 7..10 (128 x 128 tiles, K stages of 32: NS 3 / 4, plain / LDS epilogue)
+EPI = len(sys.argv) > 1 and sys.argv[1] == "epi"
 # (name, K, N, H, W, stride, residual, relu, count per model forward)
 shapes1 = [("l1.conv1a", 64, 64, 200, 334, 1, 0, 1, 1), ("l1.conv1", 256, 64, 200, 334, 1, 0, 1, 2),
            ("l1.conv3", 64, 256, 200, 334, 1, 1, 1, 3), ("l1.down", 64, 256, 200, 334, 1, 0, 0, 1),
@@ -63,7 +64,7 @@ def bench(fn, variants, rounds=3, n=8):
 
 
 def report(name, flops, fn, out, tot):
-    variants = [(0, 0), (-1, 0)] if AUTO_ONLY else [(0, 0), (7, 0), (8, 0), (9, 0), (10, 0), (11, 0), (-1, 0)] if K32 else CFGS + [(-1, 0)]
+    variants = [(0, 0), (-1, 0)] if AUTO_ONLY else [(0, 0), (7, 0), (8, 0), (-1, 0)] if EPI else CFGS + [(-1, 0)]
     lib.dskd_gemm_nt_tune(0, 0)
     fn()
     ref = out.float().clone()
@@ -79,11 +80,11 @@ def report(name, flops, fn, out, tot):
     t = bench(fn, variants)
     t0, ta = t[(0, 0)], t[(-1, 0)]
     cols = ""
-    if K32:
-        k = [t.get((c, 0)) for c in (7, 8, 9, 10, 11)]
-        cols += " k32 ns3/ns4/ns3+lds/ns4+lds, small+lds " + " ".join("   -  " if v is None else f"{v:6.1f}" for v in k) + " |"
+    if EPI:
+        k = [t.get((c, 0)) for c in (7, 8)]
+        cols += " register / LDS epilogue " + " ".join("   -  " if v is None else f"{v:6.1f}" for v in k) + " |"
         tot[2] += min([v for v in k if v is not None] + [t0])
-    if not AUTO_ONLY and not K32:
+    if not AUTO_ONLY and not EPI:
         for c in range(1, 7):
             a, b = t.get((c, 0)), t.get((c, 1))
             cols += "    -  " if a is None else f" {min(a, b):5.1f}{'*' if a < b else ' '}"
@@ -136,4 +137,4 @@ for name, C, H, W, s, cnt in shapes3:
         tot_3d[0] += t[0] * cnt; tot_3d[1] += t[1] * cnt; tot_3d[2] += t[2] * cnt
 for lab, t in (("1x1 forward, one model", tot_f), ("1x1 dX (stride-1 layers)", tot_d), ("3x3 forward, one model", tot_3),
                ("3x3 dX (stride-1 layers)", tot_3d)):
-    print(f"{lab}: small tile {t[0] / 1e3:.3f} ms, best of small / k32 {t[2] / 1e3:.3f} ms, automatic choice {t[1] / 1e3:.3f} ms")
+    print(f"{lab}: small tile {t[0] / 1e3:.3f} ms, best epilogue {t[2] / 1e3:.3f} ms, automatic choice {t[1] / 1e3:.3f} ms")

@@ -1,4 +1,4 @@
-"""gemm_tn per layer shape of the step: us, TFLOP/s (scratch; B=4 800x1333 token counts)."""
+"""gemm_tn per layer shape of the step: us, TFLOP/s (B=4 800x1333 token counts)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
