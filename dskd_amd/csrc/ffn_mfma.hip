@@ -560,13 +560,18 @@ struct LinArgs {
   int N, relu;
 };
 
-__global__ __launch_bounds__(kWaves * 64, DSKD_LIN_OCC) void lin256_kernel(const LinArgs a) {
+#ifndef DSKD_LIN_WAVES
+#define DSKD_LIN_WAVES 4
+#endif
+constexpr int kLinWaves = DSKD_LIN_WAVES;      // waves (of 32 tokens) per workgroup
+
+__global__ __launch_bounds__(kLinWaves * 64, DSKD_LIN_OCC) void lin256_kernel(const LinArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];       // kLinBufs x 16 KB weight tiles | N floats of bias
   float* const s_b = reinterpret_cast<float*>(smem + kLinBufs * kLinTileBytes);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, h = lane >> 5;
-  const long long tok0 = (long long)blockIdx.x * (kWaves * 32) + wave * 32;
+  const long long tok0 = (long long)blockIdx.x * (kLinWaves * 32) + wave * 32;
   const long long tok = tok0 + r;
   const bool live = tok < a.T;
   const long long tk = live ? tok : a.T - 1;
@@ -579,8 +584,8 @@ __global__ __launch_bounds__(kWaves * 64, DSKD_LIN_OCC) void lin256_kernel(const
     const char* src = reinterpret_cast<const char*>(a.wp) + (size_t)t * kLinTileBytes;
     char* dst = smem + (t % kLinBufs) * kLinTileBytes;
 #pragma unroll
-    for (int p = 0; p < 16 / kWaves; ++p) {
-      const int blk = p * kWaves + wave;
+    for (int p = 0; p < 16 / kLinWaves; ++p) {
+      const int blk = p * kLinWaves + wave;
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(src + blk * 1024 + lane * 16),
           (__attribute__((address_space(3))) void*)(dst + blk * 1024), 16, 0, 0);
@@ -588,7 +593,7 @@ __global__ __launch_bounds__(kWaves * 64, DSKD_LIN_OCC) void lin256_kernel(const
   };
   stage(0);
   if (ntiles > 1) stage(1);
-  for (int i = threadIdx.x; i < a.N; i += kWaves * 64) s_b[i] = a.bias ? (float)a.bias[i] : 0.f;
+  for (int i = threadIdx.x; i < a.N; i += kLinWaves * 64) s_b[i] = a.bias ? (float)a.bias[i] : 0.f;
   bf16x8 xf[16];
   {
     const __bf16* xrow = a.x + tk * kD + 128 * h;
@@ -778,7 +783,7 @@ extern "C" int dskd_lin256_fwd(const void* x, const void* packed, const void* bi
   LinArgs a{};
   a.x = (const __bf16*)x; a.wp = (const __bf16*)packed; a.bias = (const __bf16*)bias; a.y = (__bf16*)y;
   a.T = tokens; a.N = N; a.relu = relu;
-  const long long grid = (tokens + kWaves * 32 - 1) / (kWaves * 32);
-  hipLaunchKernelGGL(lin256_kernel, dim3((unsigned)grid), dim3(kWaves * 64), lds, (hipStream_t)stream, a);
+  const long long grid = (tokens + kLinWaves * 32 - 1) / (kLinWaves * 32);
+  hipLaunchKernelGGL(lin256_kernel, dim3((unsigned)grid), dim3(kLinWaves * 64), lds, (hipStream_t)stream, a);
   return check_launch("dskd_lin256_fwd");
 }

@@ -208,9 +208,32 @@ __device__ __forceinline__ void lds_write4(unsigned addr, const f32x16& v, int q
 
 // rows [row0, row0 + 32) x 64 outputs of one wave: acc[nt][i] = token (lane & 31), output 32 nt + 16 (lane >> 5) + i.
 // `scr`: this wave's 32 x 272-byte LDS scratch.  PARTIAL: f32 to `dst_f32` (row stride ldp floats), no epilogue.
-template <bool PARTIAL>
+// residual / gate of the 32 x 64 block a wave stores, in the layout store_rows32 consumes them (lane = 16 B of one row):
+// requested BEFORE the K loop so that their latency runs under the loop instead of after it -- the tall thin layers of
+// ResNet stage 1-2 (K = 64 .. 256: one to four stages) are HBM-bound and spent a third of a tile's time in the epilogue
+// waiting for exactly these reads.
+#ifndef DSKD_EPI_PRE
+#define DSKD_EPI_PRE 1       // -DDSKD_EPI_PRE=0: the A/B build that reads them in the epilogue
+#endif
+struct EpiPre {
+  bf16x8 res[4], gate[4];
+};
+__device__ __forceinline__ void load_epi(const GemmArgs& a, long long m_first, int n_first, int lane, EpiPre& p) {
+  const int row = lane >> 3, n = n_first + (lane & 7) * 8;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    long long m = m_first + it * 8 + row;
+    if (m >= a.M) m = a.M - 1;
+    p.res[it] = bf16x8{};
+    p.gate[it] = bf16x8{};
+    if (a.res) p.res[it] = *reinterpret_cast<const bf16x8*>(a.res + m * a.N + n);
+    if (a.gate) p.gate[it] = *reinterpret_cast<const bf16x8*>(a.gate + m * a.N + n);
+  }
+}
+
+template <bool PARTIAL, bool PRE = false>
 __device__ __forceinline__ void store_rows32(const GemmArgs& a, const f32x16 (&acc)[2], unsigned scr, long long m_first,
-                                             int n_first, float* dst_f32, int ldp, int lane) {
+                                             int n_first, float* dst_f32, int ldp, int lane, const EpiPre* pre = nullptr) {
   const int r = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
@@ -248,12 +271,16 @@ __device__ __forceinline__ void store_rows32(const GemmArgs& a, const f32x16 (&a
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] += bias[i];
       if (a.res) {
-        const bf16x8 rr = *reinterpret_cast<const bf16x8*>(a.res + m * a.N + n);
+        bf16x8 rr;
+        if constexpr (PRE) rr = pre->res[it];
+        else rr = *reinterpret_cast<const bf16x8*>(a.res + m * a.N + n);
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] += (float)rr[i];
       }
       if (a.gate) {
-        const bf16x8 gg = *reinterpret_cast<const bf16x8*>(a.gate + m * a.N + n);
+        bf16x8 gg;
+        if constexpr (PRE) gg = pre->gate[it];
+        else gg = *reinterpret_cast<const bf16x8*>(a.gate + m * a.N + n);
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = (float)gg[i] > 0.f ? v[i] : 0.f;
       }
@@ -274,7 +301,7 @@ __device__ __forceinline__ void store_rows32(const GemmArgs& a, const f32x16 (&a
 // one round of the chip -- and there tile quantisation (264 = 256 + 8) and the second resident workgroup matter more
 // than the per-stage latency.  SQ counters of the K = 1024, N = 256, 16 800-token layer: no LDS bank conflicts, MFMA
 // pipe busy 24 % of the wave's lifetime, 30 % in s_waitcnt / barrier.
-template <int BN, int MT, bool CONV3, bool LDS_EPI = false>
+template <int BN, int MT, bool CONV3, bool LDS_EPI = false, bool EPI_PRE = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs a) {
   constexpr int NS = 2;
   constexpr int WN = BN / 64;              // waves along the outputs
@@ -385,9 +412,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
 
+  constexpr bool PRE = LDS_EPI && EPI_PRE;
+  EpiPre pre[PRE ? MT : 1];
   {
     PROF(0);
     issue(0);
+    if constexpr (PRE) {       // older than every later DMA: the loop's first counted wait covers them too
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) load_epi(a, m0 + (wm * MT + mt) * 32, n0 + wn * 64, lane, pre[mt]);
+    }
     Frags<MT> f;
     for (int kt = 0; kt < nk; ++kt) {
       if (kt + 1 < nk) {
@@ -408,7 +441,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs a) {
     const unsigned scr = base + wave * (32 * 272);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
-      store_rows32<false>(a, acc[mt], scr, m0 + (wm * MT + mt) * 32, n0 + wn * 64, nullptr, 0, lane);
+      store_rows32<false, PRE>(a, acc[mt], scr, m0 + (wm * MT + mt) * 32, n0 + wn * 64, nullptr, 0, lane, &pre[PRE ? mt : 0]);
   } else {
     store_tile<MT>(a, acc, m0 + wm * MT * 32 + r, n0 + wn * 64 + 16 * h);
   }
@@ -418,12 +451,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs a) {
 #endif
 }
 
-template <int BN, int MT, bool CONV3, bool LDS_EPI = false>
+template <int BN, int MT, bool CONV3, bool LDS_EPI = false, bool EPI_PRE = false>
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
   constexpr int BM = (4 / (BN / 64)) * MT * 32;
   constexpr int LDS = 2 * 2 * (BM * 64 + BN * 64);
   static_assert(LDS >= 4 * 32 * 272, "epilogue scratch");
-  auto kern = gemm_nt_kernel<BN, MT, CONV3, LDS_EPI>;
+  auto kern = gemm_nt_kernel<BN, MT, CONV3, LDS_EPI, EPI_PRE>;
   int dev = 0;
   static bool done[64] = {};              // the attribute is per device: set it once on each
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -771,7 +804,20 @@ struct TnArgs {
   int splits;            // workgroups along M per output tile
   long long chunk;       // tokens per split (a multiple of 32)
   int tn;                // 128-row groups of the output tile (1: 128 x 128, 2: 256 x 128)
+  // CONV (3x3 weight gradient): x is the INPUT image [B, Hi, Wi, C = ldx], row m of g is output pixel (img, ho, wo); column
+  // tap * C + c of the virtual x operand is channel c of input pixel (s ho + ky - 1, s wo + kx - 1), zeros outside
+  int Hi, Wi, Wo, HoWo, s;
+  float inv_howo, inv_wo;
 };
+
+// m / d for 0 <= m < 2^24 (exact in f32) with inv = 1 / d: the float quotient is off by at most one
+__device__ __forceinline__ int fast_div(int m, int d, float inv) {
+  int q = (int)((float)m * inv);
+  const int r = m - q * d;
+  q += r >= d ? 1 : 0;
+  q -= r < 0 ? 1 : 0;
+  return q;
+}
 
 __device__ __forceinline__ bf16x8 tr_pair(unsigned a0, unsigned a1) {      // tokens t .. t+3 (a0) and t+4 .. t+7 (a1) of one channel column
   const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(unsigned long)a0);
@@ -779,7 +825,7 @@ __device__ __forceinline__ bf16x8 tr_pair(unsigned a0, unsigned a1) {      // to
   return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-template <bool ATOMIC, int TN>
+template <bool ATOMIC, int TN, bool CONV = false>
 __global__ __launch_bounds__((4 * TN + 4) * 64) void gemm_tn_kernel(const TnArgs a) {
   // TN = 2 (r4): a 256 (N) x 128 (K) output tile, eight multiplying waves (two per SIMD) + four producers: per stage 48 KB of
   // operands for 4.2 MFLOP instead of 32 KB for 2.1 -- with the 128 x 128 tile the matrix pipe (512 cycles per stage), the
@@ -823,7 +869,10 @@ __global__ __launch_bounds__((4 * TN + 4) * 64) void gemm_tn_kernel(const TnArgs
   // image of one DMA instruction stays lane-linear.
   const int lrow = lane >> 4;
   const char* gp = reinterpret_cast<const char*>(a.g) + (long long)tn * 256 * TN;
-  const char* xp = reinterpret_cast<const char*>(a.x) + (long long)tk * 256;
+  // CONV: a 128-column tile of the virtual operand lies inside ONE tap (C is a multiple of 128)
+  const int tap = CONV ? (tk * 128) / a.ldx : 0;
+  const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;              // tap / 3 for tap < 9
+  const char* xp = reinterpret_cast<const char*>(a.x) + (CONV ? (long long)(tk * 128 - tap * a.ldx) * 2 : (long long)tk * 256);
   const char* const zp = g_zero_page;
   auto issue = [&](int st, int j0, int j1) {          // the LDS-DMA instructions of token groups [j0, j1) of stage st
     char* sg = smem + (st % NS) * STAGE;
@@ -839,7 +888,20 @@ __global__ __launch_bounds__((4 * TN + 4) * 64) void gemm_tn_kernel(const TnArgs
       for (int im = 0; im < TN; ++im)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ok ? gp + m * a.ldg * 2 + im * 256 + lcol : zp),
                                          (__attribute__((address_space(3))) void*)(sg + im * TILE + (wave * (TOK / 4) + j * 4) * ROWB), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ok ? xp + m * a.ldx * 2 + lcol : zp),
+      const char* xsrc = zp;
+      if constexpr (CONV) {
+        if (ok) {
+          const int mi = (int)m;
+          const int img = fast_div(mi, a.HoWo, a.inv_howo), rem = mi - img * a.HoWo;
+          const int ho = fast_div(rem, a.Wo, a.inv_wo), wo = rem - ho * a.Wo;
+          const int hi = a.s * ho + ky - 1, wi = a.s * wo + kx - 1;
+          if ((unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi)
+            xsrc = xp + (((long long)img * a.Hi + hi) * a.Wi + wi) * a.ldx * 2 + lcol;
+        }
+      } else if (ok) {
+        xsrc = xp + m * a.ldx * 2 + lcol;
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)xsrc,
                                        (__attribute__((address_space(3))) void*)(sx + (wave * (TOK / 4) + j * 4) * ROWB), 16, 0, 0);
     }
   };
@@ -1050,15 +1112,21 @@ using namespace dskd;
 
 // ---- tile choice ---------------------------------------------------------------------------------------------------
 // cfg 0 = gemm_nt_kernel (64 x 128 / 128 x 64 tiles, 3 workgroups per CU; epilogue by M), 1 .. kBigCfgs = big_cfg(cfg - 1),
-// kBigCfgs + 1 / + 2 = gemm_nt_kernel with the register / the LDS epilogue forced.
+// kBigCfgs + 1 / + 2 / + 3 = gemm_nt_kernel with the register / the LDS epilogue / the LDS epilogue without the early
+// residual + gate reads forced.
 // dskd_gemm_nt_tune: a tuning hook for microbenchmarks and tests (scratch/r04_gemm_big.py) -- cfg < 0: automatic
 // (default); splits: 0 automatic, 1 never split, > 1 forced (clamped to the K stages and the scratch).
 static int g_tune_cfg = -1, g_tune_splits = 0;
 static int g_tn_force = 0;      // tuning hook (dskd_gemm_nt_tune with cfg -2 / -3): force the 128 x 128 / 256 x 128 dW tile
+static int g_tn_splits = 0;     // ... and, with splits > 0, the number of token splits of the dW kernels
 extern "C" int dskd_gemm_nt_tune(int cfg, int splits) {
-  if (cfg == -2 || cfg == -3) { g_tn_force = cfg == -2 ? 1 : 2; return DSKD_OK; }      // dW tile: 128 x 128 / 256 x 128
-  if (cfg == -1) g_tn_force = 0;
-  if (cfg > kBigCfgs + 2) return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_nt_tune: cfg %d > %d", cfg, kBigCfgs + 2);
+  if (cfg == -2 || cfg == -3) {      // dW tile: 128 x 128 / 256 x 128
+    g_tn_force = cfg == -2 ? 1 : 2;
+    g_tn_splits = splits > 0 ? splits : 0;
+    return DSKD_OK;
+  }
+  if (cfg == -1) g_tn_force = g_tn_splits = 0;
+  if (cfg > kBigCfgs + 3) return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_nt_tune: cfg %d > %d", cfg, kBigCfgs + 3);
   g_tune_cfg = cfg;
   g_tune_splits = splits;
   return DSKD_OK;
@@ -1141,9 +1209,17 @@ static int launch_choice(const GemmArgs& a, BigChoice c, void* scratch, hipStrea
     // layer shape of the trunk (scratch/r03_conv1x1.py) -- three workgroups per CU instead of two.  Epilogue through LDS
     // (whole 128-byte lines) for the tall layers: 3 - 10 % on the write-heavy ones (l1.conv3 82.6 -> 78.4 us, l1.down 42.8 ->
     // 38.2, l2.conv1 dX 46.1 -> 41.3), a wash or a small loss on the 4 200-row layers (profiles/r04_gemm_big_microbench.txt)
-    const bool lds_epi = c.cfg == 0 ? a.M >= 8192 : c.cfg == kBigCfgs + 2;
-    if (a.N % 128) return lds_epi ? launch_gemm<64, 1, CONV3, true>(a, st) : launch_gemm<64, 1, CONV3, false>(a, st);
-    return lds_epi ? launch_gemm<128, 1, CONV3, true>(a, st) : launch_gemm<128, 1, CONV3, false>(a, st);
+    // r4 (tools/prof/gemm_tiles_bench.py epi, interleaved): with the residual / gate reads requested before the K loop the
+    // LDS epilogue gains 13 - 16 % on the HBM-bound stage-1 layers that read a residual (l1.conv3 80 -> 70 us, l1.conv1 dX
+    // 105 -> 88); input gradients that only read a gate are 1 - 3 % faster with the register epilogue on every shape
+    const bool lds_epi = c.cfg == 0 ? (a.M >= 8192 && !(a.gate && !a.res)) : c.cfg >= kBigCfgs + 2;
+    // residual / gate requested before the K loop (EpiPre) where the epilogue reads one: +36 VGPRs, nothing for the others
+    const bool pre = lds_epi && DSKD_EPI_PRE && (a.res || a.gate) && c.cfg != kBigCfgs + 3;
+    if (a.N % 128)
+      return pre ? launch_gemm<64, 1, CONV3, true, true>(a, st)
+                 : lds_epi ? launch_gemm<64, 1, CONV3, true>(a, st) : launch_gemm<64, 1, CONV3, false>(a, st);
+    return pre ? launch_gemm<128, 1, CONV3, true, true>(a, st)
+               : lds_epi ? launch_gemm<128, 1, CONV3, true>(a, st) : launch_gemm<128, 1, CONV3, false>(a, st);
   }
   c.plan.planes = (float*)scratch;
   int rc;
@@ -1249,7 +1325,7 @@ extern "C" int dskd_conv3x3_ws(const void* x, const void* w, const void* bias, c
 }
 
 static int gemm_tn_plan(const void* g, const void* x, const void* c, int64_t M, int N, int K, int ldg, int ldx, int dtype,
-                        TnArgs* a, long long* tiles_out) {
+                        TnArgs* a, long long* tiles_out, int force_tn = 0) {
   if (dtype != DSKD_DTYPE_BF16) return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_tn: bf16 only");
   if (!g || !x || !c || M < 0) return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_tn: null pointer or negative row count");
   if (N <= 0 || K <= 0 || (N & 127) || (K & 127) || ldg < N || ldx < K || (ldg & 7) || (ldx & 7))
@@ -1261,13 +1337,14 @@ static int gemm_tn_plan(const void* g, const void* x, const void* c, int64_t M, 
   // 256 x 128 output tiles only for the large products of the encoder FFN (N K >= 256 K, M >= 64 K tokens: 3 % faster there,
   // 10-25 % slower on the convolution shapes: profiles/r04_gemm_tn_phases.txt)
   a->tn = (N % 256 == 0 && (long long)N * K >= 262144 && M >= 65536) ? 2 : 1;
-  if (g_tn_force) a->tn = (g_tn_force == 2 && N % 256 == 0) ? 2 : 1;
+  if (force_tn || g_tn_force) a->tn = ((g_tn_force ? g_tn_force : force_tn) == 2 && N % 256 == 0) ? 2 : 1;
   const long long tiles = (long long)(N / (128 * a->tn)) * (K >> 7);
   // splits: one workgroup per CU (256 in all: each flushes its 64 KB tile, 16 MB per launch), two per CU
   // where that still leaves the flush volume small and >= 1 024 tokens per workgroup; never fewer than 256 tokens each
   long long sp = 256 / tiles;
   if (sp < 1) sp = 1;
   if (tiles * sp * 2 * 65536 <= (long long)(DSKD_TN_ATOMIC_MB * 1.0e6) && M / (2 * sp) >= 1024) sp *= 2;
+  if (g_tn_splits > 0) sp = g_tn_splits;
   const long long by_work = (M + 255) / 256;
   if (sp > by_work) sp = by_work;
   if (sp < 1) sp = 1;
@@ -1278,13 +1355,13 @@ static int gemm_tn_plan(const void* g, const void* x, const void* c, int64_t M, 
   return DSKD_OK;
 }
 
-template <bool ATOMIC, int TN>
+template <bool ATOMIC, int TN, bool CONV = false>
 static int gemm_tn_launch_t(const TnArgs& a, long long tiles, hipStream_t st) {
   constexpr int lds = DSKD_TN_NS * (TN + 1) * DSKD_TN_TOK * 256;
   static bool done[64] = {};
-  if (!reserve_lds((const void*)gemm_tn_kernel<ATOMIC, TN>, lds, done))
+  if (!reserve_lds((const void*)gemm_tn_kernel<ATOMIC, TN, CONV>, lds, done))
     return fail(DSKD_ERR_LAUNCH, "dskd_gemm_tn: cannot reserve %d bytes of LDS", lds);
-  hipLaunchKernelGGL((gemm_tn_kernel<ATOMIC, TN>), dim3((unsigned)(tiles * a.splits)), dim3((4 * TN + 4) * 64), lds, st, a);
+  hipLaunchKernelGGL((gemm_tn_kernel<ATOMIC, TN, CONV>), dim3((unsigned)(tiles * a.splits)), dim3((4 * TN + 4) * 64), lds, st, a);
   return check_launch("dskd_gemm_tn");
 }
 template <bool ATOMIC>
@@ -1328,6 +1405,54 @@ extern "C" int dskd_gemm_tn_bf16(const void* g, const void* x, void* out, void* 
     hipLaunchKernelGGL(reduce_cvt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float*)scratch, a.splits, n, (__bf16*)out);
   return check_launch("dskd_gemm_tn_bf16/reduce");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradient of a 3x3 convolution (padding 1, stride 1 | 2) as the SAME split-K kernel: dW[n][ky][kx][c] = sum over the
+// output pixels of dY[pixel][n] * X[pixel shifted by the tap][c] -- gemm_tn over a virtual [pixels, 9 C] operand whose
+// 128-column tiles each lie inside one tap, so only the producers' source addresses change (shifted row, zero page outside
+// the image).  Replaces MIOpen's igemm_wrw + its f32 workspace helpers (SubTensorOp fill / cast: 1.3 ms per step for the 16
+// convolutions of the trunk, and the memset nodes that keep its backward out of a hipGraph).
+static int conv3x3_wgrad_plan(const void* g, const void* x, const void* c, int B, int Hi, int Wi, int C, int N, int stride,
+                              int dtype, TnArgs* a, long long* tiles) {
+  if (B < 1 || Hi < 1 || Wi < 1 || (stride != 1 && stride != 2) || C < 128 || (C & 127) || N < 128 || (N & 127))
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_conv3x3_wgrad: C and N must be multiples of 128, stride 1 or 2 (got C=%d N=%d "
+                "stride=%d)", C, N, stride);
+  const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
+  const long long M = (long long)B * Ho * Wo;
+  if (M >= (1ll << 24) || (long long)B * Hi * Wi * C >= (1ll << 40))
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_conv3x3_wgrad: %lld output pixels (the index arithmetic is built for < 2^24)", M);
+  // 256 x 128 output tiles where N allows (stages 3-4): 36-72 tiles x floor(256 / tiles) splits fill the chip once, and a
+  // stage moves 48 KB for 4.2 MFLOP instead of 32 KB for 2.1 (tools/prof/conv3x3_wgrad_bench.py sweep: l3 53 -> 46 us, l4 76 -> 50)
+  if (int rc = gemm_tn_plan(g, x, c, M, N, 9 * C, N, 9 * C, dtype, a, tiles, N % 256 == 0 ? 2 : 1)) return rc;
+  a->ldx = C; a->Hi = Hi; a->Wi = Wi; a->Wo = Wo; a->HoWo = Ho * Wo; a->s = stride;
+  a->inv_howo = 1.0f / (float)(Ho * Wo); a->inv_wo = 1.0f / (float)Wo;
+  return DSKD_OK;
+}
+
+extern "C" int64_t dskd_conv3x3_wgrad_scratch_bytes(int B, int Hi, int Wi, int C, int N, int stride) {
+  TnArgs a;
+  long long tiles = 0;
+  static const char dummy[16] __attribute__((aligned(16))) = {};
+  if (conv3x3_wgrad_plan(dummy, dummy, dummy, B, Hi, Wi, C, N, stride, DSKD_DTYPE_BF16, &a, &tiles)) return -1;
+  return (int64_t)a.splits * N * 9 * C * (int64_t)sizeof(float);
+}
+
+extern "C" int dskd_conv3x3_wgrad(const void* g, const void* x, void* dw, void* scratch, int64_t scratch_bytes, int B, int Hi,
+                                  int Wi, int C, int N, int stride, int dtype, void* stream) {
+  TnArgs a;
+  long long tiles = 0;
+  if (!dw || (reinterpret_cast<uintptr_t>(dw) & 1)) return fail(DSKD_ERR_INVALID_ARG, "dskd_conv3x3_wgrad: null output");
+  if (int rc = conv3x3_wgrad_plan(g, x, scratch, B, Hi, Wi, C, N, stride, dtype, &a, &tiles)) return rc;
+  const long long n = (long long)N * 9 * C;
+  if (scratch_bytes < (int64_t)a.splits * n * (int64_t)sizeof(float))
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_conv3x3_wgrad: scratch of %lld bytes, %lld needed", (long long)scratch_bytes,
+                (long long)a.splits * n * (long long)sizeof(float));
+  if (int rc = a.tn == 2 ? gemm_tn_launch_t<false, 2, true>(a, tiles, (hipStream_t)stream)
+                         : gemm_tn_launch_t<false, 1, true>(a, tiles, (hipStream_t)stream)) return rc;
+  hipLaunchKernelGGL(reduce_cvt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)scratch, a.splits, n, (__bf16*)dw);
+  return check_launch("dskd_conv3x3_wgrad/reduce");
 }
 
 extern "C" int dskd_cvt_clear(float* src, void* dst, int64_t n, int dtype, void* stream) {

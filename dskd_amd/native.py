@@ -70,6 +70,8 @@ _SIGNATURES = {
     "dskd_gemm_tn_bf16": (C.c_int, [_vp] * 4 + [_i64, _i64] + [C.c_int] * 5 + [_vp]),
     "dskd_winattn_fwd": (C.c_int, [_vp] * 4 + [C.c_int] * 5 + [_f32, C.c_int, _vp]),
     "dskd_winattn_bwd": (C.c_int, [_vp] * 6 + [C.c_int] * 5 + [_f32, C.c_int, _vp]),
+    "dskd_conv3x3_wgrad_scratch_bytes": (C.c_int64, [C.c_int] * 6),
+    "dskd_conv3x3_wgrad": (C.c_int, [_vp] * 4 + [C.c_int64] + [C.c_int] * 7 + [_vp]),
     "dskd_attn_fwd": (C.c_int, [_vp] * 5 + [C.c_int] * 4 + [_vp, _f32, _f32, C.c_uint64, C.c_uint64, _vp, C.c_int, _vp]),
     "dskd_attn_bwd": (C.c_int, [_vp] * 10 + [C.c_int] * 4 + [_vp, _f32, _f32, C.c_uint64, C.c_uint64, _vp, C.c_int, _vp]),
     "dskd_clip_adamw_chunk": (C.c_int, []),
@@ -106,7 +108,7 @@ def lib_path() -> str:
 # every DSKD_* environment switch something in this repository reads (package, library, bench.py, tools/): a variable that
 # is set but not listed here does nothing -- load() says so, instead of an A/B run quietly timing the same code twice
 KNOWN_ENV = frozenset((
-    "DSKD_HIP_LIB", "DSKD_CONV_LIB", "DSKD_SDPA_ATTN", "DSKD_NO_GRAPHS", "DSKD_FORCE_GRAPHS", "DSKD_EAGER_HEAD",
+    "DSKD_HIP_LIB", "DSKD_CONV_LIB", "DSKD_CONV3_WGRAD_LIB", "DSKD_SDPA_ATTN", "DSKD_NO_GRAPHS", "DSKD_FORCE_GRAPHS", "DSKD_EAGER_HEAD",
     "DSKD_EAGER_LOSSES", "DSKD_GRAPH_TRACE", "DSKD_MSDA_MM", "DSKD_MSDA_PULL_LEVELS", "DSKD_GRADSYNC_NOCOMM",
     "DSKD_GRADSYNC_BUCKET_MB", "DSKD_WRAP_DDP", "DSKD_BENCH_REHEARSE", "DSKD_BENCH_STEPTIMES", "DSKD_BENCH_DDP1",
     "DSKD_BENCH_WRAP_DDP"))
@@ -160,8 +162,7 @@ _acc_cache = {}
 def _persistent_acc(shape, device) -> torch.Tensor:
     """A zeroed f32 accumulator of ``shape`` that STAYS zeroed between uses: the kernels add their column sums into it and
     :func:`sum_clear` hands the result over and clears it again -- no zero-fill launch per call.  One per (shape, device,
-    STREAM): two streams never add into the same words.  It must exist before a hipGraph capture (the warm-up on the
-    capture stream creates it).  Use it under :func:`_acc_guard`."""
+    STREAM): two streams never add into the same words.  Use it under :func:`_acc_guard`."""
     device = torch.device(device)
     if device.index is None and device.type == "cuda":
         device = torch.device("cuda", torch.cuda.current_device())
@@ -169,8 +170,9 @@ def _persistent_acc(shape, device) -> torch.Tensor:
     t = _acc_cache.get(key)
     if t is None:
         if torch.cuda.is_current_stream_capturing():
-            raise NativeError("a column-sum accumulator must exist before a hipGraph capture (run one eager step on the "
-                              "capture stream)")
+            # no warm-up ran on the capture stream: an accumulator of the graph's own pool, zeroed by a captured fill
+            # kernel on every replay (torch.zeros would be a memset node: see zeros()); not cached -- it lives with the graph
+            return zeros(shape, torch.float32, device)
         t = _acc_cache[key] = torch.zeros(shape, dtype=torch.float32, device=device)
     return t
 
@@ -361,8 +363,7 @@ _msda_ws_cache = {}
 
 def _msda_bwd_workspace(device, B, Nv, Nq, heads, L, P) -> torch.Tensor:
     """Workspace of ``dskd_msda_bwd_ws`` (stray-sample list; header zeroed once, the library leaves it zeroed),
-    one per (device, stream): launches of one stream run one after the other, two streams never share a stray list; a
-    hipGraph capture finds the buffer its warm-up on the capture stream made."""
+    one per (device, stream): launches of one stream run one after the other, two streams never share a stray list."""
     need = int(load().dskd_msda_bwd_workspace(B, Nv, Nq, heads, L, P))
     device = torch.device(device)
     if device.index is None:
@@ -371,7 +372,7 @@ def _msda_bwd_workspace(device, B, Nv, Nq, heads, L, P) -> torch.Tensor:
     ws = _msda_ws_cache.get(key)
     if ws is None or ws.numel() < need:
         if torch.cuda.is_current_stream_capturing():
-            raise NativeError("msda backward workspace must be allocated before a hipGraph capture (run one eager step)")
+            return zeros((need + 15) // 16 * 16, torch.uint8, device)     # the graph's own (see _persistent_acc)
         ws = _msda_ws_cache[key] = torch.zeros(need, dtype=torch.uint8, device=device)
     return ws
 
@@ -1061,8 +1062,9 @@ def gemm_tn_bf16_atomic(g2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     acc = _tn_acc.get(key)
     if acc is None:
         if torch.cuda.is_current_stream_capturing():
-            raise NativeError("gemm_tn_bf16: the accumulator must exist before a hipGraph capture (run one eager step)")
-        acc = _tn_acc[key] = torch.zeros((N, K), dtype=torch.float32, device=g2.device)
+            acc = zeros((N, K), torch.float32, g2.device)            # the graph's own (see _persistent_acc)
+        else:
+            acc = _tn_acc[key] = torch.zeros((N, K), dtype=torch.float32, device=g2.device)
     with _acc_guard(acc):
         gemm_tn(g2, x2, out=acc)
         out = torch.empty((N, K), dtype=torch.bfloat16, device=g2.device)
@@ -1070,12 +1072,53 @@ def gemm_tn_bf16_atomic(g2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def _tn_ws(dev, need):
+    """The split-K scratch of gemm_tn_bf16 / conv3x3_wgrad for the current stream (inside a capture: the graph's own)."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _tn_scratch.get(key)
+    if ws is None or ws.numel() < need:
+        if torch.cuda.is_current_stream_capturing():
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)     # from the graph's own pool: lives with the graph
+        else:
+            ws = _tn_scratch[key] = torch.empty(max(need, 32 << 20), dtype=torch.uint8, device=dev)
+    return ws
+
+
+def conv3x3_wgrad_ok(g: torch.Tensor, x: torch.Tensor, stride: int) -> bool:
+    """Can dskd_conv3x3_wgrad take this weight gradient: channels_last bf16 CUDA dY [B, N, Ho, Wo] and input [B, C, Hi, Wi],
+    C and N multiples of 128, stride 1 or 2?"""
+    cl = torch.channels_last
+    return (g.is_cuda and x.is_cuda and g.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and g.dim() == 4 and x.dim() == 4
+            and g.shape[1] % 128 == 0 and x.shape[1] % 128 == 0 and stride in (1, 2) and g.shape[0] == x.shape[0]
+            and g.shape[2] == (x.shape[2] - 1) // stride + 1 and g.shape[3] == (x.shape[3] - 1) // stride + 1
+            and g.is_contiguous(memory_format=cl) and x.is_contiguous(memory_format=cl)
+            and g.shape[0] * g.shape[2] * g.shape[3] < (1 << 24) and g.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0)
+
+
+def conv3x3_wgrad(g: torch.Tensor, x: torch.Tensor, stride: int) -> torch.Tensor:
+    """d(weight) of ``conv2d(x, w, stride, padding=1)`` for a 3x3 kernel: [N, C, 3, 3] channels_last bf16, two launches
+    (split-K products + fixed-order reduction), deterministic (dskd_conv3x3_wgrad)."""
+    _need_gpu(g, x)
+    B, Cc, Hi, Wi = x.shape
+    N = g.shape[1]
+    need = int(load().dskd_conv3x3_wgrad_scratch_bytes(B, Hi, Wi, Cc, N, stride))
+    if need < 0:
+        raise NativeError("conv3x3_wgrad: " + load().dskd_last_error().decode())
+    ws = _tn_ws(x.device, need)
+    dw = torch.empty((N, Cc, 3, 3), dtype=torch.bfloat16, device=x.device).contiguous(memory_format=torch.channels_last)
+    rc = load().dskd_conv3x3_wgrad(g.data_ptr(), x.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(), B, Hi, Wi, Cc, N,
+                                   stride, DTYPE_BF16, _stream(x))
+    _check(rc, "dskd_conv3x3_wgrad")
+    global _ffn_flops
+    _ffn_flops += 2 * B * g.shape[2] * g.shape[3] * N * 9 * Cc
+    return dw
+
+
 def gemm_tn_bf16(g2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     """``(g2^T @ x2).to(bf16)`` -- a weight gradient in the low-precision parameter's dtype -- in two launches without
     atomics: the split-K kernel writes every split's partial product into a persistent scratch ([splits, N, K] f32, plain
     stores), a second launch sums the planes in a fixed order and casts (dskd_gemm_tn_bf16).  The float-atomic flush of the
-    earlier form ran at the chip's ~1.3 TB/s atomic rate: 12 us of every launch.  One scratch per (device, stream); it must
-    exist before a hipGraph capture."""
+    earlier form ran at the chip's ~1.3 TB/s atomic rate: 12 us of every launch.  One scratch per (device, stream)."""
     _need_gpu(g2, x2)
     M, N = g2.shape
     K = x2.shape[1]
@@ -1083,12 +1126,7 @@ def gemm_tn_bf16(g2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     if need < 0:
         raise NativeError("gemm_tn_bf16: " + load().dskd_last_error().decode())
     dev = g2.device
-    key = (dev, _stream(g2))
-    ws = _tn_scratch.get(key)
-    if ws is None or ws.numel() < need:
-        if torch.cuda.is_current_stream_capturing():
-            raise NativeError("gemm_tn_bf16: the scratch must exist before a hipGraph capture (run one eager step)")
-        ws = _tn_scratch[key] = torch.empty(max(need, 32 << 20), dtype=torch.uint8, device=dev)
+    ws = _tn_ws(dev, need)
     out = torch.empty((N, K), dtype=torch.bfloat16, device=dev)
     rc = load().dskd_gemm_tn_bf16(g2.data_ptr(), x2.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), M, N, K,
                                   g2.stride(0), x2.stride(0), DTYPE_BF16, _stream(g2))
@@ -1128,6 +1166,18 @@ def conv3x3_raw(x, w, bias, res, relu, stride, out=None, gate=None):
     return out
 
 
+CONV3_WGRAD = not os.environ.get("DSKD_CONV3_WGRAD_LIB")      # A/B switch: MIOpen's weight gradient for the 3x3 convolutions
+
+
+def _dw3x3(g, x, w, stride):
+    """d(weight) of a 3x3 convolution: the split-K MFMA kernel where its shape rules hold (C, N multiples of 128: ResNet
+    stages 2-4), the library otherwise (stage 1: 64 channels)."""
+    if CONV3_WGRAD and w.dtype == torch.bfloat16 and conv3x3_wgrad_ok(g, x, stride):
+        return conv3x3_wgrad(g, x, stride)
+    return torch.ops.aten.convolution_backward(g, x, w, None, [stride] * 2, [1, 1], [1, 1], False, [0, 0], 1,
+                                               [False, True, False])[1]
+
+
 class _Conv3x3Function(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, identity, relu, stride):
@@ -1155,8 +1205,7 @@ class _Conv3x3Function(torch.autograd.Function):
                 gx = torch.ops.aten.convolution_backward(g, x, w, None, [ctx.stride] * 2, [1, 1], [1, 1], False, [0, 0], 1,
                                                          [True, False, False])[0]
         if need[1]:
-            gw = torch.ops.aten.convolution_backward(g, x, w, None, [ctx.stride] * 2, [1, 1], [1, 1], False, [0, 0], 1,
-                                                     [False, True, False])[1]
+            gw = _dw3x3(g, x, w, ctx.stride)
         if need[2]:
             gb = g.sum((0, 2, 3))
         return gx, gw, gb, (g if need[3] else None), None, None
@@ -1323,8 +1372,7 @@ class _BottleneckFunction(torch.autograd.Function):
         gemm_nt_dx_raw(g3, w3.reshape(N, P).t().contiguous(), None, y2, B * Ho * Wo, P, N, g2)
         # conv2: dW2 from the library; dY1 = conv3x3(g2, W2') masked by y1 > 0 (stride 1), the library's data gradient else
         if need[3]:
-            gw2 = torch.ops.aten.convolution_backward(g2, y1, w2, None, [s] * 2, [1, 1], [1, 1], False, [0, 0], 1,
-                                                      [False, True, False])[1]
+            gw2 = _dw3x3(g2, y1, w2, s)
         if need[4]:
             gb2 = g2.sum((0, 2, 3))
         if s == 1 and P in (64, 128, 256, 512, 1024):

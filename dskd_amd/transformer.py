@@ -369,6 +369,28 @@ class _JoinRows(torch.autograd.Function):
         return g[:ctx.n], g[ctx.n:]
 
 
+class _SplitRows(torch.autograd.Function):
+    """``(w[:n], w[n:])`` whose backward is ONE concatenation.  Autograd's own slice backward makes a zero tensor of the
+    whole shape per slice, copies the slice's gradient in and adds the two: five launches per parameter where one does (the
+    in_proj weight and bias of the decoder's MultiheadAttention: 60 launches per step)."""
+
+    @staticmethod
+    def forward(ctx, w, n):
+        ctx.n, ctx.shape = n, w.shape
+        return w[:n], w[n:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None and gb is None:
+            return None, None
+        ref = ga if ga is not None else gb
+        if ga is None:
+            ga = ref.new_zeros((ctx.n,) + tuple(ctx.shape[1:]))
+        if gb is None:
+            gb = ref.new_zeros((ctx.shape[0] - ctx.n,) + tuple(ctx.shape[1:]))
+        return torch.cat([ga, gb], 0), None
+
+
 def join_rows(a, b):
     """cat([a, b], 0) -- as a view when the two already are neighbours in memory (see :class:`_JoinRows`)."""
     if _JoinRows.adjacent(a, b):
@@ -747,16 +769,17 @@ class MultiheadAttention(nn.Module):
         w, b, wo, bo = live if live is not None else (self.attn.in_proj_weight, self.attn.in_proj_bias,
                                                       self.attn.out_proj.weight, self.attn.out_proj.bias)
         p_drop = self.attn.dropout if self.training else 0.0
-        v = tall_linear(value, w[2 * E:], b[2 * E:])
+        (w_qk, w_v), (b_qk, b_v) = _SplitRows.apply(w, 2 * E), _SplitRows.apply(b, 2 * E)
+        v = tall_linear(value, w_v, b_v)
         if query is key:
-            qk = tall_linear(query, w[:2 * E], b[:2 * E])
+            qk = tall_linear(query, w_qk, b_qk)
             if _ATTN_KERNEL and E == H * native.ATTN_HEAD_DIM and query.shape[1 if batch_first else 0] <= native.ATTN_MAX_TOKENS \
                     and native.self_attention_ok(qk, v, H):
                 # own kernels (csrc/attn.hip): q | k, v and the result stay where the projections wrote / read them
                 return tall_linear(native.self_attention(qk, v, H, p_drop, batch_first=batch_first), wo, bo)
             q, k = qk.split(E, dim=-1)
         else:
-            q, k = tall_linear(query, w[:E], b[:E]), tall_linear(key, w[E:2 * E], b[E:2 * E])
+            q, k = tall_linear(query, w_qk[:E], b_qk[:E]), tall_linear(key, w_qk[E:], b_qk[E:])
         if batch_first:         # [B, L, E] tokens: the head split is a view either way, nothing is permuted + copied on the way in
             B, L, _ = query.shape
             S = key.shape[1]

@@ -470,8 +470,8 @@ int dskd_conv3x3_dx(const void* g, const void* wt, const void* gate, void* y, in
  * Which tile runs where is a measured table (profiles/r04_gemm_big_microbench.txt): the big tiles serve the 3x3 convolutions
  * of ResNet stage 4, the 64 x 128 kernel everything else (with its epilogue through LDS -- whole 128-byte lines -- for M >= 8192).
  * dskd_gemm_nt_tune(cfg, splits): tuning hook of the microbenchmarks / tests (cfg < 0: automatic (default), 0: the small-tile
- * kernel, 1..6: a fixed big tile, 7 / 8: the small tile with the register / LDS epilogue; splits 0: automatic, 1: never,
- * > 1: forced).  Process-global; not for use while launches of another thread are in flight.
+ * kernel, 1..6: a fixed big tile, 7 / 8 / 9: the small tile with the register / LDS epilogue / LDS epilogue without the early
+ * residual + gate reads; splits 0: automatic, 1: never, > 1: forced).  Process-global; not for use while launches of another thread are in flight.
  * ------------------------------------------------------------------------- */
 int64_t dskd_gemm_nt_scratch_bytes(void);
 int dskd_gemm_nt_ws(const void* x, const void* w, const void* bias, const void* res, const void* gate, void* y, int64_t M,
@@ -496,6 +496,15 @@ int dskd_gemm_tn(const void* g, const void* x, float* c, int64_t M, int N, int K
 int64_t dskd_gemm_tn_scratch_bytes(int64_t M, int N, int K);
 int dskd_gemm_tn_bf16(const void* g, const void* x, void* out, void* scratch, int64_t scratch_bytes, int64_t M, int N, int K,
                       int ldg, int ldx, int dtype, void* stream);
+/* Weight gradient of a 3x3 convolution (padding 1, stride 1 | 2): dw[n][ky][kx][c] (bf16 = a [N, C, 3, 3] channels_last
+ * weight) = sum over the output pixels of g[pixel][n] * x[pixel shifted by the tap][c]; g [B, Ho, Wo, N] and x [B, Hi, Wi, C]
+ * channels_last bf16, Ho = (Hi - 1) / stride + 1.  The split-K kernel of dskd_gemm_tn_bf16 over a virtual [pixels, 9 C]
+ * operand (only its producers' source addresses differ): deterministic, scratch from ..._scratch_bytes (-1: bad shape).
+ * C and N multiples of 128 (ResNet stages 2-4); other shapes stay with the library.  Replaces the weight half of
+ * aten::convolution_backward for conv2 of a Bottleneck (mmdet/models/backbones/resnet.py:283-288). */
+int64_t dskd_conv3x3_wgrad_scratch_bytes(int B, int Hi, int Wi, int C, int N, int stride);
+int dskd_conv3x3_wgrad(const void* g, const void* x, void* dw, void* scratch, int64_t scratch_bytes, int B, int Hi, int Wi, int C,
+                       int N, int stride, int dtype, void* stream);
 /* dst (bf16, n elements) = src (f32); src = 0 -- the accumulator of dskd_gemm_tn handed over in the parameter's dtype and
  * left zeroed for its next use (n a multiple of 4). */
 int dskd_cvt_clear(float* src, void* dst, int64_t n, int dtype, void* stream);
@@ -520,7 +529,7 @@ int dskd_winattn_bwd(const void* qkv, const float* table, const int32_t* wtype, 
 /* ---------------------------------------------------------------------------
  * Self-attention of the decoder's object queries: dropout(softmax(q k^T * scale)) v per (image, head), 8 heads of 32
  * channels, up to 320 tokens -- the core of ext-mmcv MultiheadAttention (nn.MultiheadAttention between its input and output
- * projections; configs/deformable_detr/*_il.py:82-87, first sub-layer of each decoder layer, mmdet/models/utils/
+ * projections; configs/deformable_detr/..._il.py:82-87, first sub-layer of each decoder layer, mmdet/models/utils/
  * transformer.py:639-709) -- and its backward, one wave per 32 queries / 32 keys of an (image, head) on the matrix cores
  * (csrc/attn.hip).  bf16.  q, k, v, out and their gradients are [B, L, heads * 32] in ANY (batch, row) strides, so q | k
  * are read in place from the joint projection's [.., 2 E] rows and both token layouts ([B, L, E], [L, B, E]) need no copy:

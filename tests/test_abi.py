@@ -65,7 +65,7 @@ def test_gemm_tile_hook_and_scratch_size():
     """dskd_gemm_nt_tune refuses unknown configurations; the scratch bound covers the largest split (512 partial tiles of
     128 x 128 f32 or 256 of 256 x 128)."""
     lib = native.load()
-    assert lib.dskd_gemm_nt_tune(9, 0) == -1 and b"cfg" in lib.dskd_last_error()
+    assert lib.dskd_gemm_nt_tune(10, 0) == -1 and b"cfg" in lib.dskd_last_error()
     for cfg in (-1, 0, 1, 6, 7, 8, -1):
         assert lib.dskd_gemm_nt_tune(cfg, 0) == 0
     assert lib.dskd_gemm_nt_scratch_bytes() >= 512 * 128 * 128 * 4

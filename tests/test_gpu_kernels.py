@@ -1319,6 +1319,38 @@ def test_window_attention_vs_float_reference(nH, nW, images, shifted):
     assert _close(db, gb, 2e-2), float((db.float().cpu() - gb).abs().max()) / float(gb.abs().max())
 
 
+@pytest.mark.parametrize("B,C,N,H,W,stride", [
+    (2, 128, 128, 21, 35, 1),        # ragged last stage (1 470 pixels), borders on every side
+    (1, 256, 128, 17, 19, 2),        # stride 2, odd input: Ho = 9, Wo = 10
+    (3, 128, 256, 16, 12, 2),        # stride 2, even input (the last tap column / row falls outside on one side only)
+    (2, 256, 256, 9, 8, 1),
+    (4, 512, 512, 25, 42, 1),        # ResNet stage 4 at the benchmark's size: 36 x 4 tiles, several splits
+    (1, 128, 128, 1, 1, 1),          # one pixel: only the centre tap sees data
+])
+def test_conv3x3_weight_gradient_vs_float_reference(B, C, N, H, W, stride):
+    """dskd_conv3x3_wgrad (native.conv3x3_wgrad: the split-K MFMA kernel over a virtual [pixels, 9 C] operand) against
+    ``torch.nn.grad.conv2d_weight`` in fp32 on the CPU from the same bf16 tensors; deterministic (two calls bit-equal, whatever
+    the scratch held).  Tolerance: bf16 result of an f32 accumulation over up to 4 200 pixels, 8e-3 of the largest entry."""
+    g = torch.Generator().manual_seed(B * 100 + C + stride)
+    x = torch.randn(B, C, H, W, generator=g).bfloat16()
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    gy = torch.randn(B, N, Ho, Wo, generator=g).bfloat16()
+    ref = torch.nn.grad.conv2d_weight(x.float(), (N, C, 3, 3), gy.float(), stride=stride, padding=1)
+    cl = torch.channels_last
+    xd, gd = x.to(DEV).contiguous(memory_format=cl), gy.to(DEV).contiguous(memory_format=cl)
+    assert native.conv3x3_wgrad_ok(gd, xd, stride)
+    dw = native.conv3x3_wgrad(gd, xd, stride)
+    assert dw.shape == (N, C, 3, 3) and dw.dtype == torch.bfloat16 and dw.is_contiguous(memory_format=cl)
+    assert _close(dw, ref, 8e-3), float((dw.float().cpu() - ref).abs().max()) / float(ref.abs().max())
+    for ws in native._tn_scratch.values():
+        ws.fill_(0x7F)
+    assert torch.equal(native.conv3x3_wgrad(gd, xd, stride), dw)
+    # shapes the kernel is not built for are refused, not mis-computed
+    assert not native.conv3x3_wgrad_ok(gd[:, :64].contiguous(memory_format=cl), xd, stride)
+    assert native.load().dskd_conv3x3_wgrad_scratch_bytes(B, H, W, 64, N, stride) == -1
+    assert native.load().dskd_conv3x3_wgrad_scratch_bytes(B, H, W, C, N, 3) == -1
+
+
 def _self_attention_reference(qk, v, H, keep=None, p=0.0):
     """softmax(q k^T / sqrt(32)) (* keep / (1 - p)) @ v in fp32; qk [B, L, 2 E], v [B, L, E] -> [B, L, E]."""
     B, L, E = v.shape
@@ -1695,7 +1727,7 @@ def test_gemm_tile_configurations_agree_with_float_reference(M, N, K, conv3):
     bd, rd, gd = bias.to(DEV), res.to(DEV), gate.to(DEV)
     guard = 3.0
     try:
-        for cfg, sp in [(-1, 0), (0, 0), (7, 0), (8, 0)] + [(c, s) for c in range(1, 7) for s in (1, 3, 7)]:
+        for cfg, sp in [(-1, 0), (0, 0), (7, 0), (8, 0), (9, 0)] + [(c, s) for c in range(1, 7) for s in (1, 3, 7)]:
             assert lib.dskd_gemm_nt_tune(cfg, sp) == 0
             bn = 64 * (1, 2, 2, 4, 1, 2, 2)[cfg] if 1 <= cfg <= 6 else 64
             for form in ("fwd", "dx"):

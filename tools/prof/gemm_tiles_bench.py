@@ -3,7 +3,8 @@ cfg 1..6, with and without the split-K remainder) on every 1x1 / 3x3 convolution
 B=4, 800x1333 (bf16, channels_last): forward (bias + residual + ReLU) and the input-gradient form (gate + residual).
 Interleaved rounds in one process, random data (cdna_hip_programming.md rules 24, 25).
 Usage: python tools/prof/gemm_tiles_bench.py [auto | epi]      ("auto": only cfg 0 against the automatic choice; "epi": the
-small tile with the register epilogue (cfg 7) against the LDS epilogue (cfg 8))"""
+small tile with the register epilogue (cfg 7), the LDS epilogue (cfg 8), the LDS epilogue without the early residual / gate
+reads (cfg 9))"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -64,7 +65,7 @@ def bench(fn, variants, rounds=3, n=8):
 
 
 def report(name, flops, fn, out, tot):
-    variants = [(0, 0), (-1, 0)] if AUTO_ONLY else [(0, 0), (7, 0), (8, 0), (-1, 0)] if EPI else CFGS + [(-1, 0)]
+    variants = [(0, 0), (-1, 0)] if AUTO_ONLY else [(0, 0), (7, 0), (8, 0), (9, 0), (-1, 0)] if EPI else CFGS + [(-1, 0)]
     lib.dskd_gemm_nt_tune(0, 0)
     fn()
     ref = out.float().clone()
@@ -81,8 +82,8 @@ def report(name, flops, fn, out, tot):
     t0, ta = t[(0, 0)], t[(-1, 0)]
     cols = ""
     if EPI:
-        k = [t.get((c, 0)) for c in (7, 8)]
-        cols += " register / LDS epilogue " + " ".join("   -  " if v is None else f"{v:6.1f}" for v in k) + " |"
+        k = [t.get((c, 0)) for c in (7, 8, 9)]
+        cols += " register / LDS / LDS-no-prefetch epilogue " + " ".join("   -  " if v is None else f"{v:6.1f}" for v in k) + " |"
         tot[2] += min([v for v in k if v is not None] + [t0])
     if not AUTO_ONLY and not EPI:
         for c in range(1, 7):
