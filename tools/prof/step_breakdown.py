@@ -5,6 +5,8 @@ rows.sort(key=lambda r:int(r['Start_Timestamp']))
 naive=[i for i,r in enumerate(rows) if 'naive_conv' in r['Kernel_Name']]
 rs=rows[(max(naive)+1 if naive else 0):]
 adam=[i for i,r in enumerate(rs) if 'adam' in r['Kernel_Name'].lower()]
+if not adam:      # other optimizers (GFL: SGD with momentum through ATen's multi-tensor kernels)
+    adam=[i for i,r in enumerate(rs) if 'sgd' in r['Kernel_Name'].lower() or 'multi_tensor_apply' in r['Kernel_Name']]
 groups=[]; prev=None
 for i in adam:
     if prev is None or i-prev>50: groups.append([i])
