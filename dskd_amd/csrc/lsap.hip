@@ -265,10 +265,287 @@ __global__ __launch_bounds__(64) void lsap_kernel(const float* __restrict__ cost
   if (lane == 0) status[blockIdx.x] = 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Several waves per problem (r4): ONE COLUMN PER THREAD.  The one-wave kernel above strides its 64 lanes over the columns
+// (300 queries: 5 rounds of five LDS reads + one strided global read each, then 18 ds_bpermute steps of reduction: ~2 us per
+// scan, 477 us for 300 x 110).  Here a column's state -- v, shortest path cost, predecessor, assignment, position in the
+// `remaining` list, scanned flag -- lives in the REGISTERS of its thread, the work matrix is staged TRANSPOSED in LDS when it
+// fits (row i contiguous over the columns: one conflict-free read per scan), a wave reduces (value, tie score) with DPP row
+// operations + four v_readlane, and the waves meet in ONE barrier per scan through a double-buffered table of per-wave
+// winners.  Same arithmetic (IEEE double, same operation order), same tie rule -- the key (value, unassigned?, position) is
+// reduced lexicographically, first inside a wave, then over the waves -- so the result is the sequential solver's, bit for bit.
+struct MwCand {      // (carrying the next row's dual along as well was measured: 254 vs 241 us at 300 x 110 -- the larger entry costs more)
+  double val;
+  int score, j, r4c, pad;
+};
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+__device__ __forceinline__ double dmin(double a, double b) { return b < a ? b : a; }
+__device__ __forceinline__ double readlane_d(double v, int l) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_readlane((int)b, l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+__device__ __forceinline__ double wave_min_d(double v) {      // no NaN among the inputs (validated)
+  v = dmin(v, dpp_d<0xB1>(v));       // quad_perm [1, 0, 3, 2]
+  v = dmin(v, dpp_d<0x4E>(v));       // quad_perm [2, 3, 0, 1]
+  v = dmin(v, dpp_d<0x141>(v));      // row_half_mirror
+  v = dmin(v, dpp_d<0x140>(v));      // row_mirror: every lane of a 16-lane row holds the row's minimum
+  return dmin(dmin(readlane_d(v, 0), readlane_d(v, 16)), dmin(readlane_d(v, 32), readlane_d(v, 48)));
+}
+__device__ __forceinline__ float wave_min_f32(float v) {
+  v = fminf(v, dpp_quad_xor1(v));
+  v = fminf(v, dpp_quad_xor2(v));
+  v = fminf(v, dpp_half_mirror(v));
+  v = fminf(v, dpp_row_mirror(v));
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return fminf(fminf(r0, r1), fminf(r2, r3));
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true));
+  return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+             max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+// dynamic LDS: doubles u[nr_max], spc[nc_max] | MwCand red[2][16] | ints path[nc_max], row4col[nc_max], remaining[nc_max],
+// col4row[nr_max] | bytes SR[nr_max] (padded to 16) | floats costT[nr * nc] (LDS_COST)
+struct MwDims {
+  int nr_max, nc_max;
+};
+__host__ __device__ inline size_t mw_state_bytes(int nr_max, int nc_max) {
+  size_t b = (size_t)(nr_max + nc_max) * 8 + 2 * 16 * sizeof(MwCand) + (size_t)(3 * nc_max + nr_max) * 4;
+  b += ((size_t)nr_max + 15) / 16 * 16;
+  return (b + 15) / 16 * 16;
+}
+
+template <bool LDS_COST, int CPT>      // CPT: columns per thread (column j = t + k NT); up to 1024 columns in every form
+__global__ __launch_bounds__(CPT == 1 ? 1024 : 512) void lsap_mw_kernel(const float* __restrict__ cost_all, DescPack descs, MwDims dims,
+                                                       int64_t* __restrict__ row_out, int64_t* __restrict__ col_out,
+                                                       int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char mw_smem[];
+  double* s_u = reinterpret_cast<double*>(mw_smem);
+  double* s_spc = s_u + dims.nr_max;
+  MwCand* s_red = reinterpret_cast<MwCand*>(s_spc + dims.nc_max);
+  int* s_path = reinterpret_cast<int*>(s_red + 2 * 16);
+  int* s_row4col = s_path + dims.nc_max;
+  int* s_remaining = s_row4col + dims.nc_max;
+  int* s_col4row = s_remaining + dims.nc_max;
+  unsigned char* s_SR = reinterpret_cast<unsigned char*>(s_col4row + dims.nr_max);
+  float* s_cost = reinterpret_cast<float*>(mw_smem + mw_state_bytes(dims.nr_max, dims.nc_max));
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int NT = blockDim.x, NW = NT >> 6;
+  const ProbDesc d = descs.d[blockIdx.x];
+  const float* cost = cost_all + d.cost_off;
+  const int nr_in = d.nr, nc_in = d.nc;
+  if (nr_in == 0 || nc_in == 0) {
+    if (t == 0) status[blockIdx.x] = 0;
+    return;
+  }
+  const bool tr = nc_in < nr_in;
+  const int nr = tr ? nc_in : nr_in, nc = tr ? nr_in : nc_in;
+  const int si = tr ? 1 : nc_in, sj = tr ? nc_in : 1;          // element (i, j) of the work matrix = cost[i si + j sj]
+  int64_t* ro = row_out + d.out_off;
+  int64_t* co = col_out + d.out_off;
+
+  // validation (scipy: NaN or -inf anywhere -> invalid) + the transposed copy of the work matrix
+  int bad = 0;
+  for (int e = t; e < nr_in * nc_in; e += NT) {
+    const float c = cost[e];
+    bad |= (c != c) || (c == -INFINITY);
+    if constexpr (LDS_COST) {
+      const int a = e / nc_in, b2 = e - a * nc_in;             // source (row a, column b2)
+      const int i = tr ? b2 : a, j = tr ? a : b2;
+      s_cost[i * nc + j] = c;
+    }
+  }
+  if (__syncthreads_or(bad)) {
+    for (int k = t; k < nr; k += NT) { ro[k] = k; co[k] = k; }
+    if (t == 0) status[blockIdx.x] = DSKD_ERR_INVALID_COST;
+    return;
+  }
+  double v[CPT], spc[CPT];
+  int path[CPT], r4c[CPT], pos[CPT];
+  bool SC[CPT], mine[CPT];
+#pragma unroll
+  for (int k = 0; k < CPT; ++k) {
+    const int j = t + k * NT;
+    mine[k] = j < nc;
+    v[k] = 0.0; spc[k] = INFINITY; path[k] = -1; r4c[k] = -1; pos[k] = 0; SC[k] = false;
+    if (mine[k]) s_row4col[j] = -1;
+  }
+  for (int i = t; i < nr; i += NT) { s_u[i] = 0.0; s_col4row[i] = -1; }
+
+  for (int cur = 0; cur < nr; ++cur) {
+    double minVal = 0.0;
+    int num_remaining = nc;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+      const int j = t + k * NT;
+      if (mine[k]) s_remaining[nc - 1 - j] = j;      // remaining[it] = nc - it - 1
+      pos[k] = nc - 1 - j;
+      SC[k] = false;
+      spc[k] = INFINITY;
+    }
+    for (int i = t; i < nr; i += NT) s_SR[i] = 0;
+    __syncthreads();
+
+    int sink = -1, i = cur, par = 0;
+    while (sink == -1) {
+      if (t == 0) s_SR[i] = 1;
+      const double ui = s_u[i];
+      double cval = INFINITY;
+      int cscore = -1, cj = 0, cr4c = -1;
+      double cst[CPT];
+#pragma unroll
+      for (int k = 0; k < CPT; ++k) {
+        const int j = t + k * NT;
+        const int jj = mine[k] ? j : 0;
+        cst[k] = LDS_COST ? (double)s_cost[i * nc + jj] : (double)cost[(size_t)i * si + (size_t)jj * sj];
+      }
+#pragma unroll
+      for (int k = 0; k < CPT; ++k) {
+        if (mine[k] && !SC[k]) {
+          const double r = minVal + cst[k] - ui - v[k];
+          if (r < spc[k]) { path[k] = i; spc[k] = r; }
+          const int sc = (r4c[k] == -1) ? 4096 + pos[k] : 2047 - pos[k];
+          if (spc[k] < cval || (spc[k] == cval && sc > cscore)) { cval = spc[k]; cscore = sc; cj = t + k * NT; cr4c = r4c[k]; }
+        }
+      }
+      // Wave minimum.  Rounding to f32 is monotone, so the double minimum sits among the lanes that hold the f32 minimum:
+      // four v_min_f32 with DPP operands find those; usually it is ONE lane and its double is the minimum.  Otherwise
+      // (values closer than an f32 ulp, or real ties) the exact reduction runs over those lanes only.
+      const float c32 = (float)cval;
+      const float m32 = wave_min_f32(c32);
+      unsigned long long tie = __builtin_amdgcn_ballot_w64(c32 == m32);
+      double m;
+      if (__builtin_popcountll(tie) == 1) {               // wave-uniform
+        m = readlane_d(cval, __builtin_amdgcn_readfirstlane(__builtin_ctzll(tie)));
+      } else {
+        const double cv2 = c32 == m32 ? cval : INFINITY;
+        m = wave_min_d(cv2);
+        tie = __builtin_amdgcn_ballot_w64(cv2 == m);
+        if (__builtin_popcountll(tie) > 1) {             // several columns at the minimum: the tie score decides
+          const int bs = wave_max_i(cv2 == m ? cscore : -2);
+          tie = __builtin_amdgcn_ballot_w64(cv2 == m && cscore == bs);
+        }
+      }
+      const int wl = __builtin_amdgcn_readfirstlane(__builtin_ctzll(tie));
+      const int w_score = __builtin_amdgcn_readlane(cscore, wl), w_r4c = __builtin_amdgcn_readlane(cr4c, wl);
+      const int w_j = __builtin_amdgcn_readlane(cj, wl);
+      MwCand best = MwCand{m, w_score, w_j, w_r4c, 0};
+      if (NW > 1) {
+        if (lane == 0) s_red[par * 16 + wave] = best;
+        __syncthreads();
+        best = s_red[par * 16];
+        for (int w = 1; w < NW; ++w) {
+          const MwCand o = s_red[par * 16 + w];
+          if (o.val < best.val || (o.val == best.val && o.score > best.score)) best = o;
+        }
+        par ^= 1;
+      }
+      minVal = best.val;
+      if (minVal == INFINITY) {                           // uniform over the workgroup
+        for (int k = t; k < nr; k += NT) { ro[k] = k; co[k] = k; }
+        if (t == 0) status[blockIdx.x] = DSKD_ERR_INFEASIBLE;
+        return;
+      }
+      const int index = best.score >= 4096 ? best.score - 4096 : 2047 - best.score;
+      const int j = best.j;
+      if (best.r4c == -1) sink = j; else i = best.r4c;
+      --num_remaining;
+      // swap-remove j from `remaining` (the slot written here is read again only behind the next scan's barrier)
+      if (NW == 1) wave_lds_sync();
+      const int jl = s_remaining[num_remaining];
+#pragma unroll
+      for (int k = 0; k < CPT; ++k) {
+        if (t + k * NT == j) SC[k] = true;
+        if (t + k * NT == jl) pos[k] = index;
+      }
+      if (NW == 1) wave_lds_sync();                       // every lane has read remaining[num_remaining] before lane 0 writes
+      if (t == 0) s_remaining[index] = jl;
+    }
+
+    // dual update, then augmentation (same order as the sequential solver)
+#pragma unroll
+    for (int k = 0; k < CPT; ++k)
+      if (mine[k]) { s_spc[t + k * NT] = spc[k]; s_path[t + k * NT] = path[k]; }
+    __syncthreads();
+    for (int k = t; k < nr; k += NT)
+      if (s_SR[k] && k != cur) s_u[k] += minVal - s_spc[s_col4row[k]];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k)
+      if (mine[k] && SC[k]) v[k] -= minVal - spc[k];
+    __syncthreads();
+    if (t == 0) {
+      s_u[cur] += minVal;
+      int j = sink;
+      while (true) {
+        const int k = s_path[j];
+        s_row4col[j] = k;
+        const int tmp = s_col4row[k];
+        s_col4row[k] = j;
+        j = tmp;
+        if (k == cur) break;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CPT; ++k)
+      if (mine[k]) r4c[k] = s_row4col[t + k * NT];
+  }
+
+  if (tr) {
+    // pairs sorted by original row = col4row value (all distinct): rank by counting
+    for (int k = t; k < nr; k += NT) {
+      const int mine_c = s_col4row[k];
+      int rank = 0;
+      for (int m2 = 0; m2 < nr; ++m2) rank += s_col4row[m2] < mine_c;
+      ro[rank] = mine_c;
+      co[rank] = k;
+    }
+  } else {
+    for (int k = t; k < nr; k += NT) { ro[k] = k; co[k] = s_col4row[k]; }
+  }
+  if (t == 0) status[blockIdx.x] = 0;
+}
+
+template <bool LDS_COST, int CPT>
+static int launch_mw(int n, int threads, size_t lds, hipStream_t st, const float* cost, const DescPack& pack, MwDims dims,
+                     int64_t* row, int64_t* col, int32_t* status) {
+  static bool done[64] = {};
+  if (!reserve_lds((const void*)lsap_mw_kernel<LDS_COST, CPT>, 156 * 1024, done))
+    return fail(DSKD_ERR_LAUNCH, "dskd_lsap_batched: cannot reserve LDS");
+  hipLaunchKernelGGL((lsap_mw_kernel<LDS_COST, CPT>), dim3(n), dim3(threads), lds, st, cost, pack, dims, row, col, status);
+  return DSKD_OK;
+}
+
 }  // namespace
 }  // namespace dskd
 
 using namespace dskd;
+
+static int g_lsap_mode = 0;
+/* test / A-B hook: 0 = automatic (default), 1 = the one-wave-per-problem kernel of round 1 for every size, 2 / 3 = the
+ * register-resident kernel with 1 / 2 columns per thread */
+extern "C" int dskd_lsap_tune(int mode) {
+  if (mode < 0 || mode > 3)
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_lsap_tune: mode %d", mode);
+  g_lsap_mode = mode;
+  return DSKD_OK;
+}
 
 extern "C" int dskd_lsap_host(const float* cost, int nr, int nc, int64_t* row, int64_t* col) {
   if (nr < 0 || nc < 0) return fail(DSKD_ERR_INVALID_ARG, "dskd_lsap_host: negative size");
@@ -300,7 +577,34 @@ extern "C" int dskd_lsap_batched(const float* cost, const int32_t* nr, const int
       const int p = p0 + (k < n ? k : 0);
       pack.d[k] = ProbDesc{nr[p], nc[p], (long long)offsets[p], (long long)out_offsets[p]};
     }
-    hipLaunchKernelGGL(lsap_kernel, dim3(n), dim3(64), 0, st, cost, pack, row, col, status + p0);
+    // the work matrix of a problem has max(nr, nc) columns: more than 64 -> one column per thread, several waves per problem
+    int nc_max = 1, nr_max = 1;
+    long long elems = 0;
+    for (int k = 0; k < n; ++k) {
+      const int a = nr[p0 + k], b = nc[p0 + k];
+      nc_max = std::max(nc_max, std::max(a, b));
+      nr_max = std::max(nr_max, std::min(a, b));
+      elems = std::max(elems, (long long)a * b);
+    }
+    if (nc_max > 64 && g_lsap_mode != 1) {
+      // columns per thread: 1 (automatic) | 2 (dskd_lsap_tune(3)).  Measured at 300 x 110 (profiles/r04_lsap_several_waves.txt):
+      // 1: 236 us, 2: 233, 5: 339, 16 (one wave, no barrier at all): 632 -- the scan is bound by the dependent double-precision
+      // chain of ONE column plus the reduction, so more columns per thread only lengthen it; the 5 / 16 forms were removed
+      const int cpt = g_lsap_mode == 3 ? 2 : 1;
+      const int threads = ((nc_max + cpt - 1) / cpt + 63) / 64 * 64;
+      const MwDims dims{nr_max, nc_max};
+      const size_t state = mw_state_bytes(nr_max, nc_max), with_cost = state + (size_t)elems * sizeof(float);
+      const bool lc = with_cost <= 156 * 1024;
+      const size_t lds = lc ? with_cost : state;
+      int rc = DSKD_OK;
+#define DSKD_MW(C) (lc ? launch_mw<true, C>(n, threads, lds, st, cost, pack, dims, row, col, status + p0) \
+                       : launch_mw<false, C>(n, threads, lds, st, cost, pack, dims, row, col, status + p0))
+      rc = cpt == 1 ? DSKD_MW(1) : DSKD_MW(2);
+#undef DSKD_MW
+      if (rc) return rc;
+    } else {
+      hipLaunchKernelGGL(lsap_kernel, dim3(n), dim3(64), 0, st, cost, pack, row, col, status + p0);
+    }
     if (int rc = check_launch("dskd_lsap_batched")) return rc;
   }
   return DSKD_OK;

@@ -84,6 +84,7 @@ _SIGNATURES = {
     "dskd_gn_bwd": (C.c_int, [_vp] * 8 + [C.c_int, C.c_int, _i64, C.c_int, C.c_int, _i64, _i64, _i64, C.c_int, C.c_int, _vp]),
     "dskd_lsap_host": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "dskd_lsap_batched": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
+    "dskd_lsap_tune": (C.c_int, [C.c_int]),
     "dskd_match_cost": (C.c_int, [_vp] * 7 + [C.c_int] * 3 + [_f32] * 3 + [_vp]),
     "dskd_dense_loss_fwd": (C.c_int, [_vp] * 13 + [C.c_int] * 4 + [_f32] * 4 + [_vp]),
     "dskd_dense_loss_bwd": (C.c_int, [_vp] * 8 + [C.c_int] * 4 + [_f32] * 4 + [_vp]),

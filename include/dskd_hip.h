@@ -184,6 +184,12 @@ int dskd_lsap_host(const float* cost, int nr, int nc, int64_t* row, int64_t* col
 int dskd_lsap_batched(const float* cost, const int32_t* nr, const int32_t* nc,
                       const int64_t* offsets, int nprob, int64_t* row, int64_t* col,
                       const int64_t* out_offsets, int32_t* status, void* stream);
+/* Problems whose larger side exceeds 64 (300 queries x G boxes always does) run on the register-resident kernel: every
+ * column's state in the registers of its thread, the work matrix transposed in LDS when it fits (r4: 300 x 110 in half of
+ * the one-wave kernel's 477 us); same arithmetic and tie rule, bit-identical results.  dskd_lsap_tune(mode): 0 automatic
+ * (default), 1 the one-wave kernel of round 1 for every size, 2 / 3 = 1 / 2 columns per thread (tests and A/B runs).
+ * Process-global. */
+int dskd_lsap_tune(int mode);
 
 /* ---------------------------------------------------------------------------
  * Fused matching cost of GFLHungarianAssigner for nprob (layer, image) problems.

@@ -734,6 +734,54 @@ def test_lsap_device_bit_exact():
         assert np.array_equal(r, a[0]) and np.array_equal(c_, a[1]), (m.shape,)
 
 
+@pytest.mark.parametrize("shapes,kind", [
+    ([(300, 17)] * 24, "float"),            # the benchmark's 6 layers x 4 images
+    ([(300, 110), (300, 100), (300, 65)], "float"),
+    ([(300, 110), (300, 100), (300, 65)], "ties"),
+    ([(120, 128), (128, 120), (65, 65)], "ties"),
+    ([(300, 17), (300, 1), (1, 300), (300, 64)], "dup"),
+])
+def test_lsap_several_waves_per_problem(shapes, kind):
+    """r4: problems wider than 64 run with one column per thread on several waves (column state in registers, the work matrix
+    transposed in LDS when it fits -- these sets fit, the 300 x 310 set of test_lsap_device_bit_exact does not).  Bit-equal
+    with scipy AND with the one-wave kernel (dskd_lsap_tune(1)) on float, tie-heavy integer and duplicated-column costs."""
+    from scipy.optimize import linear_sum_assignment as sp
+    rng = np.random.default_rng(len(shapes) * 7 + len(kind))
+    mats = []
+    for nr, nc in shapes:
+        if kind == "float":
+            c = rng.random((nr, nc))
+        elif kind == "ties":
+            c = rng.integers(0, 4, size=(nr, nc))
+        else:
+            c = np.round(rng.normal(size=(nr, nc)), 1)
+            c[:, -1] = c[:, 0]
+        mats.append(c.astype(np.float32))
+    lib = native.load()
+    runs = {}
+    try:
+        for mode in (0, 1, 2, 3):       # automatic | one-wave kernel | 1 / 2 columns per thread
+            assert lib.dskd_lsap_tune(mode) == 0
+            runs[mode] = _lsap_device(mats)
+    finally:
+        lib.dskd_lsap_tune(0)
+    assert lib.dskd_lsap_tune(4) != 0
+    for p, m in enumerate(mats):
+        a = sp(m)
+        for mode, res in runs.items():
+            r, c_, st = res[p]
+            assert st == 0
+            assert np.array_equal(r, a[0]) and np.array_equal(c_, a[1]), (m.shape, mode)
+    # errors on the several-waves path: NaN / -inf anywhere, an unreachable row
+    bad = rng.random((300, 70)).astype(np.float32); bad[17, 3] = np.nan
+    ninf = rng.random((300, 70)).astype(np.float32); ninf[299, 69] = -np.inf
+    infeas = rng.random((300, 70)).astype(np.float32); infeas[:, 5] = np.inf
+    res = _lsap_device([bad, ninf, infeas, rng.random((300, 70)).astype(np.float32)])
+    assert [x[2] for x in res] == [-3, -3, -4, 0]
+    for r, c_, st in res[:3]:
+        assert (r >= 0).all() and (r < 300).all() and (c_ >= 0).all() and (c_ < 70).all()
+
+
 def test_lsap_device_errors():
     rng = np.random.default_rng(1)
     bad = rng.random((5, 7)).astype(np.float32)
