@@ -192,6 +192,17 @@ __device__ __forceinline__ void build_tables(TileTables<NT>& tt, const PullGeom&
 //   B  per queued sample: weights as in the forward, a slot in each hit cell's list (one returning LDS add),
 //      strays to the global list
 //   sort (prefix sum, place) and reduce as described at the top of the file.
+// Experiment build (-DDSKD_PULL_COMPACT): the tile kernel reads loc / attn of ITS level from a compact
+// level- and head-major copy [B][heads][Nq][4 points] (32 + 16 bytes per (query, head), neighbouring candidates in
+// neighbouring bytes) instead of the interleaved [B][Nq][heads][16] lines (128 + 64 bytes, 32 + 16 of them used) -- the
+// best case of the "level-major record" for this kernel; the copy is made by pull_compact_kernel in front of the launch.
+// Measured: profiles/r04_msda_pull_compact_ab.txt.  Not part of the product build.
+#ifdef DSKD_PULL_COMPACT
+#define DSKD_PULL_SB(b, q, h, tl, pt) (RESCAN ? ((((size_t)(b) * g.Nq + (q)) * kHeads + (h)) * (size_t)kLP + (tl) * kPts + (pt)) \
+                                             : ((((size_t)(b) * kHeads + (h)) * g.Nq + (q)) * (size_t)kPts + (pt)))
+#else
+#define DSKD_PULL_SB(b, q, h, tl, pt) ((((size_t)(b) * g.Nq + (q)) * kHeads + (h)) * (size_t)kLP + (tl) * kPts + (pt))
+#endif
 template <typename T, int NT, int R, bool RESCAN>
 __device__ __forceinline__ void pull_tile(int vb, const float* __restrict__ loc, const float* __restrict__ attn,
                                           const T* __restrict__ grad_out, float* __restrict__ grad_value,
@@ -269,7 +280,7 @@ __device__ __forceinline__ void pull_tile(int vb, const float* __restrict__ loc,
         int q, ncx, ncy;
         decode(ci, q, ncx, ncy);
         const bool home = (ncx >> g.tws) == tx && (ncy >> g.ths) == ty;
-        const size_t sb = (((size_t)b * g.Nq + q) * kHeads + h) * (size_t)kLP + tl * kPts + half * 2;
+        const size_t sb = DSKD_PULL_SB(b, q, h, tl, half * 2);
         const f32x4 l0 = *reinterpret_cast<const f32x4*>(loc + sb * 2);
         const float xs[2] = {l0.x, l0.z}, ys[2] = {l0.y, l0.w};
 #pragma unroll
@@ -340,7 +351,7 @@ __device__ __forceinline__ void pull_tile(int vb, const float* __restrict__ loc,
         const int p = ent & 3;
         int q, ncx, ncy;
         decode(cbase + (int)((ent & 0xFFFFu) >> 2), q, ncx, ncy);
-        const size_t sb = (((size_t)b * g.Nq + q) * kHeads + h) * (size_t)kLP + tl * kPts + p;
+        const size_t sb = DSKD_PULL_SB(b, q, h, tl, p);
         const f32x2 xy = *reinterpret_cast<const f32x2*>(loc + sb * 2);
         const float a = attn[sb];
         // same arithmetic as the forward: phase A accepted the location (strictly inside (-1, size))
@@ -608,6 +619,23 @@ inline bool make_pull_geom(const MsdaLevels& lg, int level, int dtype, int B, in
   return true;
 }
 
+#ifdef DSKD_PULL_COMPACT
+__global__ __launch_bounds__(256) void pull_compact_kernel(const float* __restrict__ loc, const float* __restrict__ attn,
+                                                           float* __restrict__ cloc, float* __restrict__ cattn, int B, int Nq,
+                                                           int tl) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;      // (b, q, h), h fastest: coalesced reads of 32-B pieces
+  if (i >= (long long)B * Nq * kHeads) return;
+  const int h = (int)(i % kHeads);
+  const long long bq = i / kHeads;
+  const int q = (int)(bq % Nq), b = (int)(bq / Nq);
+  const size_t src = (size_t)i * kLP + tl * kPts, dst = (((size_t)b * kHeads + h) * Nq + q) * kPts;
+  const f32x4 a = *reinterpret_cast<const f32x4*>(loc + src * 2), c = *reinterpret_cast<const f32x4*>(loc + src * 2 + 4);
+  *reinterpret_cast<f32x4*>(cloc + dst * 2) = a;
+  *reinterpret_cast<f32x4*>(cloc + dst * 2 + 4) = c;
+  *reinterpret_cast<f32x4*>(cattn + dst) = *reinterpret_cast<const f32x4*>(attn + src);
+}
+#endif
+
 template <typename T, int NT, int R>
 int launch_pull_level(const float* loc, const float* attn, const T* grad_out, float* grad_value, const PullGeom& g,
                       FbHeader* hdr, FbEntry* fb, unsigned cap, hipStream_t st) {
@@ -651,9 +679,28 @@ int launch_pull_t(const float* loc, const float* attn, const T* grad_out, float*
     const PullGeom& g = gs.g[i];
     int rc;
     const LevelPlan pl = plan_level(g.tl, dtype);
+    const float* ploc = loc;
+    const float* pattn = attn;
+#ifdef DSKD_PULL_COMPACT
+    {
+      static float* cbuf = nullptr;
+      static size_t cbytes = 0;
+      const size_t need = (size_t)B * Nq * kHeads * kPts * 3 * sizeof(float);
+      if (cbytes < need) {
+        if (cbuf) (void)hipFree(cbuf);
+        if (hipMalloc(&cbuf, need) != hipSuccess) return fail(DSKD_ERR_LAUNCH, "pull experiment: hipMalloc");
+        cbytes = need;
+      }
+      float* cloc = cbuf;
+      float* cattn = cbuf + (size_t)B * Nq * kHeads * kPts * 2;
+      const long long n = (long long)B * Nq * kHeads;
+      hipLaunchKernelGGL(pull_compact_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, loc, attn, cloc, cattn, B, Nq, g.tl);
+      ploc = cloc; pattn = cattn;
+    }
+#endif
 #define DSKD_PULL_LAUNCH(NT_)                                                                                      \
-  (pl.R == 1 ? launch_pull_level<T, NT_, 1>(loc, attn, grad_out, grad_value, g, hdr, fb, cap, st)                  \
-             : launch_pull_level<T, NT_, 4>(loc, attn, grad_out, grad_value, g, hdr, fb, cap, st))
+  (pl.R == 1 ? launch_pull_level<T, NT_, 1>(ploc, pattn, grad_out, grad_value, g, hdr, fb, cap, st)                \
+             : launch_pull_level<T, NT_, 4>(ploc, pattn, grad_out, grad_value, g, hdr, fb, cap, st))
     if (pl.nt == 1024) rc = DSKD_PULL_LAUNCH(1024);
     else if (pl.nt == 512) rc = DSKD_PULL_LAUNCH(512);
     else rc = DSKD_PULL_LAUNCH(256);
