@@ -137,6 +137,38 @@ __device__ __forceinline__ void load_vals(__amdgpu_buffer_rsrc_t rsrc, int voff,
   }
 }
 
+// Ablation builds of the FORWARD kernels (tools/prof/msda_fwd_ablation.sh, profiles/r04_msda_fwd_ablation.txt;
+// timing only, results are garbage): -DDSKD_FWD_ABLATE=1 keeps every corner load (texture path / LDS) and drops the unpack +
+// FMA work (one xor chain + one FMA per sample); =2 keeps staging + arithmetic and drops the corner loads (operands made from
+// the offsets).  0 = the product.
+#ifndef DSKD_FWD_ABLATE
+#define DSKD_FWD_ABLATE 0
+#endif
+__device__ __forceinline__ void fwd_fma4_bf16(float (&acc)[8], const u32x4& r0, const u32x4& r1, const u32x4& r2,
+                                              const u32x4& r3, const f32x4& w) {
+#if DSKD_FWD_ABLATE == 1
+  const u32x4 x = r0 ^ r1 ^ r2 ^ r3;
+  acc[0] = fmaf(w.x, as_f32((x.x ^ x.y ^ x.z ^ x.w) & 0x3FFFFFFFu), acc[0]);
+#else
+  float v0[8], v1[8], v2[8], v3[8];
+  unpack_bf16x8(r0, v0);
+  unpack_bf16x8(r1, v1);
+  unpack_bf16x8(r2, v2);
+  unpack_bf16x8(r3, v3);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    acc[i] = fmaf(w.x, v0[i], acc[i]);
+    acc[i] = fmaf(w.y, v1[i], acc[i]);
+    acc[i] = fmaf(w.z, v2[i], acc[i]);
+    acc[i] = fmaf(w.w, v3[i], acc[i]);
+  }
+#endif
+}
+__device__ __forceinline__ u32x4 fwd_fake_operand(int off) {
+  const unsigned u = (unsigned)off;
+  return u32x4{u * 0x9E3779B1u, u ^ 0x3F803F80u, u + 0x3F003F00u, ~u};
+}
+
 // Cooperative parameter pass shared by forward and backward.
 //
 // PH > 1: the samples of a query are staged and consumed in PH phases of LP / PH samples per head
@@ -302,6 +334,20 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_kernel(
       for (int s = 0; s < LPS; ++s) {
         const i32x4 o = my_off[s];
         const f32x4 w = my_wt[s];
+#if DSKD_FWD_ABLATE
+        if constexpr (sizeof(T) == 2) {
+#if DSKD_FWD_ABLATE == 2
+          fwd_fma4_bf16(acc, fwd_fake_operand(o.x + hb), fwd_fake_operand(o.y + hb), fwd_fake_operand(o.z + hb),
+                        fwd_fake_operand(o.w + hb), w);
+#else
+          fwd_fma4_bf16(acc, __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.x + hb, 0, 0)),
+                        __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.y + hb, 0, 0)),
+                        __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.z + hb, 0, 0)),
+                        __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.w + hb, 0, 0)), w);
+#endif
+          continue;
+        }
+#endif
         float v0[TR::NACC], v1[TR::NACC], v2[TR::NACC], v3[TR::NACC];
         load_vals<T>(rsrc, o.x + hb, v0);
         load_vals<T>(rsrc, o.y + hb, v1);
@@ -1341,22 +1387,16 @@ __global__ __launch_bounds__(1024) void msda_fwd_win_kernel(
         for (int sl = 0; sl < 4; ++sl) {
           const i32x4 o = s_off[ql * kFwdHS + sl];
           const f32x4 w = s_wt[ql * kFwdHS + sl];
+#if DSKD_FWD_ABLATE == 2
+          const u32x4 r0 = fwd_fake_operand(o.x + part), r1 = fwd_fake_operand(o.y + part), r2 = fwd_fake_operand(o.z + part),
+                      r3 = fwd_fake_operand(o.w + part);
+#else
           const u32x4 r0 = *reinterpret_cast<const u32x4*>(win + o.x + part * 16);
           const u32x4 r1 = *reinterpret_cast<const u32x4*>(win + o.y + part * 16);
           const u32x4 r2 = *reinterpret_cast<const u32x4*>(win + o.z + part * 16);
           const u32x4 r3 = *reinterpret_cast<const u32x4*>(win + o.w + part * 16);
-          float v0[8], v1[8], v2[8], v3[8];
-          unpack_bf16x8(r0, v0);
-          unpack_bf16x8(r1, v1);
-          unpack_bf16x8(r2, v2);
-          unpack_bf16x8(r3, v3);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            acc[i] = fmaf(w.x, v0[i], acc[i]);
-            acc[i] = fmaf(w.y, v1[i], acc[i]);
-            acc[i] = fmaf(w.z, v2[i], acc[i]);
-            acc[i] = fmaf(w.w, v3[i], acc[i]);
-          }
+#endif
+          fwd_fma4_bf16(acc, r0, r1, r2, r3, w);
         }
       } else
 #pragma unroll 2
@@ -1375,18 +1415,11 @@ __global__ __launch_bounds__(1024) void msda_fwd_win_kernel(
           r2 = *reinterpret_cast<const u32x4*>(win + o.z + part * 16);
           r3 = *reinterpret_cast<const u32x4*>(win + o.w + part * 16);
         }
-        float v0[8], v1[8], v2[8], v3[8];
-        unpack_bf16x8(r0, v0);
-        unpack_bf16x8(r1, v1);
-        unpack_bf16x8(r2, v2);
-        unpack_bf16x8(r3, v3);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          acc[i] = fmaf(w.x, v0[i], acc[i]);
-          acc[i] = fmaf(w.y, v1[i], acc[i]);
-          acc[i] = fmaf(w.z, v2[i], acc[i]);
-          acc[i] = fmaf(w.w, v3[i], acc[i]);
-        }
+#if DSKD_FWD_ABLATE == 2
+        r0 = fwd_fake_operand(o.x + part); r1 = fwd_fake_operand(o.y + part); r2 = fwd_fake_operand(o.z + part);
+        r3 = fwd_fake_operand(o.w + part);
+#endif
+        fwd_fma4_bf16(acc, r0, r1, r2, r3, w);
       }
       wave_lds_sync();   // the next level's staging overwrites the slots
     }
