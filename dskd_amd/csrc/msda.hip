@@ -169,6 +169,32 @@ __device__ __forceinline__ u32x4 fwd_fake_operand(int off) {
   return u32x4{u * 0x9E3779B1u, u ^ 0x3F803F80u, u + 0x3F003F00u, ~u};
 }
 
+// r4: the dot product of a corner's 8 bf16 channels with the 8 bf16 channels of grad_out as four v_dot2c_f32_bf16 (bf16 x bf16
+// products are exact in f32; f32 accumulation) instead of 16 unpack + 8 FMA instructions: the gather kernels of the backward
+// are bound by their vector instruction stream (profiles/r04_msda_fwd_ablation.txt shows it for the forward's same loop), and the
+// four corners of a sample were 48-64 of their ~110 instructions per sample and lane.  The forward cannot use it (its weights
+// are f32).  Both gather kernels use this helper, so they stay bit-identical to each other.
+// Inline asm, not __builtin_amdgcn_fdot2_f32_bf16: with the builtin on bit-cast vector elements this compiler (ROCm 7.2
+// clang) emitted all four instructions on the FIRST element pair (found by the oracle tests; isolated in a 20-line kernel).
+__device__ __forceinline__ float dot8_bf16(const u32x4& v, const u32x4& g) {
+  // (starting the chain with the VOP3P form "v_dot2_f32_bf16 d, a, b, 0" to save the zeroing move gave WRONG sums in 2 % of
+  // the entries: inline asm is opaque to the compiler's hazard recognizer and the VOP3P -> VOP2 accumulator hand-over is not
+  // forwarded like dot2c -> dot2c is.  Four dot2c on one accumulator are what the oracle tests pass with.)
+  float d = 0.f;
+  asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(d) : "v"(v.x), "v"(g.x));
+  asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(d) : "v"(v.y), "v"(g.y));
+  asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(d) : "v"(v.z), "v"(g.z));
+  asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(d) : "v"(v.w), "v"(g.w));
+  return d;
+}
+
+// A DOT result read by a non-DOT instruction needs 3 wait states (LLVM's hazard recognizer inserts them for instructions it
+// sees; an asm block it does not): one s_nop behind the four chains of a sample, tied to the values so that it stays between
+// the dot products and their first use.
+__device__ __forceinline__ void dot8_settle(float& a, float& b, float& c, float& d) {
+  asm volatile("s_nop 2" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+
 // Cooperative parameter pass shared by forward and backward.
 //
 // PH > 1: the samples of a query are staged and consumed in PH phases of LP / PH samples per head
@@ -435,6 +461,7 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_kernel(
     const int q = q0 + qs;
     const bool qv = q < q_end;
     float go[TR::NACC];
+    u32x4 go_pk = u32x4{0u, 0u, 0u, 0u};      // bf16: the packed slice for the dot products
     {
       const int qc = qv ? q : q_end - 1;
       const T* grow = grad_out + ((size_t)b * Nq + qc) * (kHeads * kCh) + h * kCh;
@@ -442,8 +469,8 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_kernel(
         const f32x4 t = *reinterpret_cast<const f32x4*>(grow + part * 4);
         go[0] = t.x; go[1] = t.y; go[2] = t.z; go[3] = t.w;
       } else {
-        const u32x4 t = *reinterpret_cast<const u32x4*>(grow + part * 8);
-        unpack_bf16x8(t, go);
+        go_pk = *reinterpret_cast<const u32x4*>(grow + part * 8);
+        unpack_bf16x8(go_pk, go);
       }
     }
 #pragma unroll 1
@@ -454,18 +481,27 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_kernel(
       for (int s = 0; s < LPS; ++s) {
         const i32x4 o = s_off[myslot + s];
         const f32x4 ax = s_aux[myslot + s];
-        float v0[TR::NACC], v1[TR::NACC], v2[TR::NACC], v3[TR::NACC];
-        load_vals<T>(rsrc, o.x + hb, v0);
-        load_vals<T>(rsrc, o.y + hb, v1);
-        load_vals<T>(rsrc, o.z + hb, v2);
-        load_vals<T>(rsrc, o.w + hb, v3);
         float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+        if constexpr (sizeof(T) == 2) {
+          const u32x4 r0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.x + hb, 0, 0));
+          const u32x4 r1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.y + hb, 0, 0));
+          const u32x4 r2 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.z + hb, 0, 0));
+          const u32x4 r3 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.w + hb, 0, 0));
+          d0 = dot8_bf16(r0, go_pk); d1 = dot8_bf16(r1, go_pk); d2 = dot8_bf16(r2, go_pk); d3 = dot8_bf16(r3, go_pk);
+          dot8_settle(d0, d1, d2, d3);
+        } else {
+          float v0[TR::NACC], v1[TR::NACC], v2[TR::NACC], v3[TR::NACC];
+          load_vals<T>(rsrc, o.x + hb, v0);
+          load_vals<T>(rsrc, o.y + hb, v1);
+          load_vals<T>(rsrc, o.z + hb, v2);
+          load_vals<T>(rsrc, o.w + hb, v3);
 #pragma unroll
-        for (int i = 0; i < TR::NACC; ++i) {
-          d0 = fmaf(v0[i], go[i], d0);
-          d1 = fmaf(v1[i], go[i], d1);
-          d2 = fmaf(v2[i], go[i], d2);
-          d3 = fmaf(v3[i], go[i], d3);
+          for (int i = 0; i < TR::NACC; ++i) {
+            d0 = fmaf(v0[i], go[i], d0);
+            d1 = fmaf(v1[i], go[i], d1);
+            d2 = fmaf(v2[i], go[i], d2);
+            d3 = fmaf(v3[i], go[i], d3);
+          }
         }
         if constexpr (TR::LPH == 8) {
           d0 = group8_sum(d0); d1 = group8_sum(d1); d2 = group8_sum(d2); d3 = group8_sum(d3);
@@ -1649,8 +1685,7 @@ __global__ __launch_bounds__(1024) void msda_bwd_win_kernel(
     float c_a[kMaxLevels];
 #pragma unroll
     for (int l = 0; l < kMaxLevels; ++l) { c_xy[l] = n_xy[l]; c_a[l] = n_a[l]; }
-    float go[8];
-    unpack_bf16x8(n_go, go);
+    const u32x4 c_go = n_go;          // this pass's grad_out slice, packed (the dot products read it as it is)
     if (qg >= 0) {
       // |bf16| compares like its bit pattern: the max over the 8 packed channels without unpacking them
       const unsigned ax = n_go.x & 0x7FFF7FFFu, ay = n_go.y & 0x7FFF7FFFu, az = n_go.z & 0x7FFF7FFFu, aw = n_go.w & 0x7FFF7FFFu;
@@ -1719,19 +1754,8 @@ __global__ __launch_bounds__(1024) void msda_bwd_win_kernel(
           r2 = *reinterpret_cast<const u32x4*>(win + o.z + part * 16);
           r3 = *reinterpret_cast<const u32x4*>(win + o.w + part * 16);
         }
-        float v0[8], v1[8], v2[8], v3[8];
-        unpack_bf16x8(r0, v0);
-        unpack_bf16x8(r1, v1);
-        unpack_bf16x8(r2, v2);
-        unpack_bf16x8(r3, v3);
-        float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          d0 = fmaf(v0[i], go[i], d0);
-          d1 = fmaf(v1[i], go[i], d1);
-          d2 = fmaf(v2[i], go[i], d2);
-          d3 = fmaf(v3[i], go[i], d3);
-        }
+        float d0 = dot8_bf16(r0, c_go), d1 = dot8_bf16(r1, c_go), d2 = dot8_bf16(r2, c_go), d3 = dot8_bf16(r3, c_go);
+        dot8_settle(d0, d1, d2, d3);
         d0 = group4_sum(d0); d1 = group4_sum(d1); d2 = group4_sum(d2); d3 = group4_sum(d3);
         if (part == sl) {           // one lane of the group finishes the sample (as msda_bwd_kernel)
           const f32x4 ax = s_aux[ql * kFwdHS + sl];
