@@ -389,8 +389,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    cdev = torch.device("cpu") if rehearse else device      # small collectives: host tensors over gloo (dist.all_reduce_sum)
+
     def all_ok(flag):
-        t = torch.tensor([1 if flag else 0], device=device)
+        t = torch.tensor([1 if flag else 0], device=cdev)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(t.item())
@@ -507,8 +509,8 @@ def main():
         except Exception as e:  # noqa: BLE001  (a diagnostic, never a reason to lose the bench line)
             print(f"[bench] mfma probe failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
 
-    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-    nranks = torch.ones(1, device=device)          # counted over the same backend the gradients travel on
+    tmax = torch.tensor([dt], device=cdev, dtype=torch.float64)
+    nranks = torch.ones(1, device=cdev)            # counted over the same backend the gradients travel on
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(nranks)

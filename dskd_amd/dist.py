@@ -61,12 +61,25 @@ def init_dist(launcher="pytorch", backend="nccl", **kwargs):
     dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
 
 
+def all_reduce_sum(tensor, async_op=False):
+    """``dist.all_reduce(tensor, SUM)``.  GPU tensors over the gloo backend (the shared-GPU rehearsal of the multi-rank path,
+    never a production layout) are staged through the host: gloo's own device path faulted intermittently on this image when
+    two ranks drove one GPU (r4: 'Memory access fault ... write access to a read-only page' inside its reduction, with
+    torch DDP as well as with GradSync); its host path is what the CPU tests exercise.  Returns the work handle or None."""
+    if tensor.is_cuda and dist.get_backend() == "gloo":
+        host = tensor.detach().cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        tensor.copy_(host)
+        return None
+    return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, async_op=async_op)
+
+
 def reduce_mean(tensor):
     """dist_utils.py:68-74."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return tensor
     tensor = tensor.clone()
-    dist.all_reduce(tensor.div_(dist.get_world_size()), op=dist.ReduceOp.SUM)
+    all_reduce_sum(tensor.div_(dist.get_world_size()))
     return tensor
 
 
@@ -74,7 +87,7 @@ def allreduce_scalars(values):
     """Mean over ranks of a list of 0-dim tensors with ONE collective; returns a 1-D tensor."""
     flat = torch.stack([v.detach().float().reshape(()) for v in values])
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(flat.div_(dist.get_world_size()))
+        all_reduce_sum(flat.div_(dist.get_world_size()))
     return flat
 
 
@@ -139,8 +152,14 @@ class GradSync:
         self.overlap = overlap
         if self.world > 1:                       # what DDP's constructor does: rank 0's parameters and buffers everywhere
             with torch.no_grad():
+                stage = dist.get_backend() == "gloo"          # see all_reduce_sum
                 for t in list(model.parameters()) + list(model.buffers()):
-                    dist.broadcast(t.data, 0)
+                    if stage and t.is_cuda:
+                        host = t.data.cpu()
+                        dist.broadcast(host, 0)
+                        t.data.copy_(host)
+                    else:
+                        dist.broadcast(t.data, 0)
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad and not n.endswith("prototype.weight")]
         self.params = [p for _, p in reversed(named)]
         self.buckets, self.handles = [], []
@@ -201,8 +220,10 @@ class GradSync:
         for p in b["params"]:
             p.grad = self.views[p]
         if self.comm:
-            op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-            b["work"] = dist.all_reduce(self.flat[b["lo"]:b["hi"]], op=op, async_op=True)
+            if self._avg:
+                b["work"] = dist.all_reduce(self.flat[b["lo"]:b["hi"]], op=dist.ReduceOp.AVG, async_op=True)
+            else:
+                b["work"] = all_reduce_sum(self.flat[b["lo"]:b["hi"]], async_op=True)
         b["done"] = True
 
     @torch.no_grad()
