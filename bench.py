@@ -538,9 +538,8 @@ def main():
             # launch shape (profiles/r01_msda_pmc_hbm_B4_bf16.json: FETCH_SIZE doubled per the
             # gfx950 correction + WRITE_SIZE), valid for the default B=4 bf16 workload only.
             traffic = traffic_detail = None
-            pmc = os.path.join(ROOT, "profiles", "r03_msda_pmc_hbm_B4_bf16.json")
-            if not os.path.exists(pmc):
-                pmc = os.path.join(ROOT, "profiles", "r01_msda_pmc_hbm_B4_bf16.json")
+            pmc = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_msda_pmc_hbm_B4_bf16.json") for r in (4, 3, 1))
+                        if os.path.exists(q)), "")          # the newest committed PMC pass (tools/prof/msda_pmc.sh)
             if args.batch == 4 and args.dtype == "bf16" and os.path.exists(pmc):
                 with open(pmc) as f:
                     t_mb = json.load(f).get("traffic_corrected_MB", {}).get(dom)
