@@ -177,14 +177,14 @@ __device__ __forceinline__ u32x4 fwd_fake_operand(int off) {
 // Inline asm, not __builtin_amdgcn_fdot2_f32_bf16: with the builtin on bit-cast vector elements this compiler (ROCm 7.2
 // clang) emitted all four instructions on the FIRST element pair (found by the oracle tests; isolated in a 20-line kernel).
 __device__ __forceinline__ float dot8_bf16(const u32x4& v, const u32x4& g) {
-  // (starting the chain with the VOP3P form "v_dot2_f32_bf16 d, a, b, 0" to save the zeroing move gave WRONG sums in 2 % of
-  // the entries: inline asm is opaque to the compiler's hazard recognizer and the VOP3P -> VOP2 accumulator hand-over is not
-  // forwarded like dot2c -> dot2c is.  Four dot2c on one accumulator are what the oracle tests pass with.)
-  float d = 0.f;
-  asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(d) : "v"(v.x), "v"(g.x));
-  asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(d) : "v"(v.y), "v"(g.y));
-  asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(d) : "v"(v.z), "v"(g.z));
-  asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(d) : "v"(v.w), "v"(g.w));
+  // All four links are the VOP3P form (the first with the constant 0 as its addend: no zeroing move).  Mixing the forms --
+  // VOP3P first, then three VOP2 v_dot2c -- gave WRONG sums in 2 % of the entries: inline asm is opaque to the compiler's hazard
+  // recognizer and a DOT result handed to a DIFFERENT opcode is not forwarded; same-opcode chains are (oracle tests).
+  float d;
+  asm("v_dot2_f32_bf16 %0, %1, %2, 0" : "=v"(d) : "v"(v.x), "v"(g.x));
+  asm("v_dot2_f32_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(v.y), "v"(g.y));
+  asm("v_dot2_f32_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(v.z), "v"(g.z));
+  asm("v_dot2_f32_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(v.w), "v"(g.w));
   return d;
 }
 
@@ -1739,34 +1739,47 @@ __global__ __launch_bounds__(1024) void msda_bwd_win_kernel(
       const i32x4 lt = s_tab[4 * lvl + 1];
       const float Wf = (float)lt.z, Hf = (float)lt.w;
       // ---- consume: lane = (query, 16-B part)
-#pragma unroll 4      // all 16 corner loads of a level in flight (2: 249 us, 4: 238 us; the forward spills at 4)
-      for (int sl = 0; sl < 4; ++sl) {
+      // r4: the corner loads of sample sl + 1 are requested BEFORE sample sl is consumed (the ISA of the plain loop had each
+      // sample issue its four loads and wait for them on the spot -- the lane branch between the LDS and the buffer path kept
+      // the compiler from hoisting them: one LDS / L2 latency per sample and wave).
+      auto fetch4 = [&](int sl, u32x4& a0, u32x4& a1, u32x4& a2, u32x4& a3) {
         const i32x4 o = s_off[ql * kFwdHS + sl];
-        u32x4 r0, r1, r2, r3;
         if (o.x < 0) {
-          r0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (o.x & 0x7FFFFFFF) + hb, 0, 0));
-          r1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (o.y & 0x7FFFFFFF) + hb, 0, 0));
-          r2 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (o.z & 0x7FFFFFFF) + hb, 0, 0));
-          r3 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (o.w & 0x7FFFFFFF) + hb, 0, 0));
+          a0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (o.x & 0x7FFFFFFF) + hb, 0, 0));
+          a1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (o.y & 0x7FFFFFFF) + hb, 0, 0));
+          a2 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (o.z & 0x7FFFFFFF) + hb, 0, 0));
+          a3 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (o.w & 0x7FFFFFFF) + hb, 0, 0));
         } else {
-          r0 = *reinterpret_cast<const u32x4*>(win + o.x + part * 16);
-          r1 = *reinterpret_cast<const u32x4*>(win + o.y + part * 16);
-          r2 = *reinterpret_cast<const u32x4*>(win + o.z + part * 16);
-          r3 = *reinterpret_cast<const u32x4*>(win + o.w + part * 16);
+          a0 = *reinterpret_cast<const u32x4*>(win + o.x + part * 16);
+          a1 = *reinterpret_cast<const u32x4*>(win + o.y + part * 16);
+          a2 = *reinterpret_cast<const u32x4*>(win + o.z + part * 16);
+          a3 = *reinterpret_cast<const u32x4*>(win + o.w + part * 16);
         }
+      };
+      u32x4 n0, n1, n2, n3;
+      fetch4(0, n0, n1, n2, n3);
+      float k0 = 0.f, k1 = 0.f, k2 = 0.f, k3 = 0.f;
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl) {
+        const u32x4 r0 = n0, r1 = n1, r2 = n2, r3 = n3;
+        if (sl < 3) fetch4(sl + 1, n0, n1, n2, n3);
         float d0 = dot8_bf16(r0, c_go), d1 = dot8_bf16(r1, c_go), d2 = dot8_bf16(r2, c_go), d3 = dot8_bf16(r3, c_go);
         dot8_settle(d0, d1, d2, d3);
         d0 = group4_sum(d0); d1 = group4_sum(d1); d2 = group4_sum(d2); d3 = group4_sum(d3);
-        if (part == sl) {           // one lane of the group finishes the sample (as msda_bwd_kernel)
-          const f32x4 ax = s_aux[ql * kFwdHS + sl];
-          const float lx = ax.x, ly = ax.y, a = ax.z;
-          const float hx = 1.f - lx, hy = 1.f - ly;
-          const float ga = (hy * hx) * d0 + (hy * lx) * d1 + (ly * hx) * d2 + (ly * lx) * d3;
-          const float gx = Wf * a * (hy * (d1 - d0) + ly * (d3 - d2));
-          const float gy = Hf * a * (hx * (d2 - d0) + lx * (d3 - d1));
-          s_gl[ql * LP + lvl * 4 + sl] = f32x2{gx, gy};
-          s_ga[ql * LP + lvl * 4 + sl] = ga;
-        }
+        // lane `part` of the group keeps the sums of sample `part` and finishes it ONCE behind the loop (r4: the ~25
+        // instructions of the finishing arithmetic ran on all four lanes for every sample, three of them for nothing --
+        // the kernel is bound by its vector instruction count, not by the gathers)
+        if (part == sl) { k0 = d0; k1 = d1; k2 = d2; k3 = d3; }
+      }
+      {
+        const f32x4 ax = s_aux[ql * kFwdHS + part];
+        const float lx = ax.x, ly = ax.y, a = ax.z;
+        const float hx = 1.f - lx, hy = 1.f - ly;
+        const float ga = (hy * hx) * k0 + (hy * lx) * k1 + (ly * hx) * k2 + (ly * lx) * k3;
+        const float gx = Wf * a * (hy * (k1 - k0) + ly * (k3 - k2));
+        const float gy = Hf * a * (hx * (k2 - k0) + lx * (k3 - k1));
+        s_gl[ql * LP + lvl * 4 + part] = f32x2{gx, gy};
+        s_ga[ql * LP + lvl * 4 + part] = ga;
       }
       wave_lds_sync();   // the next level's staging overwrites the slots
     }
