@@ -610,6 +610,10 @@ class GFLDeformableDETRHead_il(nn.Module):
                 hs_student, labels[-1], prev_mask, hs_teacher, teacher_info["pred_keepid"], teacher_labels_all,
                 len(task_labels["prev"]), float(self.loss_corr.loss_weight))
 
+        # per-layer scalars through unbind (ONE stack per loss vector in the backward) instead of 24 selects, each of which
+        # comes back as a zero fill + an accumulate into a [nl] tensor
+        losses_cls, losses_bbox, losses_iou, losses_dfl = (t.unbind(0) if torch.is_tensor(t) and t.dim() == 1 else t
+                                                           for t in (losses_cls, losses_bbox, losses_iou, losses_dfl))
         loss_dict["loss_cls"] = losses_cls[-1]
         loss_dict["loss_bbox"] = losses_bbox[-1]
         loss_dict["loss_iou"] = losses_iou[-1]
