@@ -201,12 +201,17 @@ class Bottleneck(nn.Module):
         live = [c.__dict__.get("_folded_live") for c in convs]
         if any(l is None for l in live):
             return None
-        (w1, b1), (w2, b2), (w3, b3) = live[:3]
-        wd, bd = live[3] if self.downsample is not None else (None, None)
+        (w1, b1), (w2, b2), (w3, b3) = (l[:2] for l in live[:3])
+        wd, bd = live[3][:2] if self.downsample is not None else (None, None)
         down = self.downsample[0] if self.downsample is not None else None
         if not native.bottleneck_ok(x, w1, w2, w3, wd, self.conv1, self.conv2, self.conv3, down):
             return None
-        return native.bottleneck(x, w1, b1, w2, b2, w3, b3, wd, bd, self.conv2.stride[0], self.input_is_relu)
+        # the operands of the input-gradient launches, made for the whole stage in one launch (ResNet._fold_trainable)
+        wts = [l[2] if len(l) > 2 else None for l in live[:3]] + [live[3][2] if (self.downsample is not None and len(live[3]) > 2)
+                                                                   else None]
+        if self.conv2.stride[0] != 1:
+            wts[1] = None             # stride-2 conv2: its input gradient comes from the library
+        return native.bottleneck(x, w1, b1, w2, b2, w3, b3, wd, bd, self.conv2.stride[0], self.input_is_relu, wts=wts)
 
     def forward(self, x):
         out = self._fused(x)
@@ -366,8 +371,13 @@ class ResNet(nn.Module):
         for st in sorted({p[2] for p in pairs}):
             idx = [i for i, p in enumerate(pairs) if p[2] == st]
             ws = _FoldTrainable.apply([scales[i] for i in idx], dtype, tables.get(st), *[pairs[i][0].weight for i in idx])
-            for i, w in zip(idx, ws):
-                pairs[i][0].__dict__["_folded_live"] = (w, biases[i])
+            wts = [None] * len(ws)
+            if x.is_cuda and torch.is_grad_enabled() and _CONV1X1_MFMA and ws[0].dtype == torch.bfloat16:
+                tr = self.__dict__.setdefault("_fold_wt", {}).setdefault(st, native.WeightTransposes())
+                with torch.no_grad():
+                    wts = tr.run([w.detach() for w in ws])
+            for i, w, wt in zip(idx, ws, wts):
+                pairs[i][0].__dict__["_folded_live"] = (w, biases[i], wt)
         return [c for c, _, _ in pairs]
 
     def forward(self, x):

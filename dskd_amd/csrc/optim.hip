@@ -168,6 +168,48 @@ __global__ __launch_bounds__(256) void cast_scale_many_kernel(const long long* _
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The weights the INPUT-GRADIENT launches of a trainable ResNet stage read, for all of its convolutions in one launch:
+// dst[k][taps - 1 - t][n] = src[n][t][k]  (bf16; src = a [N, K, 1, 1] or channels_last [N, K, 3, 3] weight as it lies in memory,
+// taps = 1 | 9) -- the plain transpose of a 1x1 weight (dX = dY W) and the tap-flipped, channel-swapped 3x3 weight
+// (dX = conv3x3(dY, W')).  Before r4 every Bottleneck's backward made its three or four copies itself (flip + strided copy:
+// ~75 launches of 4-5 us per step on the backward's launch chain).  Table rows {src, dst, N, K, taps}; block b of tensor i
+// (first[i] <= b < first[i + 1]) turns one 64 x 64 tile of one tap through LDS (128-byte rows in, 128-byte rows out).
+__global__ __launch_bounds__(256) void weight_t_many_kernel(const long long* __restrict__ table, const int* __restrict__ first,
+                                                            int n) {
+  __shared__ __bf16 tile[64][64 + 2];
+  const int b = blockIdx.x;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (first[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  const long long* row = table + 5ll * lo;
+  const __bf16* src = reinterpret_cast<const __bf16*>(row[0]);
+  __bf16* dst = reinterpret_cast<__bf16*>(row[1]);
+  const int N = (int)row[2], K = (int)row[3], taps = (int)row[4];
+  int lb = b - first[lo];
+  const int tk = lb % (K >> 6); lb /= (K >> 6);
+  const int tn = lb % (N >> 6);
+  const int t = lb / (N >> 6);
+  const int r = threadIdx.x >> 2, part = threadIdx.x & 3;
+  {
+    const __bf16* sp = src + ((long long)(tn * 64 + r) * taps + t) * K + tk * 64 + part * 16;
+    const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(sp), c = *reinterpret_cast<const bf16x8_t*>(sp + 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { tile[r][part * 16 + j] = a[j]; tile[r][part * 16 + 8 + j] = c[j]; }
+  }
+  __syncthreads();
+  {
+    bf16x8_t a, c;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a[j] = tile[part * 16 + j][r]; c[j] = tile[part * 16 + 8 + j][r]; }
+    __bf16* dp = dst + ((long long)(tk * 64 + r) * taps + (taps - 1 - t)) * N + tn * 64 + part * 16;
+    *reinterpret_cast<bf16x8_t*>(dp) = a;
+    *reinterpret_cast<bf16x8_t*>(dp + 8) = c;
+  }
+}
+
 extern "C" int dskd_clip_adamw_chunk(void) { return kChunk; }
 
 extern "C" int dskd_clip_adamw(const int64_t* ptrs, const int32_t* meta, const int32_t* chunks, float* partials,
@@ -197,6 +239,17 @@ extern "C" int dskd_clip_adamw(const int64_t* ptrs, const int32_t* meta, const i
 }
 
 extern "C" int dskd_cast_scale_chunk(void) { return kCastChunk; }
+
+extern "C" int dskd_weight_t_many(const int64_t* table, const int32_t* first, int n, int total_blocks, int dtype, void* stream) {
+  if (dtype != DSKD_DTYPE_BF16) return fail(DSKD_ERR_INVALID_ARG, "dskd_weight_t_many: bf16 only");
+  if (n < 0 || total_blocks < 0) return fail(DSKD_ERR_INVALID_ARG, "dskd_weight_t_many: bad argument (n=%d blocks=%d)", n, total_blocks);
+  if (n == 0 || total_blocks == 0) return DSKD_OK;
+  if (!table || !first || (reinterpret_cast<uintptr_t>(table) & 7) || (reinterpret_cast<uintptr_t>(first) & 3))
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_weight_t_many: null / misaligned table");
+  hipLaunchKernelGGL(weight_t_many_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const long long*>(table), first, n);
+  return check_launch("dskd_weight_t_many");
+}
 
 extern "C" int dskd_cast_scale_many(const int64_t* table, const int32_t* first, int n, int total_chunks, int direction,
                                     void* stream) {

@@ -72,6 +72,7 @@ _SIGNATURES = {
     "dskd_winattn_bwd": (C.c_int, [_vp] * 6 + [C.c_int] * 5 + [_f32, C.c_int, _vp]),
     "dskd_conv3x3_wgrad_scratch_bytes": (C.c_int64, [C.c_int] * 6),
     "dskd_conv3x3_wgrad": (C.c_int, [_vp] * 4 + [C.c_int64] + [C.c_int] * 7 + [_vp]),
+    "dskd_weight_t_many": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_attn_fwd": (C.c_int, [_vp] * 5 + [C.c_int] * 4 + [_vp, _f32, _f32, C.c_uint64, C.c_uint64, _vp, C.c_int, _vp]),
     "dskd_attn_bwd": (C.c_int, [_vp] * 10 + [C.c_int] * 4 + [_vp, _f32, _f32, C.c_uint64, C.c_uint64, _vp, C.c_int, _vp]),
     "dskd_clip_adamw_chunk": (C.c_int, []),
@@ -1289,6 +1290,56 @@ class MultiCast:
                                            _stream(srcs[0])), "dskd_cast_scale_many")
 
 
+class WeightTransposes:
+    """``dskd_weight_t_many`` for a fixed list of convolution weights (one ResNet stage): the operands of the input-gradient
+    launches -- ``w.t()`` of a 1x1 weight, ``w.flip(2, 3).transpose(0, 1)`` (channels_last) of a 3x3 one -- in ONE launch per
+    step instead of a flip + a strided copy per convolution in every Bottleneck's backward.  The device table is rebuilt only
+    when an address changes; not used inside a stream capture whose addresses it has not seen."""
+
+    def __init__(self):
+        self.key, self.table, self.first, self.n, self.blocks = None, None, None, 0, 0
+
+    @staticmethod
+    def eligible(w) -> bool:
+        if not (w.is_cuda and w.dtype == torch.bfloat16 and w.dim() == 4 and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0
+                and w.data_ptr() % 16 == 0):
+            return False
+        if tuple(w.shape[2:]) == (1, 1):
+            return w.stride(1) == 1 and w.stride(0) == w.shape[1]
+        return tuple(w.shape[2:]) == (3, 3) and w.is_contiguous(memory_format=torch.channels_last)
+
+    def run(self, ws):
+        """[transposed weight | None] per entry of ``ws``: [K, N] for 1x1, [K, N, 3, 3] channels_last for 3x3."""
+        idx = [i for i, w in enumerate(ws) if self.eligible(w)]
+        outs = [None] * len(ws)
+        if not idx:
+            return outs
+        for i in idx:
+            w = ws[i]
+            N, K = w.shape[0], w.shape[1]
+            outs[i] = torch.empty((K, N), dtype=w.dtype, device=w.device) if w.shape[2] == 1 else \
+                torch.empty((K, N, 3, 3), dtype=w.dtype, device=w.device).contiguous(memory_format=torch.channels_last)
+        key = tuple((ws[i].data_ptr(), outs[i].data_ptr(), tuple(ws[i].shape)) for i in idx)
+        if key != self.key:
+            if torch.cuda.is_current_stream_capturing():
+                return [None] * len(ws)               # the callers make their own copies (capturable)
+            rows, first = [], [0]
+            for i in idx:
+                N, K, taps = ws[i].shape[0], ws[i].shape[1], ws[i].shape[2] * ws[i].shape[3]
+                rows += [ws[i].data_ptr(), outs[i].data_ptr(), N, K, taps]
+                first.append(first[-1] + taps * (N // 64) * (K // 64))
+            t_host = torch.tensor(rows + first, dtype=torch.int64).pin_memory()
+            dev = ws[idx[0]].device
+            self.table = torch.empty(t_host.numel(), dtype=torch.int64, device=dev)
+            self.first = torch.empty(len(first), dtype=torch.int32, device=dev)
+            self.table.copy_(t_host, non_blocking=True)
+            self.first.copy_(self.table[len(rows):], non_blocking=True)
+            self.key, self.n, self.blocks = key, len(idx), first[-1]
+        _check(load().dskd_weight_t_many(self.table.data_ptr(), self.first.data_ptr(), self.n, self.blocks, DTYPE_BF16,
+                                         _stream(ws[idx[0]])), "dskd_weight_t_many")
+        return outs
+
+
 # --------------------------------------------------------------------------- a whole Bottleneck, backward fused
 def gemm_nt_dx_raw(g, wt2d, res, gate, M, N, K, out):
     """``out[M, N] = (gate > 0) ? g[M, K] wt2d[N, K]^T + res : 0`` -- the input-gradient form of dskd_gemm_nt_ws."""
@@ -1328,7 +1379,9 @@ class _BottleneckFunction(torch.autograd.Function):
     place, keeping the Python object): the version counter in the tag catches that, the sum is masked again."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, w3, b3, wd, bd, stride, dstride, x_is_relu):
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, wd, bd, stride, dstride, x_is_relu, wts=None):
+        """``wts``: (w1^T, w2 flipped / channel-swapped, w3^T, wd^T) made for the whole stage by :class:`WeightTransposes`
+        (entries may be None: the backward then makes its own copy)."""
         B, Cin, H, W = x.shape
         P, N = w1.shape[0], w3.shape[0]
         y1 = torch.empty((B, P, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
@@ -1344,12 +1397,14 @@ class _BottleneckFunction(torch.autograd.Function):
         y = torch.empty((B, N, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         gemm_nt_raw(y2, w3, b3, idn, B * Ho * Wo, N, P, True, y)
         ctx.stride, ctx.dstride, ctx.x_is_relu, ctx.has_down = stride, dstride, x_is_relu, wd is not None
+        ctx.wts = tuple(wts) if wts is not None else (None, None, None, None)
         ctx.save_for_backward(x, y1, y2, y, w1, w2, w3, wd)
         return y
 
     @staticmethod
     def backward(ctx, g):
         x, y1, y2, y, w1, w2, w3, wd = ctx.saved_tensors
+        w1t, w2t, w3t, wdt = ctx.wts
         need = ctx.needs_input_grad
         # the tag is honoured only on the very tensor it was put on, unmodified since: autograd sums several consumers of y
         # IN PLACE into the first gradient that arrived (InputBuffer: old_var.add_(var) keeps the Python object and its
@@ -1370,14 +1425,15 @@ class _BottleneckFunction(torch.autograd.Function):
         if need[6]:
             gb3 = g3.sum((0, 2, 3))
         g2 = torch.empty_like(y2)
-        gemm_nt_dx_raw(g3, w3.reshape(N, P).t().contiguous(), None, y2, B * Ho * Wo, P, N, g2)
+        gemm_nt_dx_raw(g3, w3t if w3t is not None else w3.reshape(N, P).t().contiguous(), None, y2, B * Ho * Wo, P, N, g2)
         # conv2: dW2 from the library; dY1 = conv3x3(g2, W2') masked by y1 > 0 (stride 1), the library's data gradient else
         if need[3]:
             gw2 = _dw3x3(g2, y1, w2, s)
         if need[4]:
             gb2 = g2.sum((0, 2, 3))
         if s == 1 and P in (64, 128, 256, 512, 1024):
-            g1 = conv3x3_dx_raw(g2, w2.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last), y1)
+            g1 = conv3x3_dx_raw(g2, w2t if w2t is not None else
+                                w2.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last), y1)
         else:
             g1 = torch.ops.aten.convolution_backward(g2, y1, w2, None, [s] * 2, [1, 1], [1, 1], False, [0, 0], 1,
                                                      [True, False, False])[0]
@@ -1396,7 +1452,8 @@ class _BottleneckFunction(torch.autograd.Function):
             if need[0]:
                 if ds == 1:
                     gid = torch.empty_like(x)
-                    gemm_nt_dx_raw(g3, wd.reshape(N, Cin).t().contiguous(), None, None, B * H * W, Cin, N, gid)
+                    gemm_nt_dx_raw(g3, wdt if wdt is not None else wd.reshape(N, Cin).t().contiguous(), None, None, B * H * W,
+                                   Cin, N, gid)
                 else:
                     gid = torch.ops.aten.convolution_backward(g3, x, wd, None, [ds] * 2, [0, 0], [1, 1], False, [0, 0], 1,
                                                               [True, False, False])[0]
@@ -1405,10 +1462,11 @@ class _BottleneckFunction(torch.autograd.Function):
         # conv1: dX = (g1 W1 + identity gradient) masked by x > 0 when x is a ReLU output whose producer masks anyway
         if need[0]:
             gx = torch.empty_like(x)
-            gemm_nt_dx_raw(g1, w1.reshape(P, Cin).t().contiguous(), gid, x if ctx.x_is_relu else None, B * H * W, Cin, P, gx)
+            gemm_nt_dx_raw(g1, w1t if w1t is not None else w1.reshape(P, Cin).t().contiguous(), gid,
+                           x if ctx.x_is_relu else None, B * H * W, Cin, P, gx)
             if ctx.x_is_relu:
                 gx._dskd_relu_masked = (x.data_ptr(), gx.data_ptr(), gx._version)
-        return gx, gw1, gb1, gw2, gb2, gw3, gb3, gwd, gbd, None, None, None
+        return gx, gw1, gb1, gw2, gb2, gw3, gb3, gwd, gbd, None, None, None, None
 
 
 def bottleneck_ok(x, w1, w2, w3, wd, conv1, conv2, conv3, down) -> bool:
@@ -1428,12 +1486,13 @@ def bottleneck_ok(x, w1, w2, w3, wd, conv1, conv2, conv3, down) -> bool:
     return conv1x1_ok(x, wd, down) and down.stride == conv2.stride and wd.shape[0] == w3.shape[0]
 
 
-def bottleneck(x, w1, b1, w2, b2, w3, b3, wd=None, bd=None, stride=1, x_is_relu=False):
-    """One Bottleneck (folded BatchNorms) as ONE autograd node: see :class:`_BottleneckFunction`."""
+def bottleneck(x, w1, b1, w2, b2, w3, b3, wd=None, bd=None, stride=1, x_is_relu=False, wts=None):
+    """One Bottleneck (folded BatchNorms) as ONE autograd node: see :class:`_BottleneckFunction`.  ``wts``: the operands of
+    its input-gradient launches when the caller has them (:class:`WeightTransposes`)."""
     def bf(b):
         return b if b is None or (b.dtype == torch.bfloat16 and b.is_contiguous()) else b.to(torch.bfloat16).contiguous()
     return _BottleneckFunction.apply(x, w1, bf(b1), w2, bf(b2), w3, bf(b3), wd, bf(bd), int(stride), int(stride),
-                                     bool(x_is_relu))
+                                     bool(x_is_relu), wts)
 
 
 # --------------------------------------------------------------------------- Swin window attention (MFMA kernels)

@@ -583,6 +583,13 @@ int dskd_clip_adamw(const int64_t* ptrs, const int32_t* meta, const int32_t* chu
  * ------------------------------------------------------------------------- */
 int dskd_cast_scale_chunk(void);
 int dskd_cast_scale_many(const int64_t* table, const int32_t* first, int n, int total_chunks, int direction, void* stream);
+/* dst_i[k][taps - 1 - t][n] = src_i[n][t][k] for a list of bf16 convolution weights in ONE launch: the operands of the
+ * input-gradient launches of a trainable ResNet stage (dskd_gemm_nt_dx: the transposed 1x1 weight; dskd_conv3x3_dx: the
+ * tap-flipped, channel-swapped 3x3 weight -- what `w.flip(2, 3).transpose(0, 1)` of a channels_last [N, K, 3, 3] tensor holds;
+ * mmdet/models/backbones/resnet.py:271-303 backward).  table: device rows {src, dst, N, K, taps} (int64; N, K multiples of 64,
+ * taps 1 | 9, pointers 16-byte aligned), first[i] = number of 64 x 64 tiles (taps * N / 64 * K / 64 each) of the tensors
+ * before i, first[n] = total_blocks. */
+int dskd_weight_t_many(const int64_t* table, const int32_t* first, int n, int total_blocks, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
  * GroupNorm(32 groups, 256 channels) on a channels_last activation -- the norm of every ChannelMapper level

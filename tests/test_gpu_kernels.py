@@ -1399,6 +1399,31 @@ def test_conv3x3_weight_gradient_vs_float_reference(B, C, N, H, W, stride):
     assert native.load().dskd_conv3x3_wgrad_scratch_bytes(B, H, W, C, N, 3) == -1
 
 
+def test_weight_transposes_of_a_stage_in_one_launch():
+    """dskd_weight_t_many (native.WeightTransposes): the operands of the input-gradient launches -- w^T of 1x1 weights, the
+    tap-flipped channel-swapped 3x3 weight -- for a list of convolutions at once, bit-equal with the torch expressions the
+    Bottleneck backward used to evaluate per convolution; ineligible entries (odd channel counts, f32) come back as None; a
+    second call with the same addresses reuses the device table."""
+    g = torch.Generator().manual_seed(5)
+    cl = torch.channels_last
+    ws = [torch.randn(128, 256, 1, 1, generator=g).bfloat16().to(DEV).contiguous(memory_format=cl),
+          torch.randn(128, 128, 3, 3, generator=g).bfloat16().to(DEV).contiguous(memory_format=cl),
+          torch.randn(512, 128, 1, 1, generator=g).bfloat16().to(DEV),
+          torch.randn(256, 64, 3, 3, generator=g).bfloat16().to(DEV).contiguous(memory_format=cl),
+          torch.randn(96, 64, 1, 1, generator=g).bfloat16().to(DEV),                  # 96 rows: not eligible
+          torch.randn(64, 64, 1, 1, generator=g).to(DEV)]                             # f32: not eligible
+    tr = native.WeightTransposes()
+    for _ in range(2):
+        outs = tr.run(ws)
+        assert outs[4] is None and outs[5] is None
+        for w, o in zip(ws[:4], outs[:4]):
+            if w.shape[2] == 1:
+                assert o.shape == (w.shape[1], w.shape[0]) and torch.equal(o, w.reshape(w.shape[0], w.shape[1]).t().contiguous())
+            else:
+                ref = w.flip(2, 3).transpose(0, 1).contiguous(memory_format=cl)
+                assert o.shape == ref.shape and o.is_contiguous(memory_format=cl) and torch.equal(o, ref)
+
+
 def _self_attention_reference(qk, v, H, keep=None, p=0.0):
     """softmax(q k^T / sqrt(32)) (* keep / (1 - p)) @ v in fp32; qk [B, L, 2 E], v [B, L, E] -> [B, L, E]."""
     B, L, E = v.shape
