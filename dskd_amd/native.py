@@ -1107,7 +1107,7 @@ def conv3x3_wgrad(g: torch.Tensor, x: torch.Tensor, stride: int) -> torch.Tensor
     if need < 0:
         raise NativeError("conv3x3_wgrad: " + load().dskd_last_error().decode())
     ws = _tn_ws(x.device, need)
-    dw = torch.empty((N, Cc, 3, 3), dtype=torch.bfloat16, device=x.device).contiguous(memory_format=torch.channels_last)
+    dw = torch.empty((N, Cc, 3, 3), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
     rc = load().dskd_conv3x3_wgrad(g.data_ptr(), x.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(), B, Hi, Wi, Cc, N,
                                    stride, DTYPE_BF16, _stream(x))
     _check(rc, "dskd_conv3x3_wgrad")
@@ -1318,7 +1318,7 @@ class WeightTransposes:
             w = ws[i]
             N, K = w.shape[0], w.shape[1]
             outs[i] = torch.empty((K, N), dtype=w.dtype, device=w.device) if w.shape[2] == 1 else \
-                torch.empty((K, N, 3, 3), dtype=w.dtype, device=w.device).contiguous(memory_format=torch.channels_last)
+                torch.empty((K, N, 3, 3), dtype=w.dtype, device=w.device, memory_format=torch.channels_last)
         key = tuple((ws[i].data_ptr(), outs[i].data_ptr(), tuple(ws[i].shape)) for i in idx)
         if key != self.key:
             if torch.cuda.is_current_stream_capturing():
