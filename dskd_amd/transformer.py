@@ -1216,13 +1216,16 @@ class DeformableDetrTransformerDecoder(TransformerLayerSequence):
                 if bf:      # the LayerNorm launches that also form x + query_pos read the f32 values (native._pos_f32)
                     kwargs["query_pos"]._dskd_f32 = qp.detach().float().contiguous()
         intermediate, intermediate_reference_points = [], []
+        reference_points_input = None
         for lid, layer in enumerate(self.layers):
-            if reference_points.shape[-1] == 4:
-                reference_points_input = reference_points[:, :, None] * \
-                    torch.cat([valid_ratios, valid_ratios], -1)[:, None]
-            else:
-                assert reference_points.shape[-1] == 2
-                reference_points_input = reference_points[:, :, None] * valid_ratios[:, None]
+            # without box refinement (every DSKD config) the reference points never change: one product for all layers
+            if reference_points_input is None or reg_branches is not None:
+                if reference_points.shape[-1] == 4:
+                    reference_points_input = reference_points[:, :, None] * \
+                        torch.cat([valid_ratios, valid_ratios], -1)[:, None]
+                else:
+                    assert reference_points.shape[-1] == 2
+                    reference_points_input = reference_points[:, :, None] * valid_ratios[:, None]
             output = layer(output, *args, reference_points=reference_points_input, **kwargs)
             if not bf:
                 output = output.permute(1, 0, 2)
