@@ -1,5 +1,6 @@
 """Where do the calls of a few torch ops of one training step come from (file:line inside dskd_amd / bench.py), and how big
-are they?  Usage: python tools/prof/op_sites.py [op ...]   (default: cat stack)."""
+are they?  Usage: python tools/prof/op_sites.py [op ...]   (default: cat stack; ".to" / ".contiguous" / ".float" ...: Tensor methods that
+returned NEW memory)."""
 import sys, os, collections, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, bench
@@ -35,8 +36,25 @@ def wrap(name):
             sizes[(name, site)] = max(sizes[(name, site)], out.numel() * out.element_size())
         return out
     setattr(torch, name, g)
+def wrap_method(name):
+    f = getattr(torch.Tensor, name)
+    def g(self, *a, **k):
+        out = f(self, *a, **k)
+        if torch.is_tensor(out) and out is not self and out.is_cuda and (name.endswith("_") or out.data_ptr() != self.data_ptr()):
+            site = "?"
+            for fr in reversed(traceback.extract_stack()[:-1]):
+                if "dskd_amd" in fr.filename or fr.filename.endswith("bench.py"):
+                    site = f"{os.path.basename(fr.filename)}:{fr.lineno}"
+                    break
+            counts[("." + name, site)] += 1
+            sizes[("." + name, site)] = max(sizes[("." + name, site)], out.numel() * out.element_size())
+        return out
+    setattr(torch.Tensor, name, g)
 for o in ops:
-    wrap(o)
+    if o.startswith("."):
+        wrap_method(o[1:])
+    else:
+        wrap(o)
 bench.train_step(model, model, opt, data, synth, torch.bfloat16, ahead=ahead)
 torch.cuda.synchronize()
 for (name, site), c in counts.most_common(40):
