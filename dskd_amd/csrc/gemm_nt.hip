@@ -804,6 +804,7 @@ struct TnArgs {
   int splits;            // workgroups along M per output tile
   long long chunk;       // tokens per split (a multiple of 32)
   int tn;                // 128-row groups of the output tile (1: 128 x 128, 2: 256 x 128)
+  float* db;             // null | [splits][N] f32 planes: column sums of g (the bias gradient), formed by the k-tile-0 waves
   // CONV (3x3 weight gradient): x is the INPUT image [B, Hi, Wi, C = ldx], row m of g is output pixel (img, ho, wo); column
   // tap * C + c of the virtual x operand is channel c of input pixel (s ho + ky - 1, s wo + kx - 1), zeros outside
   int Hi, Wi, Wo, HoWo, s;
@@ -963,6 +964,13 @@ __global__ __launch_bounds__((4 * TN + 4) * 64) void gemm_tn_kernel(const TnArgs
   // offsets (64 v_add per stage before), (3) the stage's barrier sits in front of its last MFMA group, whose gaps take the
   // first reads of the next stage.
   bf16x4 fr[2][8];                          // [buffer][g0.lo, g0.hi, g1.lo, g1.hi, x0.lo, x0.hi, x1.lo, x1.hi]
+  const bool bias_wave = !ATOMIC && a.db != nullptr && tk == 0 && wk == 0;      // wave-uniform
+  const bf16x8 ones = {(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
+  f32x16 accb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) accb[i][e] = 0.f;
   unsigned sa[8];                           // this stage's fragment bases: g (t, e) = sa[2 t + e], x (t, e) = sa[4 + 2 t + e]
   auto set_bases = [&](int st) {
     const unsigned o = (st % NS) * STAGE;
@@ -979,10 +987,15 @@ __global__ __launch_bounds__((4 * TN + 4) * 64) void gemm_tn_kernel(const TnArgs
 #define TN_WAIT0(B) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr[B][0]), "+v"(fr[B][1]), "+v"(fr[B][2]), "+v"(fr[B][3]), "+v"(fr[B][4]), \
                                  "+v"(fr[B][5]), "+v"(fr[B][6]), "+v"(fr[B][7])::"memory")
   // one k-step: the 4 MFMAs on buffer B with the 8 reads of (buffer NB, k-step NK) in their gaps
+  // r4 (late): the bias gradient = column sums of g rides along as one more product per g fragment, g^T x ONES, on the
+  // waves that own output columns 0-63 of k-tile 0 (each row block of the result exactly once): the colsum + hand-over
+  // launches of every Linear layer's backward (~150 launches of 3-10 us per step) disappear into the dW launch and its reduce.
+#define TN_BIAS(B) if (bias_wave) { accb[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(B, 0), ones, accb[0], 0, 0, 0); \
+                                    accb[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(B, 2), ones, accb[1], 0, 0, 0); }
 #define TN_GROUP(B, NB, NK)                                                   \
   TN_MFMA(B, 0, 0); TN_FENCE(); TN_READS(NB, NK, 0); TN_FENCE();              \
   TN_MFMA(B, 0, 1); TN_FENCE(); TN_READS(NB, NK, 4); TN_FENCE();              \
-  TN_MFMA(B, 1, 0); TN_MFMA(B, 1, 1); TN_FENCE();
+  TN_MFMA(B, 1, 0); TN_MFMA(B, 1, 1); TN_BIAS(B) TN_FENCE();
 #ifdef DSKD_GEMM_PROFILE
   long long t_wait = 0, t_bar = 0, t_lgkm = 0, t_mark;
 #define TN_T0() t_mark = (long long)__builtin_amdgcn_s_memtime()
@@ -1019,6 +1032,7 @@ __global__ __launch_bounds__((4 * TN + 4) * 64) void gemm_tn_kernel(const TnArgs
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the look-ahead reads of the last stage land in dead registers
 #undef TN_GROUP
+#undef TN_BIAS
 #undef TN_WAIT0
 #undef TN_FENCE
 #undef TN_MFMA
@@ -1048,6 +1062,13 @@ __global__ __launch_bounds__((4 * TN + 4) * 64) void gemm_tn_kernel(const TnArgs
         else cp[(long long)((e & 3) + 8 * (e >> 2)) * a.K] = acc[i][j][e];
       }
     }
+  if (bias_wave && r == 0) {          // every column of accb holds the same sums: lanes 0 and 32 write their 16 rows each
+    float* bp = a.db + (long long)sp * a.N + tn * 128 * TN + wn * 64 + 4 * h;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) bp[i * 32 + (e & 3) + 8 * (e >> 2)] = accb[i][e];
+  }
 }
 
 // dst (bf16) = src (f32), src = 0: hands a weight gradient over in the parameter's dtype and leaves the accumulator that
@@ -1063,9 +1084,14 @@ __global__ __launch_bounds__(256) void cvt_clear_kernel(float* __restrict__ src,
 
 // dst[i] (bf16) = sum over the planes of part[p][i]: the split-K partial products of gemm_tn_kernel<false> summed in a fixed
 // order (deterministic, unlike the atomic form) and handed over in the parameter's dtype.
+// (r4: a second, short segment -- the bias-gradient planes [planes][n2] behind the product planes -- is summed by the blocks
+// behind the first segment's: i in [n_pad, n_pad + n2), n_pad = n rounded up to the block size)
 __global__ __launch_bounds__(256) void reduce_cvt_kernel(const float* __restrict__ part, int planes, long long n,
-                                                         __bf16* __restrict__ dst) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+                                                         __bf16* __restrict__ dst, const float* __restrict__ part2 = nullptr,
+                                                         long long n2 = 0, __bf16* __restrict__ dst2 = nullptr) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long n_pad = (n + 255) / 256 * 256;
+  if (i >= n_pad) { i -= n_pad; part = part2; n = n2; dst = dst2; }
   if (i >= n) return;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int p = 0;
@@ -1082,10 +1108,13 @@ __global__ __launch_bounds__(256) void reduce_cvt_kernel(const float* __restrict
 // The same sum for MANY planes of a small result (64 planes of 256 x 256: the thin layers): 32 outputs per workgroup, 8 lanes
 // of planes each (independent loads), one LDS step -- a thread of the form above walks its 64 planes alone.
 __global__ __launch_bounds__(256) void reduce_cvt_wide_kernel(const float* __restrict__ part, int planes, long long n,
-                                                              __bf16* __restrict__ dst) {
+                                                              __bf16* __restrict__ dst, const float* __restrict__ part2 = nullptr,
+                                                              long long n2 = 0, __bf16* __restrict__ dst2 = nullptr) {
   __shared__ float s_part[8][33];
   const int cl = threadIdx.x & 31, kg = threadIdx.x >> 5;
-  const long long i = (long long)blockIdx.x * 32 + cl;
+  long long i = (long long)blockIdx.x * 32 + cl;
+  const long long n_pad = (n + 31) / 32 * 32;
+  if ((long long)blockIdx.x * 32 >= n_pad) { i -= n_pad; part = part2; n = n2; dst = dst2; }      // block-uniform
   float s0 = 0.f, s1 = 0.f;
   if (i < n) {
     int p = kg;
@@ -1334,6 +1363,7 @@ static int gemm_tn_plan(const void* g, const void* x, const void* c, int64_t M, 
   if ((reinterpret_cast<uintptr_t>(g) & 15) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(c) & 15))
     return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_tn: pointers must be 16-byte aligned");
   a->g = (const __bf16*)g; a->x = (const __bf16*)x; a->c = (float*)c; a->M = M; a->N = N; a->K = K; a->ldg = ldg; a->ldx = ldx;
+  a->db = nullptr;
   // 256 x 128 output tiles only for the large products of the encoder FFN (N K >= 256 K, M >= 64 K tokens: 3 % faster there,
   // 10-25 % slower on the convolution shapes: profiles/r04_gemm_tn_phases.txt)
   a->tn = (N % 256 == 0 && (long long)N * K >= 262144 && M >= 65536) ? 2 : 1;
@@ -1383,28 +1413,43 @@ extern "C" int64_t dskd_gemm_tn_scratch_bytes(int64_t M, int N, int K) {
   long long tiles = 0;
   static const char dummy[16] __attribute__((aligned(16))) = {};
   if (gemm_tn_plan(dummy, dummy, dummy, M, N, K, N, K, DSKD_DTYPE_BF16, &a, &tiles)) return -1;
-  return (int64_t)a.splits * N * K * (int64_t)sizeof(float);
+  return (int64_t)a.splits * ((int64_t)N * K + N) * (int64_t)sizeof(float);      // product planes + bias-gradient planes
 }
 
-extern "C" int dskd_gemm_tn_bf16(const void* g, const void* x, void* out, void* scratch, int64_t scratch_bytes, int64_t M,
-                                 int N, int K, int ldg, int ldx, int dtype, void* stream) {
+static int gemm_tn_bf16_impl(const void* g, const void* x, void* out, void* db_out, void* scratch, int64_t scratch_bytes,
+                             int64_t M, int N, int K, int ldg, int ldx, int dtype, void* stream) {
   TnArgs a;
   long long tiles = 0;
   if (!out || (reinterpret_cast<uintptr_t>(out) & 1)) return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_tn_bf16: null output");
   if (int rc = gemm_tn_plan(g, x, scratch, M, N, K, ldg, ldx, dtype, &a, &tiles)) return rc;
   if (M == 0) return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_tn_bf16: M must be positive");
-  if (scratch_bytes < (int64_t)a.splits * N * K * (int64_t)sizeof(float))
-    return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_tn_bf16: scratch of %lld bytes, %lld needed", (long long)scratch_bytes,
-                (long long)a.splits * N * K * (long long)sizeof(float));
-  if (int rc = gemm_tn_launch<false>(a, tiles, (hipStream_t)stream)) return rc;
   const long long n = (long long)N * K;
+  const int64_t need = (int64_t)a.splits * (n + N) * (int64_t)sizeof(float);      // = dskd_gemm_tn_scratch_bytes, with or without db
+  if (scratch_bytes < need)
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_tn_bf16: scratch of %lld bytes, %lld needed", (long long)scratch_bytes,
+                (long long)need);
+  float* dbp = db_out ? reinterpret_cast<float*>(scratch) + (long long)a.splits * n : nullptr;
+  a.db = dbp;
+  if (int rc = gemm_tn_launch<false>(a, tiles, (hipStream_t)stream)) return rc;
+  const long long n2 = db_out ? N : 0;
   if (a.splits >= 16 && n <= (1 << 20))
-    hipLaunchKernelGGL(reduce_cvt_wide_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)scratch, a.splits, n, (__bf16*)out);
+    hipLaunchKernelGGL(reduce_cvt_wide_kernel, dim3((unsigned)((n + 31) / 32 + (n2 + 31) / 32)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)scratch, a.splits, n, (__bf16*)out, (const float*)dbp, n2, (__bf16*)db_out);
   else
-    hipLaunchKernelGGL(reduce_cvt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)scratch, a.splits, n, (__bf16*)out);
+    hipLaunchKernelGGL(reduce_cvt_kernel, dim3((unsigned)((n + 255) / 256 + (n2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)scratch, a.splits, n, (__bf16*)out, (const float*)dbp, n2, (__bf16*)db_out);
   return check_launch("dskd_gemm_tn_bf16/reduce");
+}
+
+extern "C" int dskd_gemm_tn_bf16(const void* g, const void* x, void* out, void* scratch, int64_t scratch_bytes, int64_t M,
+                                 int N, int K, int ldg, int ldx, int dtype, void* stream) {
+  return gemm_tn_bf16_impl(g, x, out, nullptr, scratch, scratch_bytes, M, N, K, ldg, ldx, dtype, stream);
+}
+
+extern "C" int dskd_gemm_tn_bias_bf16(const void* g, const void* x, void* out, void* db_out, void* scratch, int64_t scratch_bytes,
+                                      int64_t M, int N, int K, int ldg, int ldx, int dtype, void* stream) {
+  if (!db_out || (reinterpret_cast<uintptr_t>(db_out) & 1)) return fail(DSKD_ERR_INVALID_ARG, "dskd_gemm_tn_bias_bf16: null db output");
+  return gemm_tn_bf16_impl(g, x, out, db_out, scratch, scratch_bytes, M, N, K, ldg, ldx, dtype, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -70,6 +70,7 @@ _SIGNATURES = {
     "dskd_gemm_tn_bf16": (C.c_int, [_vp] * 4 + [_i64, _i64] + [C.c_int] * 5 + [_vp]),
     "dskd_winattn_fwd": (C.c_int, [_vp] * 4 + [C.c_int] * 5 + [_f32, C.c_int, _vp]),
     "dskd_winattn_bwd": (C.c_int, [_vp] * 6 + [C.c_int] * 5 + [_f32, C.c_int, _vp]),
+    "dskd_gemm_tn_bias_bf16": (C.c_int, [_vp] * 5 + [_i64, _i64] + [C.c_int] * 5 + [_vp]),
     "dskd_conv3x3_wgrad_scratch_bytes": (C.c_int64, [C.c_int] * 6),
     "dskd_conv3x3_wgrad": (C.c_int, [_vp] * 4 + [C.c_int64] + [C.c_int] * 7 + [_vp]),
     "dskd_weight_t_many": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
@@ -1116,7 +1117,7 @@ def conv3x3_wgrad(g: torch.Tensor, x: torch.Tensor, stride: int) -> torch.Tensor
     return dw
 
 
-def gemm_tn_bf16(g2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
+def gemm_tn_bf16(g2: torch.Tensor, x2: torch.Tensor, want_bias: bool = False):
     """``(g2^T @ x2).to(bf16)`` -- a weight gradient in the low-precision parameter's dtype -- in two launches without
     atomics: the split-K kernel writes every split's partial product into a persistent scratch ([splits, N, K] f32, plain
     stores), a second launch sums the planes in a fixed order and casts (dskd_gemm_tn_bf16).  The float-atomic flush of the
@@ -1130,11 +1131,17 @@ def gemm_tn_bf16(g2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     dev = g2.device
     ws = _tn_ws(dev, need)
     out = torch.empty((N, K), dtype=torch.bfloat16, device=dev)
+    global _ffn_flops
+    _ffn_flops += 2 * M * N * K
+    if want_bias:         # (dW, db): the column sums of g2 come out of the same two launches (dskd_gemm_tn_bias_bf16)
+        db = torch.empty((N,), dtype=torch.bfloat16, device=dev)
+        rc = load().dskd_gemm_tn_bias_bf16(g2.data_ptr(), x2.data_ptr(), out.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(),
+                                           M, N, K, g2.stride(0), x2.stride(0), DTYPE_BF16, _stream(g2))
+        _check(rc, "dskd_gemm_tn_bias_bf16")
+        return out, db
     rc = load().dskd_gemm_tn_bf16(g2.data_ptr(), x2.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), M, N, K,
                                   g2.stride(0), x2.stride(0), DTYPE_BF16, _stream(g2))
     _check(rc, "dskd_gemm_tn_bf16")
-    global _ffn_flops
-    _ffn_flops += 2 * M * N * K
     return out
 
 

@@ -143,9 +143,13 @@ class _TallLinearFn(torch.autograd.Function):
                 gx = native.lin256(g2, native.lin256_pack(weight, transposed=True), weight.shape[1]).view(x.shape)
             else:
                 gx = (g2 @ weight).view(x.shape)
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] and want_b and weight.dtype == torch.bfloat16 and native.gemm_tn_ok(g2, x2):
+            gw, gb = native.gemm_tn_bf16(g2, x2, want_bias=True)      # the bias gradient rides in the dW launch pair
+            return gx, gw, gb, None, None
         if ctx.needs_input_grad[1]:
             gw = _weight_grad(g2, x2, ctx.chunk, weight.dtype)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if want_b:
             gb = bias_grad(g2)
         return gx, gw, gb, None, None
 
@@ -206,10 +210,14 @@ class _FusedFFNFn(torch.autograd.Function):
             gw1 = _weight_grad(gh, x, ctx.chunk, ctx.dt)
         if ctx.needs_input_grad[2]:
             gb1 = cs.to(ctx.dt)
-        if ctx.needs_input_grad[3]:
-            gw2 = _weight_grad(gy, h, ctx.chunk, ctx.dt)
-        if ctx.needs_input_grad[4]:
-            gb2 = native.colsum(gy, out_dtype=ctx.dt) if ctx.dt in (torch.float32, torch.bfloat16) else native.colsum(gy).to(ctx.dt)
+        if ctx.needs_input_grad[3] and ctx.needs_input_grad[4] and ctx.dt == torch.bfloat16 and native.gemm_tn_ok(gy, h):
+            gw2, gb2 = native.gemm_tn_bf16(gy, h, want_bias=True)       # d(b2) rides in the dW2 launch pair
+        else:
+            if ctx.needs_input_grad[3]:
+                gw2 = _weight_grad(gy, h, ctx.chunk, ctx.dt)
+            if ctx.needs_input_grad[4]:
+                gb2 = native.colsum(gy, out_dtype=ctx.dt) if ctx.dt in (torch.float32, torch.bfloat16) else \
+                    native.colsum(gy).to(ctx.dt)
         return (gx if ctx.needs_input_grad[0] else None), gw1, gb1, gw2, gb2, None, None
 
 

@@ -502,6 +502,11 @@ int dskd_gemm_tn(const void* g, const void* x, float* c, int64_t M, int N, int K
 int64_t dskd_gemm_tn_scratch_bytes(int64_t M, int N, int K);
 int dskd_gemm_tn_bf16(const void* g, const void* x, void* out, void* scratch, int64_t scratch_bytes, int64_t M, int N, int K,
                       int ldg, int ldx, int dtype, void* stream);
+/* The same launch pair with the BIAS gradient as a by-product: db_out [N] (bf16) = column sums of g -- one more product per g
+ * fragment (g^T x ones) on the waves of k-tile 0, its planes behind the product planes of the scratch, summed by the same
+ * reduction launch: the separate column-sum + hand-over launches of a Linear layer's backward are gone.  Same scratch size. */
+int dskd_gemm_tn_bias_bf16(const void* g, const void* x, void* out, void* db_out, void* scratch, int64_t scratch_bytes, int64_t M,
+                           int N, int K, int ldg, int ldx, int dtype, void* stream);
 /* Weight gradient of a 3x3 convolution (padding 1, stride 1 | 2): dw[n][ky][kx][c] (bf16 = a [N, C, 3, 3] channels_last
  * weight) = sum over the output pixels of g[pixel][n] * x[pixel shifted by the tap][c]; g [B, Ho, Wo, N] and x [B, Hi, Wi, C]
  * channels_last bf16, Ho = (Hi - 1) / stride + 1.  The split-K kernel of dskd_gemm_tn_bf16 over a virtual [pixels, 9 C]

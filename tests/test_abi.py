@@ -122,12 +122,14 @@ def test_round3_late_entry_points_validate_their_arguments():
     assert lib.dskd_conv3x3_dx(p, p, None, p, 0, 8, 8, 64, 64, bf16, None) == 0
     # split-K scratch: the planner's answer, and a buffer one byte short of it
     need = lib.dskd_gemm_tn_scratch_bytes(88892, 256, 256)
-    assert need > 0 and need % (256 * 256 * 4) == 0 and need <= 64 << 20
+    assert need > 0 and need % ((256 * 256 + 256) * 4) == 0 and need <= 64 << 20      # product planes + bias-gradient planes
     assert lib.dskd_gemm_tn_scratch_bytes(1000, 100, 256) == -1
     assert lib.dskd_gemm_tn_bf16(p, p, p, p, need - 1, 88892, 256, 256, 256, 256, bf16, None) == -1
     assert b"scratch" in lib.dskd_last_error()
     assert lib.dskd_gemm_tn_bf16(p, p, None, p, need, 88892, 256, 256, 256, 256, bf16, None) == -1
     assert lib.dskd_gemm_tn_bf16(p, p, p, p, need, 88892, 256, 256, 128, 256, bf16, None) == -1          # ldg < N
+    assert lib.dskd_gemm_tn_bias_bf16(p, p, p, None, p, need, 88892, 256, 256, 256, 256, bf16, None) == -1    # no db output
+    assert lib.dskd_gemm_tn_bias_bf16(p, p, p, p, p, need - 1, 88892, 256, 256, 256, 256, bf16, None) == -1
     assert lib.dskd_colsum_short(p, p, 70000, 256, bf16, None) == -1 and b"rows" in lib.dskd_last_error()
     assert lib.dskd_colsum_short(p, p, 100, 250, bf16, None) == -1
     assert lib.dskd_colsum_short(p + 2, p, 100, 256, bf16, None) == -1

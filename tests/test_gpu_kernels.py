@@ -1913,6 +1913,14 @@ def test_gemm_tn_vs_float_reference(M, N, K):
     native._tn_scratch[skey].fill_(0x7F)                           # NaN-ish garbage in every plane
     b2 = native.gemm_tn_bf16(gd, xd)
     assert b1.dtype == torch.bfloat16 and _close(b1, ref, 6e-3) and torch.equal(b1, b2)
+    # ... with the bias gradient (column sums of g) as a by-product of the same two launches (dskd_gemm_tn_bias_bf16): the
+    # weight gradient is bit-equal with the plain form, the sums match the f32 column sums of the bf16 input
+    native._tn_scratch[skey].fill_(0x7F)
+    b3, db = native.gemm_tn_bf16(gd, xd, want_bias=True)
+    assert torch.equal(b3, b1) and db.shape == (N,) and db.dtype == torch.bfloat16
+    ref_db = gm[:, :N].float().sum(0)
+    assert _close(db, ref_db, 6e-3), float((db.float().cpu() - ref_db).abs().max()) / float(ref_db.abs().max())
+    assert torch.equal(native.gemm_tn_bf16(gd, xd, want_bias=True)[1], db)
     # the atomic form (persistent accumulator + dskd_cvt_clear): same values, and the accumulator is zero again
     a1 = native.gemm_tn_bf16_atomic(gd, xd)
     a2 = native.gemm_tn_bf16_atomic(gd, xd)
