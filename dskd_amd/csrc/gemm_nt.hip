@@ -1480,24 +1480,39 @@ extern "C" int64_t dskd_conv3x3_wgrad_scratch_bytes(int B, int Hi, int Wi, int C
   long long tiles = 0;
   static const char dummy[16] __attribute__((aligned(16))) = {};
   if (conv3x3_wgrad_plan(dummy, dummy, dummy, B, Hi, Wi, C, N, stride, DSKD_DTYPE_BF16, &a, &tiles)) return -1;
-  return (int64_t)a.splits * N * 9 * C * (int64_t)sizeof(float);
+  return (int64_t)a.splits * ((int64_t)N * 9 * C + N) * (int64_t)sizeof(float);
 }
 
-extern "C" int dskd_conv3x3_wgrad(const void* g, const void* x, void* dw, void* scratch, int64_t scratch_bytes, int B, int Hi,
-                                  int Wi, int C, int N, int stride, int dtype, void* stream) {
+static int conv3x3_wgrad_impl(const void* g, const void* x, void* dw, void* db_out, void* scratch, int64_t scratch_bytes, int B,
+                              int Hi, int Wi, int C, int N, int stride, int dtype, void* stream) {
   TnArgs a;
   long long tiles = 0;
   if (!dw || (reinterpret_cast<uintptr_t>(dw) & 1)) return fail(DSKD_ERR_INVALID_ARG, "dskd_conv3x3_wgrad: null output");
   if (int rc = conv3x3_wgrad_plan(g, x, scratch, B, Hi, Wi, C, N, stride, dtype, &a, &tiles)) return rc;
   const long long n = (long long)N * 9 * C;
-  if (scratch_bytes < (int64_t)a.splits * n * (int64_t)sizeof(float))
+  const int64_t need = (int64_t)a.splits * (n + N) * (int64_t)sizeof(float);
+  if (scratch_bytes < need)
     return fail(DSKD_ERR_INVALID_ARG, "dskd_conv3x3_wgrad: scratch of %lld bytes, %lld needed", (long long)scratch_bytes,
-                (long long)a.splits * n * (long long)sizeof(float));
+                (long long)need);
+  float* dbp = db_out ? reinterpret_cast<float*>(scratch) + (long long)a.splits * n : nullptr;
+  a.db = dbp;
   if (int rc = a.tn == 2 ? gemm_tn_launch_t<false, 2, true>(a, tiles, (hipStream_t)stream)
                          : gemm_tn_launch_t<false, 1, true>(a, tiles, (hipStream_t)stream)) return rc;
-  hipLaunchKernelGGL(reduce_cvt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const float*)scratch, a.splits, n, (__bf16*)dw);
+  const long long n2 = db_out ? N : 0;
+  hipLaunchKernelGGL(reduce_cvt_kernel, dim3((unsigned)((n + 255) / 256 + (n2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)scratch, a.splits, n, (__bf16*)dw, (const float*)dbp, n2, (__bf16*)db_out);
   return check_launch("dskd_conv3x3_wgrad/reduce");
+}
+
+extern "C" int dskd_conv3x3_wgrad(const void* g, const void* x, void* dw, void* scratch, int64_t scratch_bytes, int B, int Hi,
+                                  int Wi, int C, int N, int stride, int dtype, void* stream) {
+  return conv3x3_wgrad_impl(g, x, dw, nullptr, scratch, scratch_bytes, B, Hi, Wi, C, N, stride, dtype, stream);
+}
+
+extern "C" int dskd_conv3x3_wgrad_bias(const void* g, const void* x, void* dw, void* db_out, void* scratch, int64_t scratch_bytes,
+                                       int B, int Hi, int Wi, int C, int N, int stride, int dtype, void* stream) {
+  if (!db_out || (reinterpret_cast<uintptr_t>(db_out) & 1)) return fail(DSKD_ERR_INVALID_ARG, "dskd_conv3x3_wgrad_bias: null db output");
+  return conv3x3_wgrad_impl(g, x, dw, db_out, scratch, scratch_bytes, B, Hi, Wi, C, N, stride, dtype, stream);
 }
 
 extern "C" int dskd_cvt_clear(float* src, void* dst, int64_t n, int dtype, void* stream) {

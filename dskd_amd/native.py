@@ -73,6 +73,7 @@ _SIGNATURES = {
     "dskd_gemm_tn_bias_bf16": (C.c_int, [_vp] * 5 + [_i64, _i64] + [C.c_int] * 5 + [_vp]),
     "dskd_conv3x3_wgrad_scratch_bytes": (C.c_int64, [C.c_int] * 6),
     "dskd_conv3x3_wgrad": (C.c_int, [_vp] * 4 + [C.c_int64] + [C.c_int] * 7 + [_vp]),
+    "dskd_conv3x3_wgrad_bias": (C.c_int, [_vp] * 5 + [C.c_int64] + [C.c_int] * 7 + [_vp]),
     "dskd_weight_t_many": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "dskd_attn_fwd": (C.c_int, [_vp] * 5 + [C.c_int] * 4 + [_vp, _f32, _f32, C.c_uint64, C.c_uint64, _vp, C.c_int, _vp]),
     "dskd_attn_bwd": (C.c_int, [_vp] * 10 + [C.c_int] * 4 + [_vp, _f32, _f32, C.c_uint64, C.c_uint64, _vp, C.c_int, _vp]),
@@ -1098,7 +1099,7 @@ def conv3x3_wgrad_ok(g: torch.Tensor, x: torch.Tensor, stride: int) -> bool:
             and g.shape[0] * g.shape[2] * g.shape[3] < (1 << 24) and g.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0)
 
 
-def conv3x3_wgrad(g: torch.Tensor, x: torch.Tensor, stride: int) -> torch.Tensor:
+def conv3x3_wgrad(g: torch.Tensor, x: torch.Tensor, stride: int, want_bias: bool = False):
     """d(weight) of ``conv2d(x, w, stride, padding=1)`` for a 3x3 kernel: [N, C, 3, 3] channels_last bf16, two launches
     (split-K products + fixed-order reduction), deterministic (dskd_conv3x3_wgrad)."""
     _need_gpu(g, x)
@@ -1109,11 +1110,17 @@ def conv3x3_wgrad(g: torch.Tensor, x: torch.Tensor, stride: int) -> torch.Tensor
         raise NativeError("conv3x3_wgrad: " + load().dskd_last_error().decode())
     ws = _tn_ws(x.device, need)
     dw = torch.empty((N, Cc, 3, 3), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    global _ffn_flops
+    _ffn_flops += 2 * B * g.shape[2] * g.shape[3] * N * 9 * Cc
+    if want_bias:        # (dW, db): the sums of g over the pixels from the same two launches
+        db = torch.empty((N,), dtype=torch.bfloat16, device=x.device)
+        rc = load().dskd_conv3x3_wgrad_bias(g.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(), B,
+                                            Hi, Wi, Cc, N, stride, DTYPE_BF16, _stream(x))
+        _check(rc, "dskd_conv3x3_wgrad_bias")
+        return dw, db
     rc = load().dskd_conv3x3_wgrad(g.data_ptr(), x.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(), B, Hi, Wi, Cc, N,
                                    stride, DTYPE_BF16, _stream(x))
     _check(rc, "dskd_conv3x3_wgrad")
-    global _ffn_flops
-    _ffn_flops += 2 * B * g.shape[2] * g.shape[3] * N * 9 * Cc
     return dw
 
 
@@ -1178,13 +1185,14 @@ def conv3x3_raw(x, w, bias, res, relu, stride, out=None, gate=None):
 CONV3_WGRAD = not os.environ.get("DSKD_CONV3_WGRAD_LIB")      # A/B switch: MIOpen's weight gradient for the 3x3 convolutions
 
 
-def _dw3x3(g, x, w, stride):
+def _dw3x3(g, x, w, stride, want_bias=False):
     """d(weight) of a 3x3 convolution: the split-K MFMA kernel where its shape rules hold (C, N multiples of 128: ResNet
-    stages 2-4), the library otherwise (stage 1: 64 channels)."""
+    stages 2-4), the library otherwise (stage 1: 64 channels).  ``want_bias``: (dW, sum of g over batch and pixels)."""
     if CONV3_WGRAD and w.dtype == torch.bfloat16 and conv3x3_wgrad_ok(g, x, stride):
-        return conv3x3_wgrad(g, x, stride)
-    return torch.ops.aten.convolution_backward(g, x, w, None, [stride] * 2, [1, 1], [1, 1], False, [0, 0], 1,
-                                               [False, True, False])[1]
+        return conv3x3_wgrad(g, x, stride, want_bias)
+    gw = torch.ops.aten.convolution_backward(g, x, w, None, [stride] * 2, [1, 1], [1, 1], False, [0, 0], 1,
+                                             [False, True, False])[1]
+    return (gw, g.sum((0, 2, 3))) if want_bias else gw
 
 
 class _Conv3x3Function(torch.autograd.Function):
@@ -1363,15 +1371,25 @@ def _rows(t):          # [B, C, H, W] channels_last -> its NHWC rows [B*H*W, C] 
     return t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])
 
 
-def _dw1x1(g, x, w, stride):
-    """Weight gradient of a 1x1 convolution y = conv(x, w, stride) from g = dL/dy."""
+def _dw1x1(g, x, w, stride, want_bias=False):
+    """Weight gradient of a 1x1 convolution y = conv(x, w, stride) from g = dL/dy.  ``want_bias``: (dW, sum of g over batch
+    and pixels) -- from the same launch pair where the split-K kernel runs."""
     N, K = w.shape[0], w.shape[1]
     g2, x2 = _rows(g), _rows(x)
     if stride == 1 and gemm_tn_ok(g2, x2):
-        gw = (gemm_tn_bf16(g2, x2) if w.dtype == torch.bfloat16 else gemm_tn(g2, x2).to(w.dtype)).view(N, K, 1, 1)
-        return gw.as_strided(w.shape, w.stride()) if w.stride() != gw.stride() else gw
-    return torch.ops.aten.convolution_backward(g, x, w, None, [stride] * 2, [0, 0], [1, 1], False, [0, 0], 1,
-                                               [False, True, False])[1]
+        gb = None
+        if w.dtype == torch.bfloat16 and want_bias:
+            gw, gb = gemm_tn_bf16(g2, x2, want_bias=True)
+        else:
+            gw = gemm_tn_bf16(g2, x2) if w.dtype == torch.bfloat16 else gemm_tn(g2, x2).to(w.dtype)
+        gw = gw.view(N, K, 1, 1)
+        gw = gw.as_strided(w.shape, w.stride()) if w.stride() != gw.stride() else gw
+        if want_bias:
+            return gw, (gb if gb is not None else g.sum((0, 2, 3)))
+        return gw
+    gw = torch.ops.aten.convolution_backward(g, x, w, None, [stride] * 2, [0, 0], [1, 1], False, [0, 0], 1,
+                                             [False, True, False])[1]
+    return (gw, g.sum((0, 2, 3))) if want_bias else gw
 
 
 class _BottleneckFunction(torch.autograd.Function):
@@ -1427,17 +1445,23 @@ class _BottleneckFunction(torch.autograd.Function):
         s, ds = ctx.stride, ctx.dstride
         gw1 = gw2 = gw3 = gwd = gb1 = gb2 = gb3 = gbd = gx = None
         # conv3: dW3 = g3^T y2; dY2 = (g3 W3) masked by y2 > 0
-        if need[5]:
-            gw3 = _dw1x1(g3, y2, w3, 1)
-        if need[6]:
-            gb3 = g3.sum((0, 2, 3))
+        if need[5] and need[6]:
+            gw3, gb3 = _dw1x1(g3, y2, w3, 1, want_bias=True)       # the bias sums ride in the dW launch pair
+        else:
+            if need[5]:
+                gw3 = _dw1x1(g3, y2, w3, 1)
+            if need[6]:
+                gb3 = g3.sum((0, 2, 3))
         g2 = torch.empty_like(y2)
         gemm_nt_dx_raw(g3, w3t if w3t is not None else w3.reshape(N, P).t().contiguous(), None, y2, B * Ho * Wo, P, N, g2)
         # conv2: dW2 from the library; dY1 = conv3x3(g2, W2') masked by y1 > 0 (stride 1), the library's data gradient else
-        if need[3]:
-            gw2 = _dw3x3(g2, y1, w2, s)
-        if need[4]:
-            gb2 = g2.sum((0, 2, 3))
+        if need[3] and need[4]:
+            gw2, gb2 = _dw3x3(g2, y1, w2, s, want_bias=True)
+        else:
+            if need[3]:
+                gw2 = _dw3x3(g2, y1, w2, s)
+            if need[4]:
+                gb2 = g2.sum((0, 2, 3))
         if s == 1 and P in (64, 128, 256, 512, 1024):
             g1 = conv3x3_dx_raw(g2, w2t if w2t is not None else
                                 w2.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last), y1)
@@ -1445,17 +1469,20 @@ class _BottleneckFunction(torch.autograd.Function):
             g1 = torch.ops.aten.convolution_backward(g2, y1, w2, None, [s] * 2, [1, 1], [1, 1], False, [0, 0], 1,
                                                      [True, False, False])[0]
             g1 = torch.ops.aten.threshold_backward(g1, y1, 0)
-        if need[1]:
-            gw1 = _dw1x1(g1, x, w1, 1)
-        if need[2]:
-            gb1 = g1.sum((0, 2, 3))
+        if need[1] and need[2]:
+            gw1, gb1 = _dw1x1(g1, x, w1, 1, want_bias=True)
+        else:
+            if need[1]:
+                gw1 = _dw1x1(g1, x, w1, 1)
+            if need[2]:
+                gb1 = g1.sum((0, 2, 3))
         # the identity path: g3 itself, or through the downsample convolution
         gid = g3
         if ctx.has_down:
             if need[7]:
                 gwd = _dw1x1(g3, x, wd, ds)
-            if need[8]:
-                gbd = g3.sum((0, 2, 3))
+            if need[8]:       # the downsample branch's output gradient IS g3: the same sums as d(b3)
+                gbd = gb3 if gb3 is not None else g3.sum((0, 2, 3))
             if need[0]:
                 if ds == 1:
                     gid = torch.empty_like(x)

@@ -516,6 +516,10 @@ int dskd_gemm_tn_bias_bf16(const void* g, const void* x, void* out, void* db_out
 int64_t dskd_conv3x3_wgrad_scratch_bytes(int B, int Hi, int Wi, int C, int N, int stride);
 int dskd_conv3x3_wgrad(const void* g, const void* x, void* dw, void* scratch, int64_t scratch_bytes, int B, int Hi, int Wi, int C,
                        int N, int stride, int dtype, void* stream);
+/* ... with db_out [N] (bf16) = the sums of g over all output pixels (the gradient of the folded-BN bias) as a by-product, as in
+ * dskd_gemm_tn_bias_bf16. */
+int dskd_conv3x3_wgrad_bias(const void* g, const void* x, void* dw, void* db_out, void* scratch, int64_t scratch_bytes, int B,
+                            int Hi, int Wi, int C, int N, int stride, int dtype, void* stream);
 /* dst (bf16, n elements) = src (f32); src = 0 -- the accumulator of dskd_gemm_tn handed over in the parameter's dtype and
  * left zeroed for its next use (n a multiple of 4). */
 int dskd_cvt_clear(float* src, void* dst, int64_t n, int dtype, void* stream);

@@ -1393,6 +1393,11 @@ def test_conv3x3_weight_gradient_vs_float_reference(B, C, N, H, W, stride):
     for ws in native._tn_scratch.values():
         ws.fill_(0x7F)
     assert torch.equal(native.conv3x3_wgrad(gd, xd, stride), dw)
+    # dskd_conv3x3_wgrad_bias: the same dW bit for bit, plus the sums of g over batch and pixels (the folded-BN bias gradient)
+    dw2, db = native.conv3x3_wgrad(gd, xd, stride, want_bias=True)
+    assert torch.equal(dw2, dw) and db.shape == (N,) and db.dtype == torch.bfloat16
+    bref = gy.float().sum((0, 2, 3))
+    assert _close(db, bref, 8e-3), float((db.float().cpu() - bref).abs().max()) / float(bref.abs().max())
     # shapes the kernel is not built for are refused, not mis-computed
     assert not native.conv3x3_wgrad_ok(gd[:, :64].contiguous(memory_format=cl), xd, stride)
     assert native.load().dskd_conv3x3_wgrad_scratch_bytes(B, H, W, 64, N, stride) == -1
