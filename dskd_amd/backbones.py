@@ -380,11 +380,29 @@ class ResNet(nn.Module):
                 pairs[i][0].__dict__["_folded_live"] = (w, biases[i], wt)
         return [c for c, _, _ in pairs]
 
+    def _stem(self, x):
+        """conv1 -> norm1 -> ReLU -> MaxPool (resnet.py:633-640).  Without gradients (teacher; student with a frozen stem) and
+        a folded weight in the cache: the library's 7x7 convolution, then bias + ReLU + pooling as ONE pass
+        (native.bias_relu_maxpool) instead of an in-place bias + ReLU pass and the pooling."""
+        conv, bn = self.conv1, self.bn1
+        folded = conv.__dict__.get("_folded")
+        if folded is not None and not bn.training and x.is_cuda and conv.__dict__.get("_folded_live") is None \
+                and not (conv.weight.requires_grad or bn.weight.requires_grad or bn.bias.requires_grad or x.requires_grad):
+            dtype = torch.get_autocast_dtype(x.device.type) if torch.is_autocast_enabled(x.device.type) else x.dtype
+            key = (conv.weight._version, bn.weight._version, bn.running_var._version, bn.running_mean._version, dtype,
+                   conv.weight.device)
+            if folded[0] == key and folded[2] is not None:
+                y = F.conv2d(x, folded[1], None, conv.stride, conv.padding, conv.dilation, conv.groups)
+                if native.bias_relu_maxpool_ok(y, folded[2]):
+                    return native.bias_relu_maxpool(y, folded[2])
+                return F.max_pool2d(native.bias_act(y, folded[2], None, True), kernel_size=3, stride=2, padding=1)
+        x = conv_bn(conv, bn, x, relu=True)         # (also fills the cache of a frozen stem for the next call)
+        return F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+
     def forward(self, x):
         live = self._fold_trainable(x)
         try:
-            x = conv_bn(self.conv1, self.bn1, x, relu=True)
-            x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+            x = self._stem(x)
             outs = []
             for i, name in enumerate(self.res_layers):
                 x = getattr(self, name)(x)

@@ -88,10 +88,85 @@ void launch(T* x, const T* bias, const T* identity, long long n, int C, bool rel
   }
 }
 
+// The stem's tail where nothing needs a gradient (the teacher, and the student's frozen stem): conv1 -> folded BN -> ReLU ->
+// MaxPool(3, stride 2, padding 1) (reference resnet.py:633-640) leaves a bias + ReLU pass over [B, 64, 400, 667] (137 MB read
+// and written) and the pooling (137 MB read, 34 MB written).  Rounding and ReLU are monotonic and the bias is constant over
+// a window, so max(relu(round(x + b))) = relu(round(max(x) + b)): one pass, 137 MB read + 34 MB written, bit-identical.
+// thread = (output pixel, 16-byte channel group); the windows of neighbouring outputs overlap in L1 / L2.
+template <typename T>
+__global__ __launch_bounds__(256) void bias_relu_maxpool_kernel(const T* __restrict__ x, const T* __restrict__ bias,
+                                                                T* __restrict__ y, int H, int W, int Ho, int Wo, int C,
+                                                                long long nvec) {
+  constexpr int V = Vec<T>::n;
+  const int cv = C / V;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv) * V;
+    long long p = i / cv;
+    const int wo = (int)(p % Wo); p /= Wo;
+    const int ho = (int)(p % Ho);
+    const long long b = p / Ho;
+    float m[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) m[k] = -INFINITY;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int hi = 2 * ho + dy;
+      if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int wi = 2 * wo + dx;
+        if ((unsigned)wi >= (unsigned)W) continue;
+        float v[V];
+        load_vec(x + ((b * H + hi) * W + wi) * C + c, v);
+#pragma unroll
+        for (int k = 0; k < V; ++k) m[k] = fmaxf(m[k], v[k]);
+      }
+    }
+    float bv[V];
+    load_vec(bias + c, bv);
+    if constexpr (sizeof(T) == 2) {
+      // round(x + b) first (what the unfused pass stores), then ReLU
+      float r[V];
+#pragma unroll
+      for (int k = 0; k < V; ++k) r[k] = fmaxf((float)(__bf16)(m[k] + bv[k]), 0.f);
+      store_vec(y + i * V, r);
+    } else {
+#pragma unroll
+      for (int k = 0; k < V; ++k) m[k] = fmaxf(m[k] + bv[k], 0.f);
+      store_vec(y + i * V, m);
+    }
+  }
+}
+
 }  // namespace
 }  // namespace dskd
 
 using namespace dskd;
+
+extern "C" int dskd_bias_relu_maxpool(const void* x, const void* bias, void* y, int B, int H, int W, int C, int dtype,
+                                      void* stream) {
+  if (dtype != DSKD_DTYPE_F32 && dtype != DSKD_DTYPE_BF16)
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_bias_relu_maxpool: unknown dtype %d", dtype);
+  const int V = dtype == DSKD_DTYPE_F32 ? 4 : 8;
+  if (!x || !bias || !y || B < 0 || H <= 0 || W <= 0 || C <= 0 || C % V != 0)
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_bias_relu_maxpool: need C %% %d == 0 and positive sizes (B=%d, H=%d, W=%d, C=%d)", V,
+                B, H, W, C);
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(y)) & 15)
+    return fail(DSKD_ERR_INVALID_ARG, "dskd_bias_relu_maxpool: pointers must be 16-byte aligned");
+  if (B == 0) return DSKD_OK;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long long nvec = (long long)B * Ho * Wo * (C / V);
+  const long long want = (nvec + 255) / 256;
+  const dim3 grid((unsigned)(want < 65536 ? want : 65536)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DSKD_DTYPE_F32)
+    hipLaunchKernelGGL(bias_relu_maxpool_kernel<float>, grid, block, 0, st, (const float*)x, (const float*)bias, (float*)y, H, W,
+                       Ho, Wo, C, nvec);
+  else
+    hipLaunchKernelGGL(bias_relu_maxpool_kernel<__bf16>, grid, block, 0, st, (const __bf16*)x, (const __bf16*)bias, (__bf16*)y, H,
+                       W, Ho, Wo, C, nvec);
+  return check_launch("dskd_bias_relu_maxpool");
+}
 
 extern "C" int dskd_bias_act(void* x, const void* bias, const void* identity, int64_t n, int C, int relu,
                              int dtype, void* stream) {

@@ -508,7 +508,10 @@ __device__ __forceinline__ void pull_tile(int vb, const float* __restrict__ loc,
 
 // 8 waves per SIMD = two 16-wave workgroups per CU (64 VGPRs, ~75 KB of LDS each)
 template <typename T, int NT, int R>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void msda_bwd_pull_kernel(
+#ifndef DSKD_PULL_WPE
+#define DSKD_PULL_WPE 8      // A/B builds: -DDSKD_PULL_WPE=6 lets the compiler take 80 VGPRs (no spills) at three workgroups per CU
+#endif
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSKD_PULL_WPE, 8))) void msda_bwd_pull_kernel(
     const float* __restrict__ loc, const float* __restrict__ attn, const T* __restrict__ grad_out,
     float* __restrict__ grad_value, PullGeom g, FbHeader* hdr, FbEntry* fb, unsigned fb_cap) {
   using P = PT<T>;

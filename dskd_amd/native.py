@@ -43,6 +43,7 @@ _SIGNATURES = {
     "dskd_add_ln_bwd2": (C.c_int, [_vp] * 10 + [C.c_int, _i64, C.c_int, _f32, C.c_uint64, C.c_uint64, _vp, C.c_int, _vp]),
     "dskd_add_pos": (C.c_int, [_vp, _vp, _vp, _i64, _i64, C.c_int, C.c_int, _vp]),
     "dskd_bias_act": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, _vp]),
+    "dskd_bias_relu_maxpool": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 5 + [_vp]),
     "dskd_dropout_fwd": (C.c_int, [_vp, _i64, _f32, C.c_uint64, C.c_uint64, _vp, C.c_int, _vp]),
     "dskd_relu_dropout_bwd": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _i64, C.c_int, _f32, C.c_int, _vp]),
     "dskd_colsum": (C.c_int, [_vp, _vp, C.c_int, _i64, C.c_int, C.c_int, _vp]),
@@ -1783,6 +1784,25 @@ def bias_act(x: torch.Tensor, bias: torch.Tensor, identity: Optional[torch.Tenso
             y = y + identity
         return torch.relu_(y) if relu else y
     return _BiasActFunction.apply(x, bias.contiguous(), identity, relu)
+
+
+def bias_relu_maxpool_ok(x: torch.Tensor, bias: torch.Tensor) -> bool:
+    vec = 8 if x.dtype == torch.bfloat16 else 4
+    return (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16) and x.shape[1] % vec == 0
+            and x.is_contiguous(memory_format=torch.channels_last) and bias.dtype == x.dtype and bias.numel() == x.shape[1]
+            and not (torch.is_grad_enabled() and (x.requires_grad or bias.requires_grad)))
+
+
+def bias_relu_maxpool(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """``max_pool2d(relu(x + bias[None, :, None, None]), 3, 2, 1)`` in one pass for a convolution output that needs no
+    gradient (the stem of the teacher and of a student with frozen_stages >= 0; resnet.py:633-640).  Raw op: no autograd."""
+    _need_gpu(x, bias)
+    B, Cc, H, W = x.shape
+    y = torch.empty((B, Cc, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    rc = load().dskd_bias_relu_maxpool(x.data_ptr(), bias.contiguous().data_ptr(), y.data_ptr(), B, H, W, Cc,
+                                       DTYPE_BF16 if x.dtype == torch.bfloat16 else DTYPE_F32, _stream(x))
+    _check(rc, "dskd_bias_relu_maxpool")
+    return y
 
 
 # --------------------------------------------------------------------------- LSAP

@@ -345,6 +345,11 @@ int dskd_add_pos(const void* x, const float* pos, void* q, int64_t rows, int64_t
  * ------------------------------------------------------------------------- */
 int dskd_bias_act(void* x, const void* bias, const void* identity, int64_t n, int C, int relu,
                   int dtype, void* stream);
+/* The stem's tail without gradients: y = maxpool_3x3_s2_p1(relu(x + bias[c])) in ONE pass
+ * (`x = self.relu(x); x = self.maxpool(x)` behind the folded norm1, mmdet/models/backbones/resnet.py:633-640).
+ * x [B, H, W, C] channels_last (the convolution's output WITHOUT bias), y [B, (H-1)/2+1, (W-1)/2+1, C]; bit-identical
+ * with dskd_bias_act(relu) followed by the pooling (rounding and ReLU are monotonic, the bias constant over a window). */
+int dskd_bias_relu_maxpool(const void* x, const void* bias, void* y, int B, int H, int W, int C, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
  * FFN hidden activation (bf16 only).

@@ -685,6 +685,26 @@ def test_bias_act_vs_torch(dtype, with_id, relu, oracle_checker):
     torch.testing.assert_close(y2.float().cpu(), oracle_checker.bias_act(x.float(), b.float(), None, relu), **tol)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 64, 41, 67), (1, 8, 1, 1), (3, 72, 2, 5), (1, 64, 400, 667)])
+def test_bias_relu_maxpool_is_bit_identical_with_the_three_ops(dtype, shape):
+    """dskd_bias_relu_maxpool (the stem's tail without gradients, resnet.py:633-640) against
+    ``max_pool2d(relu(x + bias), 3, 2, 1)`` evaluated by PyTorch on the GPU in the same dtype: bit-identical (rounding and ReLU are
+    monotonic, the bias is constant over a window), odd and even sizes, windows cut by every border; refused where a
+    gradient is needed."""
+    g = torch.Generator().manual_seed(shape[2] * 7 + shape[3])
+    x = (torch.randn(*shape, generator=g) * 3).to(dtype).to(DEV).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(shape[1], generator=g).to(dtype).to(DEV)
+    ref = torch.nn.functional.max_pool2d(torch.relu(x + b.view(1, -1, 1, 1)), 3, 2, 1)
+    assert native.bias_relu_maxpool_ok(x, b)
+    y = native.bias_relu_maxpool(x, b)
+    assert y.shape == ref.shape and y.dtype == dtype and y.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(y, ref)
+    assert not native.bias_relu_maxpool_ok(x.clone().requires_grad_(True), b)
+    assert not native.bias_relu_maxpool_ok(x.contiguous(), b) or x.contiguous().is_contiguous(memory_format=torch.channels_last)
+    assert native.load().dskd_bias_relu_maxpool(x.data_ptr(), b.data_ptr(), y.data_ptr(), 1, 4, 4, 12, native.DTYPE_BF16, None) == -1
+
+
 # ----------------------------------------------------------------------------- LSAP
 def _lsap_device(mats):
     flat = torch.cat([torch.from_numpy(m).reshape(-1) for m in mats]).to(DEV)
