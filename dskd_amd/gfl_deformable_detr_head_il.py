@@ -315,6 +315,11 @@ class GFLDeformableDETRHead_il(nn.Module):
                 mlvl_masks.append(F.interpolate(img_masks[None], size=feat.shape[-2:]).to(torch.bool).squeeze(0))
                 mlvl_positional_encodings.append(self.positional_encoding(mlvl_masks[-1]))
             if full:
+                # no padding anywhere: the sine encoding is a function of the (all-False) mask alone, i.e. the same for every
+                # image -- the encoder gets the table of ONE image and the kernels that add it repeat its rows over the batch
+                # (23 MB instead of 91 MB per read at B=4; its gradient is summed over the batch where it is formed)
+                if mlvl_feats[0].is_cuda:
+                    mlvl_positional_encodings = [pe[:1].contiguous() for pe in mlvl_positional_encodings]
                 if len(pe_cache) >= 16:                   # bounded; an entry a graph was captured on is pinned by that graph
                     pe_cache.pop(next(iter(pe_cache)))
                 pe_cache[key] = (mlvl_masks, mlvl_positional_encodings)

@@ -607,7 +607,7 @@ class _AddLNFunction(torch.autograd.Function):
             if pos_rows == rows and dq.dtype == ctx.pos_dtype:
                 dpos = dq.view(pos_shape)          # nothing to sum: hand the gradient over as it is (a view, no pass)
             else:
-                dpos = dq.view(rows // pos_rows, pos_rows, D).sum(0, dtype=torch.float32).view(pos_shape)
+                dpos = dq.view(rows // pos_rows, pos_rows, D).sum(0, dtype=ctx.pos_dtype).view(pos_shape)    # (f32 accumulation inside)
         return (dres if dh is None else dh), dres, dgb[0].to(gdtype), dgb[1].to(gdtype), dpos, None, None, None, None
 
 
@@ -632,7 +632,7 @@ class _AddPosFunction(torch.autograd.Function):
             if pos_rows == rows:
                 dpos = (dq if dq.dtype == pos_dtype else dq.to(pos_dtype)).view(pos_shape)
             else:
-                dpos = dq.reshape(rows // pos_rows, pos_rows, D).sum(0, dtype=torch.float32).to(pos_dtype).view(pos_shape)
+                dpos = dq.reshape(rows // pos_rows, pos_rows, D).sum(0, dtype=pos_dtype).view(pos_shape)
         return (dq if ctx.needs_input_grad[0] else None), dpos
 
 

@@ -1322,6 +1322,8 @@ class DeformableDetrTransformer(nn.Module):
             feat_flatten.append(feat.flatten(2).transpose(1, 2))
             if not all_valid:
                 mask_flatten.append(mask.flatten(1))
+            # (a positional encoding with batch size 1 -- the head's, for an un-padded batch -- makes a [1, sum HW, C] table:
+            # the kernels that add it repeat its rows over the batch)
             lvl_pos_embed_flatten.append(_AddLevelEmbed.apply(pos_embed.flatten(2).transpose(1, 2), self.level_embeds[lvl]))
         feat_flatten = torch.cat(feat_flatten, 1)
         mask_flatten = torch.cat(mask_flatten, 1) if not all_valid else None
