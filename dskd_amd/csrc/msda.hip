@@ -1718,18 +1718,17 @@ __global__ __launch_bounds__(1024) void msda_bwd_win_kernel(
             aux.y = y - yf;
             const int wwl = lc.x, whl = lc.y;
             const int wx = x0 - lc.z, wy = y0 - lc.w;
-            if (lvl >= fw.lv0 && wx >= 0 && wx + 1 < wwl && wy >= 0 && wy + 1 < whl) {
-              const int pb = (s_tab[4 * lvl + 3].x + wy * wwl + wx) * PIXB;
-              off = i32x4{pb, pb + PIXB, pb + wwl * PIXB, pb + wwl * PIXB + PIXB};
-            } else {      // left the window: global byte offsets, flagged by the sign bit
-              const bool vx0 = x0 >= 0, vx1 = x0 + 1 <= W - 1;
-              const bool vy0 = y0 >= 0, vy1 = y0 + 1 <= H - 1;
-              const int r00 = (st + y0 * W + x0) * ROWB;
-              off.x = ((vy0 && vx0) ? r00 : kOOB) | kFwdSign;
-              off.y = ((vy0 && vx1) ? r00 + ROWB : kOOB) | kFwdSign;
-              off.z = ((vy1 && vx0) ? r00 + W * ROWB : kOOB) | kFwdSign;
-              off.w = ((vy1 && vx1) ? r00 + W * ROWB + ROWB : kOOB) | kFwdSign;
-            }
+            // (selects, not a lane branch: with the two forms in separate blocks the allocator spilled eight registers of the
+            // staging arithmetic -- 45 MB of scratch written back per launch, profiles/r04_msda_pmc_hbm_B4_bf16.json)
+            const bool inw = lvl >= fw.lv0 && wx >= 0 && wx + 1 < wwl && wy >= 0 && wy + 1 < whl;
+            const int pb = (s_tab[4 * lvl + 3].x + wy * wwl + wx) * PIXB;
+            const bool vx0 = x0 >= 0, vx1 = x0 + 1 <= W - 1;
+            const bool vy0 = y0 >= 0, vy1 = y0 + 1 <= H - 1;
+            const int r00 = (st + y0 * W + x0) * ROWB;       // left the window: global byte offsets, flagged by the sign bit
+            off.x = inw ? pb : (((vy0 && vx0) ? r00 : kOOB) | kFwdSign);
+            off.y = inw ? pb + PIXB : (((vy0 && vx1) ? r00 + ROWB : kOOB) | kFwdSign);
+            off.z = inw ? pb + wwl * PIXB : (((vy1 && vx0) ? r00 + W * ROWB : kOOB) | kFwdSign);
+            off.w = inw ? pb + wwl * PIXB + PIXB : (((vy1 && vx1) ? r00 + W * ROWB + ROWB : kOOB) | kFwdSign);
           }
         }
         s_off[ql * kFwdHS + part] = off;
