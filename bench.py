@@ -443,7 +443,7 @@ def main():
             if ddp1:
                 mode += "(1-rank rccl)"
         optimizer = build_optimizer(model, cfg.optimizer[0])
-        ahead = None if (args.no_teacher_ahead or args.backbone == "gfl_r50") else model.teacher_ahead()
+        ahead = None if args.no_teacher_ahead else model.teacher_ahead()
         if ahead is not None:
             ahead.use_graphs = not args.no_teacher_graph
             mode += "+teacher_ahead" + ("(hipgraph)" if ahead.use_graphs else "")

@@ -82,7 +82,7 @@ class TeacherAhead:
         det = self.det
         with torch.no_grad(), torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
             feats = det.teacher_model.extract_feat(img)
-            outs = det.teacher_model.bbox_head.forward(feats, img_metas)
+            outs = det._teacher_heads(feats, img_metas)
         return feats, outs
 
     @staticmethod
@@ -205,7 +205,8 @@ class TeacherAhead:
                 bboxes = [r[0][:, 0:4] for r in pred]
                 scores = [r[0][:, 4:5].flatten() for r in pred]
                 labels, logits = [r[1] for r in pred], [r[2] for r in pred]
-                keepid = torch.cat([r[3] + i * outs[0].shape[2] for i, r in enumerate(pred)])
+                stride = det._keepid_stride(outs)
+                keepid = torch.cat([r[3] + i * stride for i, r in enumerate(pred)])
             main.wait_stream(self.stream)
             # allocated on the side stream, consumed on the main one: keep the allocator from
             # recycling them before the main stream is done
@@ -353,7 +354,7 @@ class DeformableDETR_il(nn.Module):
         assert self.has_teacher, "no teacher model is set"
         with torch.no_grad():
             neck_feat = self.teacher_model.extract_feat(img)
-            head_outs = self.teacher_model.bbox_head.forward(neck_feat, img_metas)
+            head_outs = self._teacher_heads(neck_feat, img_metas)
             cfg = self.teacher_test_cfg if self.teacher_test_cfg is not None else self.test_cfg
             pred_outs = self.teacher_model.bbox_head.get_bboxes(*head_outs, img_metas=img_metas, rescale=False,
                                                                 cfg=cfg, need_logits=True)
@@ -363,8 +364,18 @@ class DeformableDETR_il(nn.Module):
             pred_logits = [r[2].detach() for r in pred_outs]
             pred_keepid = [r[3].detach() for r in pred_outs]
             if cat_keepid:
-                pred_keepid = torch.cat([pk + i * head_outs[0].shape[2] for i, pk in enumerate(pred_keepid)])
+                stride = self._keepid_stride(head_outs)
+                pred_keepid = torch.cat([pk + i * stride for i, pk in enumerate(pred_keepid)])
         return neck_feat, head_outs, pred_keepid, pred_logits, pred_labels, pred_scores, pred_bboxes
+
+    # the two places where the teacher pipeline (inline here, one batch ahead in TeacherAhead) depends on the head's kind
+    def _teacher_heads(self, feats, img_metas):
+        return self.teacher_model.bbox_head.forward(feats, img_metas)
+
+    @staticmethod
+    def _keepid_stride(head_outs):
+        """Predictions per image: image i's kept indices are offset by i times this in the concatenated ``pred_keepid``."""
+        return head_outs[0].shape[2]
 
     def __deepcopy__(self, memo):
         from .utils import deepcopy_without

@@ -485,24 +485,15 @@ class GFL(DeformableDETR_il):
     detector (``set_teacher`` / ``out_teacher`` / ``teacher_info``), so that tools/train_increment.py drives it like
     the transformer detector."""
 
-    def out_teacher(self, img, img_metas, cat_keepid=True):
-        assert self.has_teacher, "no teacher model is set"
-        with torch.no_grad():
-            feats = self.teacher_model.extract_feat(img)
-            outs = self.teacher_model.bbox_head.forward(feats)
-            cfg = self.teacher_test_cfg if self.teacher_test_cfg is not None else self.test_cfg
-            pred = self.teacher_model.bbox_head.get_bboxes(*outs, img_metas=img_metas, rescale=False, cfg=cfg, need_logits=True)
-            bboxes = [r[0][:, 0:4] for r in pred]
-            scores = [r[0][:, 4] for r in pred]
-            labels, logits = [r[1] for r in pred], [r[2] for r in pred]
-            n_prior = sum(int(c.shape[-2] * c.shape[-1]) for c in outs[0])
-            keepid = [r[3] for r in pred]
-            if cat_keepid:
-                keepid = torch.cat([k + i * n_prior for i, k in enumerate(keepid)])
-        return feats, outs, keepid, logits, labels, scores, bboxes
+    # out_teacher and the one-batch-ahead pipeline (TeacherAhead: the teacher forward as a hipGraph replay on a second stream,
+    # its decode + NMS -- host round trips -- waiting for that stream only) are the transformer detector's; the head's kind
+    # enters through these two
+    def _teacher_heads(self, feats, img_metas):
+        return self.teacher_model.bbox_head.forward(feats)
 
-    def teacher_ahead(self):
-        raise NotImplementedError("the ahead-of-time teacher pipeline is built for the transformer detector")
+    @staticmethod
+    def _keepid_stride(head_outs):
+        return sum(int(c.shape[-2] * c.shape[-1]) for c in head_outs[0])      # priors per image (one per location)
 
     def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None, teacher_info=None):
         for m in img_metas:

@@ -886,3 +886,41 @@ def test_gfl_distillation_step_on_gpu_vs_cpu_oracle(oracle_checker):
                                                   pred_labels=None)))
     out["loss"].backward()
     assert out["log_vars"]["loss_fg_feature"] > 0 and all(v == v for v in out["log_vars"].values())
+
+
+def test_gfl_teacher_one_batch_ahead_matches_inline_teacher():
+    """BASELINE.json configs[4]: the GFL detector's frozen teacher run one batch ahead on a second stream -- eagerly first,
+    as hipGraph replays once the batch signature has repeated -- hands over what the inline ``out_teacher`` computes
+    (pyramid features and head outputs to rounding: MIOpen may pick another algorithm; the decode + NMS through its sizes
+    and the per-image offsets of ``pred_keepid``), with a NEW image every step."""
+    cfg = Config.fromfile(os.path.join(ROOT, "configs", "dskd_gfl_r50_fpn_40_40.py"))
+    torch.manual_seed(4)
+    m = build_detector(cfg.model)
+    m.init_weights()
+    t = copy.deepcopy(m)
+    g = torch.Generator().manual_seed(8)
+    with torch.no_grad():
+        for p in t.parameters():
+            p.add_(torch.randn(p.shape, generator=g) * 2e-2)
+    m.set_teacher(model=t)
+    m.to("cuda:0").train()
+    B, H, W = 2, 192, 256
+    metas = [dict(img_shape=(H, W, 3), pad_shape=(H, W, 3), scale_factor=1.0, batch_input_shape=(H, W)) for _ in range(B)]
+    ahead = m.teacher_ahead()
+    ahead.use_graphs, ahead.graph_warmup = True, 2
+    for step in range(6):
+        img = torch.randn(B, 3, H, W, generator=g).to("cuda:0")
+        feats, outs, keepid, logits, labels, scores, bboxes = m.out_teacher(img, metas)
+        ahead.launch(img, metas)
+        ti = ahead.finish(img, metas)
+        for a, b in zip(ti["neck_feats"], feats):
+            torch.testing.assert_close(a, b, rtol=1e-3, atol=1e-3)
+        for a, b in zip(list(ti["head_outs"][0]) + list(ti["head_outs"][1]), list(outs[0]) + list(outs[1])):
+            torch.testing.assert_close(a, b, rtol=1e-3, atol=1e-3)
+        assert [x.shape[1] for x in ti["pred_bboxes"]] == [4] * B and len(ti["pred_labels"]) == B
+        n_prior = sum(int(c.shape[-2] * c.shape[-1]) for c in outs[0])
+        assert m._keepid_stride(outs) == n_prior
+        if ti["pred_keepid"].numel():
+            assert int(ti["pred_keepid"].max()) < B * n_prior
+    entries = [v for v in ahead._graphs.values() if v]
+    assert len(entries) == 1 and len(entries[0]) == 2        # captured, verified against eager, double-buffered
