@@ -95,6 +95,11 @@ def _weight_grad(g2, x2, chunk, dtype):
     one bmm + an f32 sum of the partial products, or one GEMM)."""
     if native.gemm_tn_ok(g2, x2):
         return native.gemm_tn_bf16(g2, x2) if dtype == torch.bfloat16 else native.gemm_tn(g2, x2).to(dtype)
+    if chunk is None and g2.is_cuda and g2.shape[0] >= 2048 and g2.is_contiguous() and x2.is_contiguous():
+        # mid-size inputs with an output the split-K kernel does not take (the head's class / box branches: [7 200, 80 | 68 | 4]^T
+        # [7 200, 256]): as ONE GEMM the library runs them on a handful of workgroups -- 46-73 us of kernel time against 16-22
+        # for token chunks as bmm batches + the sum of the partial products (tools/prof/cls_dw_bench.py)
+        chunk = _token_chunk(g2.shape[0], g2.shape[1] * x2.shape[1])
     if chunk is None:
         return (g2.t() @ x2).to(dtype)
     nb = x2.shape[0] // chunk
